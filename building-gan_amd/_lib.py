@@ -1,0 +1,91 @@
+"""ctypes binding of csrc/libbgan_hip.so (declared in include/bgan.h).
+
+The library is the only compute path: if it is missing or a call fails, an exception is raised;
+nothing here falls back to PyTorch or to the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbgan_hip.so")
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int32
+_f = C.c_float
+_int = C.c_int
+
+# name -> argument types (all functions return int)
+SIGNATURES = {
+    "bg_plan_csr": [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p],
+    "bg_plan_segptr": [_p, _i64, _i64, _p, _p, _p],
+    "bg_plan_floor_level": [_p, _p, _i64, _i64, _p, _p, _p],
+    "bg_plan_counts": [_p, _i64, _p, _p],
+    "bg_plan_chunks": [_p, _i64, _i32, _p, _p],
+    "bg_spmm_f32": [_p, _i64, _p, _p, _p, _p, _p, _int, _p, _int, _p, _i64, _i64, _i64, _p],
+    "bg_segreduce_sum_f32": [_p, _i64, _p, _p, _p, _p, _p, _int, _p, _i32, _i64, _p, _p, _i64, _i64, _i64, _p],
+    "bg_segmax_f32": [_p, _i64, _p, _p, _p, _i32, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _p],
+    "bg_gather_arg_f32": [_p, _i64, _p, _p, _i64, _i64, _i64, _p],
+    "bg_scatter_arg_f32": [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "bg_sddmm_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p],
+    "bg_cross_logits_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p],
+    "bg_cross_logits_bwd_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _p, _i32, _i64, _i64, _p],
+    "bg_seg_gumbel_softmax_f32": [_p, _p, _p, _f, _p, _p, _p, _i64, _p],
+    "bg_seg_softmax_bwd_f32": [_p, _p, _p, _f, _p, _i64, _p],
+    "bg_seg_argmax_f32": [_p, _p, _p, _i64, _p],
+    "bg_gemm_f32": [_int, _int, _i64, _i64, _int, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _int, _f, _p, _i64, _p],
+    "bg_gemm_tn_splitk_f32": [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i32, _p],
+    "bg_colsum_f32": [_p, _i64, _i64, _i64, _p, _i32, _p, _p],
+    "bg_adam_f32": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i32, _p],
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class BganError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the shared library once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BganError(f"{LIB_PATH} not found: build it with `make -C building-gan_amd/csrc` "
+                        "(or __graft_entry__.build()); there is no fallback path")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.bg_version.restype = C.c_int
+    lib.bg_error_string.restype = C.c_char_p
+    lib.bg_error_string.argtypes = [C.c_int]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().bg_error_string(rc).decode()
+        raise BganError(f"{what} failed with code {rc}: {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise BganError(f"{what}: tensor must live on the GPU (got {t.device}); the HIP library is the only "
+                        "compute path of building-gan_amd")

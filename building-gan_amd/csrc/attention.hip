@@ -1,0 +1,217 @@
+// Voxel -> program cross attention: tanh logits over cross edges (CSR by voxel), the segment
+// Gumbel-softmax pointer with its first-index arg-max, and their backward kernels.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxCPL = 8;   // channels per lane: H <= 512
+
+// One wave per voxel.  Lane l owns channels l, l+64, ... of the voxel row; every cross edge of
+// the voxel costs one program-row read (L2-resident: a story has a handful of program nodes).
+template <int CPL>
+__global__ __launch_bounds__(256) void k_cross_logits(const float* __restrict__ A, int64_t lda,
+                                                      const float* __restrict__ B, int64_t ldb,
+                                                      const float* __restrict__ theta,
+                                                      const int32_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ col,
+                                                      float* __restrict__ att, int64_t n_vox) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    float th[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) th[j] = theta[lane + 64 * j];
+    for (int64_t v = wave_id; v < n_vox; v += n_waves) {
+        float av[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) av[j] = A[v * lda + lane + 64 * j];
+        const int32_t b = rowptr[v], e = rowptr[v + 1];
+        for (int32_t k = b; k < e; ++k) {
+            const float* bp = B + (int64_t)col[k] * ldb;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) acc = fmaf(th[j], tanhf(av[j] + bp[lane + 64 * j]), acc);
+            acc = bg_wave_sum(acc);
+            if (lane == 0) att[k] = acc;
+        }
+    }
+}
+
+template <int CPL>
+__global__ __launch_bounds__(256) void k_cross_logits_bwd(const float* __restrict__ A, int64_t lda,
+                                                          const float* __restrict__ B, int64_t ldb,
+                                                          const float* __restrict__ theta,
+                                                          const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ col,
+                                                          const float* __restrict__ g,
+                                                          float* __restrict__ dpre, float* __restrict__ dA, int64_t ldda,
+                                                          float* __restrict__ dtheta_partial, int64_t n_vox, int H) {
+    __shared__ float red[4][64 * kMaxCPL];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    float th[CPL], dth[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { th[j] = theta[lane + 64 * j]; dth[j] = 0.f; }
+    for (int64_t v = wave_id; v < n_vox; v += n_waves) {
+        float av[CPL], da[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) { av[j] = A[v * lda + lane + 64 * j]; da[j] = 0.f; }
+        const int32_t b = rowptr[v], e = rowptr[v + 1];
+        for (int32_t k = b; k < e; ++k) {
+            const float* bp = B + (int64_t)col[k] * ldb;
+            const float gk = g[k];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                float t = tanhf(av[j] + bp[lane + 64 * j]);
+                float d = gk * th[j] * (1.f - t * t);
+                dpre[(int64_t)k * H + lane + 64 * j] = d;
+                da[j] += d;
+                dth[j] = fmaf(gk, t, dth[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) dA[v * ldda + lane + 64 * j] = da[j];
+    }
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) red[wave][lane + 64 * j] = dth[j];
+    __syncthreads();
+    for (int h = threadIdx.x; h < H; h += 256)
+        dtheta_partial[(int64_t)blockIdx.x * H + h] = red[0][h] + red[1][h] + red[2][h] + red[3][h];
+}
+
+// One thread per segment; segments are short (program nodes of one story).
+__global__ void k_seg_gumbel_softmax(const float* __restrict__ att, const float* __restrict__ expn,
+                                     const int32_t* __restrict__ rowptr, float tau,
+                                     float* __restrict__ soft, float* __restrict__ hard,
+                                     int32_t* __restrict__ arg, int64_t n_seg) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_seg) return;
+    const int32_t b = rowptr[v], e = rowptr[v + 1];
+    if (b >= e) { arg[v] = -1; return; }
+    float m = -3.402823466e+38f;
+    for (int32_t k = b; k < e; ++k) {
+        float y = (att[k] + (-logf(expn[k]))) / tau;
+        soft[k] = y;                       // stash y
+        m = fmaxf(m, y);
+    }
+    float s = 0.f;
+    for (int32_t k = b; k < e; ++k) {
+        float ex = expf(soft[k] - m);
+        soft[k] = ex;
+        s += ex;
+    }
+    const float den = s + 1e-16f;
+    float best = -3.402823466e+38f; int32_t ba = b;
+    for (int32_t k = b; k < e; ++k) {
+        float o = soft[k] / den;
+        soft[k] = o;
+        if (o > best) { best = o; ba = k; }
+    }
+    arg[v] = ba;
+    for (int32_t k = b; k < e; ++k) {
+        float o = soft[k];
+        float h = (k == ba) ? 1.f : 0.f;
+        hard[k] = (h - o) + o;
+    }
+}
+
+__global__ void k_seg_softmax_bwd(const float* __restrict__ soft, const float* __restrict__ g,
+                                  const int32_t* __restrict__ rowptr, float tau,
+                                  float* __restrict__ d_att, int64_t n_seg) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_seg) return;
+    const int32_t b = rowptr[v], e = rowptr[v + 1];
+    float dot = 0.f;
+    for (int32_t k = b; k < e; ++k) dot = fmaf(soft[k], g[k], dot);
+    for (int32_t k = b; k < e; ++k) d_att[k] = soft[k] * (g[k] - dot) / tau;
+}
+
+__global__ void k_seg_argmax(const float* __restrict__ logit, const int32_t* __restrict__ rowptr,
+                             int32_t* __restrict__ arg, int64_t n_seg) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_seg) return;
+    const int32_t b = rowptr[v], e = rowptr[v + 1];
+    float best = -3.402823466e+38f; int32_t ba = -1;
+    for (int32_t k = b; k < e; ++k) {
+        float o = logit[k];
+        if (o > best || ba < 0) { best = o; ba = k; }
+    }
+    arg[v] = ba;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bg_cross_logits_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* theta,
+                        const int32_t* rowptr, const int32_t* col, float* att,
+                        int64_t n_vox, int64_t H, bgStream stream) {
+    if (n_vox < 0 || H <= 0) return BG_ERR_ARG;
+    if (n_vox == 0) return BG_OK;
+    if (!a || !b || !theta || !rowptr || !col || !att || lda < H || ldb < H) return BG_ERR_ARG;
+    if (H % 64 != 0 || H > 64 * kMaxCPL) return BG_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = bg_grid_for(n_vox, 4, 256 * 16);
+    switch (H / 64) {
+        case 1: k_cross_logits<1><<<grid, 256, 0, s>>>(a, lda, b, ldb, theta, rowptr, col, att, n_vox); break;
+        case 2: k_cross_logits<2><<<grid, 256, 0, s>>>(a, lda, b, ldb, theta, rowptr, col, att, n_vox); break;
+        case 4: k_cross_logits<4><<<grid, 256, 0, s>>>(a, lda, b, ldb, theta, rowptr, col, att, n_vox); break;
+        case 8: k_cross_logits<8><<<grid, 256, 0, s>>>(a, lda, b, ldb, theta, rowptr, col, att, n_vox); break;
+        default: return BG_ERR_SHAPE;
+    }
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_cross_logits_bwd_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* theta,
+                            const int32_t* rowptr, const int32_t* col, const float* g,
+                            float* dpre, float* da, int64_t ldda, float* dtheta_partial, int32_t n_blocks,
+                            int64_t n_vox, int64_t H, bgStream stream) {
+    if (n_vox < 0 || H <= 0 || n_blocks <= 0) return BG_ERR_ARG;
+    if (!a || !b || !theta || !rowptr || !col || !g || !dpre || !da || !dtheta_partial) return BG_ERR_ARG;
+    if (lda < H || ldb < H || ldda < H) return BG_ERR_ARG;
+    if (H % 64 != 0 || H > 64 * kMaxCPL) return BG_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    switch (H / 64) {
+        case 1: k_cross_logits_bwd<1><<<n_blocks, 256, 0, s>>>(a, lda, b, ldb, theta, rowptr, col, g, dpre, da, ldda, dtheta_partial, n_vox, (int)H); break;
+        case 2: k_cross_logits_bwd<2><<<n_blocks, 256, 0, s>>>(a, lda, b, ldb, theta, rowptr, col, g, dpre, da, ldda, dtheta_partial, n_vox, (int)H); break;
+        case 4: k_cross_logits_bwd<4><<<n_blocks, 256, 0, s>>>(a, lda, b, ldb, theta, rowptr, col, g, dpre, da, ldda, dtheta_partial, n_vox, (int)H); break;
+        case 8: k_cross_logits_bwd<8><<<n_blocks, 256, 0, s>>>(a, lda, b, ldb, theta, rowptr, col, g, dpre, da, ldda, dtheta_partial, n_vox, (int)H); break;
+        default: return BG_ERR_SHAPE;
+    }
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_seg_gumbel_softmax_f32(const float* att, const float* expn, const int32_t* rowptr, float tau,
+                              float* soft, float* hard, int32_t* arg, int64_t n_seg, bgStream stream) {
+    if (n_seg < 0 || tau == 0.f) return BG_ERR_ARG;
+    if (n_seg == 0) return BG_OK;
+    if (!att || !expn || !rowptr || !soft || !hard || !arg) return BG_ERR_ARG;
+    k_seg_gumbel_softmax<<<bg_grid_for(n_seg, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(att, expn, rowptr, tau, soft, hard, arg, n_seg);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_seg_softmax_bwd_f32(const float* soft, const float* g, const int32_t* rowptr, float tau,
+                           float* d_att, int64_t n_seg, bgStream stream) {
+    if (n_seg < 0 || tau == 0.f) return BG_ERR_ARG;
+    if (n_seg == 0) return BG_OK;
+    if (!soft || !g || !rowptr || !d_att) return BG_ERR_ARG;
+    k_seg_softmax_bwd<<<bg_grid_for(n_seg, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(soft, g, rowptr, tau, d_att, n_seg);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_seg_argmax_f32(const float* logit, const int32_t* rowptr, int32_t* arg, int64_t n_seg, bgStream stream) {
+    if (n_seg < 0) return BG_ERR_ARG;
+    if (n_seg == 0) return BG_OK;
+    if (!logit || !rowptr || !arg) return BG_ERR_ARG;
+    k_seg_argmax<<<bg_grid_for(n_seg, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(logit, rowptr, arg, n_seg);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+}  // extern "C"

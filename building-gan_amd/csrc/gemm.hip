@@ -1,0 +1,347 @@
+// Dense fp32 products on the matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32 fma chains).
+//
+//   C = epilogue( sum_s opA(A_s) * opB(B)[koff_s : koff_s + K_s, :] )
+//
+// A workgroup of 4 waves owns a BM x BN tile of C; the K loop walks 32-deep steps over the
+// (up to four) A segments, i.e. torch.cat((A_0, A_1, ..), -1) is never materialised.  Operand
+// tiles are staged global -> registers -> LDS (double buffered):
+//   * K-contiguous operand  (A[M,K], nn.Linear weight W[N,K]):  LDS image [row][32+4], a lane reads
+//     its 4 consecutive k with one ds_read_b128 (pitch 36 floats is conflict-free);
+//   * K-strided operand     (A^T stored [K,M], B stored [K,N]): LDS image [k][rows+4], ds_read_b32.
+// Both feed the same k order to the MFMA: step j of an 8-deep group multiplies k = 8g+j (lanes
+// 0-31) and k = 8g+4+j (lanes 32-63) -- a permutation of k that both operands share.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int KC_PITCH = BK + 4;
+
+struct GemmArgs {
+    const float* A[4]; int64_t lda[4]; int64_t Ks[4]; int n_seg;
+    const float* B; int64_t ldb;
+    float* C; int64_t ldc;
+    const float* bias; const float* row_scale; int act; float slope;
+    const float* residual; int64_t ldr;
+    int64_t M, N;
+    int total_steps;      // sum over segments of ceil(K_s / 32)
+    int steps_per_split;  // == total_steps when not split
+    float* partial;       // split-K: [splits, M, N]
+};
+
+template <int ROWS, bool KC, bool VEC>
+struct Stage {
+    static constexpr int NF4 = ROWS * BK / 4 / 256;   // float4 per thread per tile
+    float4 r[NF4];
+
+    // tile origin: row0 (in the operand's non-reduction dim), k0 (inside the segment, length K)
+    __device__ __forceinline__ void load(const float* base, int64_t ld, int64_t row0, int64_t n_rows,
+                                         int64_t k0, int64_t K) {
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            int f = threadIdx.x + 256 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KC) {
+                int row = f / (BK / 4), kv = f % (BK / 4);
+                int64_t gr = row0 + row, gk = k0 + 4 * kv;
+                if (gr < n_rows) {
+                    const float* p = base + gr * ld + gk;
+                    if (VEC) {
+                        if (gk < K) v = bg_ld4(p);
+                    } else {
+                        if (gk + 0 < K) v.x = p[0];
+                        if (gk + 1 < K) v.y = p[1];
+                        if (gk + 2 < K) v.z = p[2];
+                        if (gk + 3 < K) v.w = p[3];
+                    }
+                }
+            } else {
+                int k = f / (ROWS / 4), r4 = f % (ROWS / 4);
+                int64_t gk = k0 + k, gr = row0 + 4 * r4;
+                if (gk < K) {
+                    const float* p = base + gk * ld + gr;
+                    if (VEC) {
+                        if (gr < n_rows) v = bg_ld4(p);
+                    } else {
+                        if (gr + 0 < n_rows) v.x = p[0];
+                        if (gr + 1 < n_rows) v.y = p[1];
+                        if (gr + 2 < n_rows) v.z = p[2];
+                        if (gr + 3 < n_rows) v.w = p[3];
+                    }
+                }
+            }
+            r[i] = v;
+        }
+    }
+
+    __device__ __forceinline__ void store(float* lds) const {
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            int f = threadIdx.x + 256 * i;
+            if (KC) {
+                int row = f / (BK / 4), kv = f % (BK / 4);
+                bg_st4(lds + row * KC_PITCH + 4 * kv, r[i]);
+            } else {
+                int k = f / (ROWS / 4), r4 = f % (ROWS / 4);
+                bg_st4(lds + k * (ROWS + 4) + 4 * r4, r[i]);
+            }
+        }
+    }
+};
+
+// fragment of one 32-row tile for the 8-deep k group g: 4 values, value j feeds MFMA step j
+template <int ROWS, bool KC>
+__device__ __forceinline__ float4 read_frag(const float* lds, int tile_row0, int g, int r, int h) {
+    if (KC) {
+        return bg_ld4(lds + (tile_row0 + r) * KC_PITCH + 8 * g + 4 * h);
+    } else {
+        const float* p = lds + (8 * g + 4 * h) * (ROWS + 4) + tile_row0 + r;
+        return make_float4(p[0], p[ROWS + 4], p[2 * (ROWS + 4)], p[3 * (ROWS + 4)]);
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, bool VEC, bool SPLIT>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+    constexpr int WM = 2, WN = 2;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_SZ = BM * KC_PITCH, B_SZ = BN * KC_PITCH;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+
+    int step_begin = 0, step_end = g.total_steps;
+    if (SPLIT) {
+        step_begin = blockIdx.z * g.steps_per_split;
+        step_end = min(step_begin + g.steps_per_split, g.total_steps);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    Stage<BM, A_KC, VEC> sa;
+    Stage<BN, B_KC, VEC> sb;
+
+    // step -> (segment, k offset inside the segment, k offset inside the concatenated K)
+    auto locate = [&](int step, int& seg, int64_t& k0, int64_t& koff) {
+        seg = 0; koff = 0;
+        int s = step;
+        while (seg < g.n_seg - 1) {
+            int n = (int)((g.Ks[seg] + BK - 1) / BK);
+            if (s < n) break;
+            s -= n; koff += g.Ks[seg]; ++seg;
+        }
+        k0 = (int64_t)s * BK;
+    };
+    auto fetch = [&](int step) {
+        int seg; int64_t k0, koff;
+        locate(step, seg, k0, koff);
+        sa.load(g.A[seg], g.lda[seg], m0, g.M, k0, g.Ks[seg]);
+        // B rows of this step: concatenated k in [koff + k0, koff + K_seg)
+        const float* bb = B_KC ? g.B + koff : g.B + koff * g.ldb;
+        sb.load(bb, g.ldb, n0, g.N, k0, g.Ks[seg]);
+    };
+
+    if (step_begin < step_end) {
+        fetch(step_begin);
+        sa.store(smem);
+        sb.store(smem + A_SZ);
+    }
+    __syncthreads();
+
+    for (int step = step_begin; step < step_end; ++step) {
+        const int cur = (step - step_begin) & 1;
+        const float* As = smem + cur * (A_SZ + B_SZ);
+        const float* Bs = As + A_SZ;
+        const bool more = step + 1 < step_end;
+        if (more) fetch(step + 1);
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, A_KC>(As, (wm * TM + i) * 32, kg, r, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32, kg, r, h);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) {
+            float* An = smem + (cur ^ 1) * (A_SZ + B_SZ);
+            sa.store(An);
+            sb.store(An + A_SZ);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds rows (q&3) + 8*(q>>2) + 4*h, column r of each 32x32 tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t col = n0 + (wn * TN + j) * 32 + r;
+            if (col >= g.N) continue;
+            const float bv = (!SPLIT && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t row = m0 + (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (row >= g.M) continue;
+                float v = acc[i][j][q];
+                if (SPLIT) {
+                    g.partial[((int64_t)blockIdx.z * g.M + row) * g.N + col] = v;
+                } else {
+                    v += bv;
+                    if (g.row_scale) v *= g.row_scale[row];
+                    if (g.act == BG_ACT_LEAKY) v = v > 0.f ? v : v * g.slope;
+                    if (g.residual) v += g.residual[row * g.ldr + col];
+                    g.C[row * g.ldc + col] = v;
+                }
+            }
+        }
+}
+
+__global__ void k_splitk_reduce(const float* __restrict__ partial, int splits, int64_t M, int64_t N,
+                                float* __restrict__ C, int64_t ldc) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * N) return;
+    float acc = 0.f;
+    for (int z = 0; z < splits; ++z) acc += partial[(int64_t)z * M * N + t];
+    C[(t / N) * ldc + (t % N)] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ x, int64_t ldx, int64_t M, int64_t N,
+                                                        float* __restrict__ partial) {
+    // block b sums rows b, b+grid, ...; thread t owns columns t, t+256, ...
+    for (int64_t n = threadIdx.x; n < N; n += 256) {
+        float acc = 0.f;
+        for (int64_t m = blockIdx.x; m < M; m += gridDim.x) acc += x[m * ldx + n];
+        partial[(int64_t)blockIdx.x * N + n] = acc;
+    }
+}
+
+__global__ void k_colsum_final(const float* __restrict__ partial, int n_blocks, int64_t N, float* __restrict__ out) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int b = 0; b < n_blocks; ++b) acc += partial[(int64_t)b * N + n];
+    out[n] = acc;
+}
+
+template <int BM, int BN, bool SPLIT>
+int launch_gemm(int transA, int transB, bool vec, const GemmArgs& g, int splits, hipStream_t s) {
+    dim3 grid((unsigned)((g.N + BN - 1) / BN), (unsigned)((g.M + BM - 1) / BM), (unsigned)splits);
+    const bool akc = !transA, bkc = transB != 0;
+#define BG_GEMM_CASE(AKC, BKC, VEC)                                                     \
+    if (akc == AKC && bkc == BKC && vec == VEC) {                                       \
+        k_gemm<BM, BN, AKC, BKC, VEC, SPLIT><<<grid, 256, 0, s>>>(g);                   \
+        BG_LAUNCH_CHECK();                                                              \
+        return BG_OK;                                                                   \
+    }
+    BG_GEMM_CASE(true, true, true)
+    BG_GEMM_CASE(true, false, true)
+    BG_GEMM_CASE(false, true, true)
+    BG_GEMM_CASE(false, false, true)
+    BG_GEMM_CASE(true, true, false)
+    BG_GEMM_CASE(true, false, false)
+    BG_GEMM_CASE(false, true, false)
+    BG_GEMM_CASE(false, false, false)
+#undef BG_GEMM_CASE
+    return BG_ERR_ARG;
+}
+
+bool operand_vec_ok(const float* p, int64_t ld, bool kc, int64_t K, int64_t rows) {
+    if (!bg_aligned16(p) || ld % 4 != 0) return false;
+    return kc ? (K % 4 == 0) : (rows % 4 == 0);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
+                const float* const* A, const int64_t* lda, const int64_t* Ks,
+                const float* B, int64_t ldb, float* C, int64_t ldc,
+                const float* bias, const float* row_scale, int act, float slope,
+                const float* residual, int64_t ldr, bgStream stream) {
+    if (M < 0 || N < 0 || n_seg < 1 || n_seg > 4 || !A || !lda || !Ks) return BG_ERR_ARG;
+    if (M == 0 || N == 0) return BG_OK;
+    if (!B || !C || ldc < N || (residual && ldr < N)) return BG_ERR_ARG;
+    GemmArgs g{};
+    g.n_seg = n_seg;
+    int64_t Ktot = 0;
+    bool vec = true;
+    int steps = 0;
+    for (int s = 0; s < n_seg; ++s) {
+        if (!A[s] || Ks[s] < 0) return BG_ERR_ARG;
+        if (lda[s] < (transA ? M : Ks[s])) return BG_ERR_ARG;
+        g.A[s] = A[s]; g.lda[s] = lda[s]; g.Ks[s] = Ks[s];
+        vec = vec && operand_vec_ok(A[s], lda[s], !transA, Ks[s], M);
+        // a segment's rows of B start at koff: keep them 16-byte aligned for the vector path
+        if (transB && (Ktot % 4 != 0)) vec = false;
+        Ktot += Ks[s];
+        steps += (int)((Ks[s] + BK - 1) / BK);
+    }
+    if (ldb < (transB ? Ktot : N)) return BG_ERR_ARG;
+    vec = vec && operand_vec_ok(B, ldb, transB != 0, 4, N);
+    for (int s = 0; s < n_seg && transB; ++s) if (Ks[s] % 4 != 0) vec = false;
+    g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.bias = bias; g.row_scale = row_scale; g.act = act; g.slope = slope;
+    g.residual = residual; g.ldr = ldr; g.M = M; g.N = N;
+    g.total_steps = steps; g.steps_per_split = steps; g.partial = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    if (big_tiles >= 256) return launch_gemm<128, 128, false>(transA, transB, vec, g, 1, st);
+    return launch_gemm<64, 64, false>(transA, transB, vec, g, 1, st);
+}
+
+int bg_gemm_tn_splitk_f32(int64_t M, int64_t N, int64_t R, const float* A, int64_t lda,
+                          const float* B, int64_t ldb, float* C, int64_t ldc,
+                          float* partial, int32_t splits, bgStream stream) {
+    if (M < 0 || N < 0 || R < 0 || splits < 1) return BG_ERR_ARG;
+    if (M == 0 || N == 0) return BG_OK;
+    if (!A || !B || !C || !partial || lda < M || ldb < N || ldc < N) return BG_ERR_ARG;
+    GemmArgs g{};
+    g.n_seg = 1; g.A[0] = A; g.lda[0] = lda; g.Ks[0] = R;
+    g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N;
+    g.total_steps = (int)((R + BK - 1) / BK);
+    g.steps_per_split = (g.total_steps + splits - 1) / splits;
+    if (g.steps_per_split < 1) g.steps_per_split = 1;
+    g.partial = partial;
+    bool vec = operand_vec_ok(A, lda, false, R, M) && operand_vec_ok(B, ldb, false, R, N);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_gemm<64, 64, true>(1, 0, vec, g, splits, st);
+    if (rc != BG_OK) return rc;
+    k_splitk_reduce<<<bg_grid_for(M * N, 256, 0x7fffffff), 256, 0, st>>>(partial, splits, M, N, C, ldc);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_colsum_f32(const float* x, int64_t ldx, int64_t M, int64_t N, float* partial, int32_t n_blocks,
+                  float* out, bgStream stream) {
+    if (M < 0 || N < 0 || n_blocks < 1) return BG_ERR_ARG;
+    if (N == 0) return BG_OK;
+    if (!out || !partial || (M > 0 && (!x || ldx < N))) return BG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    k_colsum_partial<<<n_blocks, 256, 0, s>>>(x, ldx, M, N, partial);
+    BG_LAUNCH_CHECK();
+    k_colsum_final<<<bg_grid_for(N, 256), 256, 0, s>>>(partial, n_blocks, N, out);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+}  // extern "C"

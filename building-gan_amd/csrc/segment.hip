@@ -1,0 +1,458 @@
+// Segment kernels: CSR gather-reduce (sum / mean / weighted), long-segment two-phase reductions,
+// segment max with arg, arg gather / scatter, sampled dot products.  HBM-bound: 16-byte gathers,
+// one float4 per lane, rows owned by lane groups (no atomics), slot order = COO order.
+#include "common.h"
+
+namespace {
+
+struct SpmmArgs {
+    const float* x; int64_t ldx;
+    const int32_t* rowptr; const int32_t* col;
+    const float* edge_w; const int32_t* eperm;
+    const float* row_scale; int row_mode;
+    const float* col_scale; int col_mode;
+    float* out; int64_t ldo;
+    int64_t n_rows; int H4;   // H4 = H / 4 float4 columns (<= 64 per launch)
+};
+
+__device__ __forceinline__ float apply_scale(float v, float s, int mode) {
+    return mode == BG_SCALE_MUL ? v * s : (mode == BG_SCALE_DIV ? v / s : v);
+}
+
+// XCD-aware block remap (bijective): consecutive logical blocks stay on one XCD's L2.
+__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nb) {
+    int64_t q = nb >> 3, r = nb & 7, xcd = b & 7, i = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+// LPR lanes own one output row (one float4 each); a wave owns 64/LPR rows.
+template <int LPR, bool GENERAL>
+__global__ __launch_bounds__(256) void k_spmm_vec(SpmmArgs a) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int sub = lane % LPR;
+    const int64_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = (blk * 4 + wave) * RPW + lane / LPR;
+    if (row >= a.n_rows || sub >= a.H4) return;
+    const int32_t b = a.rowptr[row], e = a.rowptr[row + 1];
+    const float* xb = a.x + 4 * sub;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int32_t k = b;
+    if (!GENERAL) {
+        for (; k + 4 <= e; k += 4) {
+            int32_t c0 = a.col[k], c1 = a.col[k + 1], c2 = a.col[k + 2], c3 = a.col[k + 3];
+            float4 v0 = bg_ld4(xb + (int64_t)c0 * a.ldx);
+            float4 v1 = bg_ld4(xb + (int64_t)c1 * a.ldx);
+            float4 v2 = bg_ld4(xb + (int64_t)c2 * a.ldx);
+            float4 v3 = bg_ld4(xb + (int64_t)c3 * a.ldx);
+            acc = bg_add4(acc, v0); acc = bg_add4(acc, v1); acc = bg_add4(acc, v2); acc = bg_add4(acc, v3);
+        }
+        for (; k < e; ++k) acc = bg_add4(acc, bg_ld4(xb + (int64_t)a.col[k] * a.ldx));
+    } else {
+        for (; k < e; ++k) {
+            int32_t c = a.col ? a.col[k] : k;
+            float w = 1.f;
+            if (a.edge_w) w = a.edge_w[a.eperm ? a.eperm[k] : k];
+            if (a.col_mode) w = apply_scale(w, a.col_scale[c], a.col_mode);
+            float4 v = bg_ld4(xb + (int64_t)c * a.ldx);
+            acc = bg_add4(acc, bg_scale4(w, v));
+        }
+    }
+    if (a.row_mode) {
+        float s = a.row_scale[row];
+        acc.x = apply_scale(acc.x, s, a.row_mode); acc.y = apply_scale(acc.y, s, a.row_mode);
+        acc.z = apply_scale(acc.z, s, a.row_mode); acc.w = apply_scale(acc.w, s, a.row_mode);
+    }
+    bg_st4(a.out + row * a.ldo + 4 * sub, acc);
+}
+
+// scalar path: one thread per (row, channel)
+__global__ void k_spmm_scalar(SpmmArgs a, int H) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n_rows * H) return;
+    int64_t row = t / H; int h = (int)(t % H);
+    float acc = 0.f;
+    for (int32_t k = a.rowptr[row]; k < a.rowptr[row + 1]; ++k) {
+        int32_t c = a.col ? a.col[k] : k;
+        float w = 1.f;
+        if (a.edge_w) w = a.edge_w[a.eperm ? a.eperm[k] : k];
+        if (a.col_mode) w = apply_scale(w, a.col_scale[c], a.col_mode);
+        acc += w * a.x[(int64_t)c * a.ldx + h];
+    }
+    if (a.row_mode) acc = apply_scale(acc, a.row_scale[row], a.row_mode);
+    a.out[row * a.ldo + h] = acc;
+}
+
+template <bool GENERAL>
+int launch_spmm_vec(const SpmmArgs& a, hipStream_t s) {
+    int lpr = 1;
+    while (lpr < a.H4) lpr <<= 1;
+    int rpb = 4 * (64 / lpr);
+    int grid = bg_grid_for(a.n_rows, rpb, 0x7fffffff);
+    switch (lpr) {
+        case 1: k_spmm_vec<1, GENERAL><<<grid, 256, 0, s>>>(a); break;
+        case 2: k_spmm_vec<2, GENERAL><<<grid, 256, 0, s>>>(a); break;
+        case 4: k_spmm_vec<4, GENERAL><<<grid, 256, 0, s>>>(a); break;
+        case 8: k_spmm_vec<8, GENERAL><<<grid, 256, 0, s>>>(a); break;
+        case 16: k_spmm_vec<16, GENERAL><<<grid, 256, 0, s>>>(a); break;
+        case 32: k_spmm_vec<32, GENERAL><<<grid, 256, 0, s>>>(a); break;
+        default: k_spmm_vec<64, GENERAL><<<grid, 256, 0, s>>>(a); break;
+    }
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int spmm_dispatch(SpmmArgs a, int64_t H, hipStream_t s) {
+    if (a.n_rows == 0 || H == 0) return BG_OK;
+    bool vec = (H % 4 == 0) && (a.ldx % 4 == 0) && (a.ldo % 4 == 0) && bg_aligned16(a.x) && bg_aligned16(a.out);
+    if (!vec) {
+        k_spmm_scalar<<<bg_grid_for(a.n_rows * H, 256, 0x7fffffff), 256, 0, s>>>(a, (int)H);
+        BG_LAUNCH_CHECK();
+        return BG_OK;
+    }
+    const bool general = !a.col || a.edge_w || a.col_mode;
+    for (int64_t h0 = 0; h0 < H; h0 += 256) {   // panels of 64 float4 columns
+        SpmmArgs p = a;
+        p.x = a.x + h0; p.out = a.out + h0;
+        p.H4 = (int)((H - h0 < 256 ? H - h0 : 256) / 4);
+        int rc = general ? launch_spmm_vec<true>(p, s) : launch_spmm_vec<false>(p, s);
+        if (rc != BG_OK) return rc;
+    }
+    return BG_OK;
+}
+
+// ---------------------------------------------------------------- two-phase long segments
+struct ChunkArgs {
+    const float* x; int64_t ldx;
+    const int32_t* rowptr; const int32_t* col;
+    const float* edge_w; const int32_t* eperm;
+    const int32_t* chunk_ptr; int32_t R; int64_t n_rows;
+    float* partial; int32_t* partial_arg; int H;
+};
+
+// binary search: the row r with chunk_ptr[r] <= c < chunk_ptr[r+1]
+__device__ __forceinline__ int64_t row_of_chunk(const int32_t* chunk_ptr, int64_t n_rows, int32_t c) {
+    int64_t lo = 0, hi = n_rows;   // invariant: chunk_ptr[lo] <= c < chunk_ptr[hi]
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (chunk_ptr[mid] <= c) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// One workgroup per chunk.  LPR lanes own one slot's row (a float4 each); the workgroup keeps
+// 256/LPR slots in flight, each lane group walking its slots with stride 256/LPR; the groups'
+// partial results are then combined through LDS in group order (deterministic; for max the
+// smallest slot wins ties, which is the first-index rule).
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void k_chunk_reduce(ChunkArgs a, int lpr, int hoff) {
+    __shared__ float4 sval[256];
+    __shared__ int4 sarg[IS_MAX ? 256 : 1];
+    const int32_t c = blockIdx.x;
+    if (c >= a.chunk_ptr[a.n_rows]) return;
+    const int64_t row = row_of_chunk(a.chunk_ptr, a.n_rows, c);
+    const int32_t k0 = a.rowptr[row] + (c - a.chunk_ptr[row]) * a.R;
+    const int32_t k1 = min(k0 + a.R, a.rowptr[row + 1]);
+    const int spb = 256 / lpr;
+    const int sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
+    const int H4 = (a.H - hoff) / 4 < 64 ? (a.H - hoff) / 4 : 64;
+    const bool live = sub < H4;
+    const float* xb = a.x + hoff + 4 * sub;
+    const float lowest = -3.402823466e+38f;
+    float4 acc = IS_MAX ? make_float4(lowest, lowest, lowest, lowest) : make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 ak = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
+    if (live) {
+        int32_t k = k0 + grp;
+        for (; k + 3 * spb < k1; k += 4 * spb) {
+            int32_t ka = k, kb = k + spb, kc = k + 2 * spb, kd = k + 3 * spb;
+            int32_t ca = a.col ? a.col[ka] : ka, cb = a.col ? a.col[kb] : kb;
+            int32_t cc = a.col ? a.col[kc] : kc, cd = a.col ? a.col[kd] : kd;
+            float4 va = bg_ld4(xb + (int64_t)ca * a.ldx), vb = bg_ld4(xb + (int64_t)cb * a.ldx);
+            float4 vc = bg_ld4(xb + (int64_t)cc * a.ldx), vd = bg_ld4(xb + (int64_t)cd * a.ldx);
+            if (IS_MAX) {
+#define BG_UPD(v, kk)                                                    \
+    if (v.x > acc.x) { acc.x = v.x; ak.x = kk; }                         \
+    if (v.y > acc.y) { acc.y = v.y; ak.y = kk; }                         \
+    if (v.z > acc.z) { acc.z = v.z; ak.z = kk; }                         \
+    if (v.w > acc.w) { acc.w = v.w; ak.w = kk; }
+                BG_UPD(va, ka) BG_UPD(vb, kb) BG_UPD(vc, kc) BG_UPD(vd, kd)
+            } else if (a.edge_w) {
+                float wa = a.edge_w[a.eperm ? a.eperm[ka] : ka], wb = a.edge_w[a.eperm ? a.eperm[kb] : kb];
+                float wc = a.edge_w[a.eperm ? a.eperm[kc] : kc], wd = a.edge_w[a.eperm ? a.eperm[kd] : kd];
+                acc = bg_add4(acc, bg_scale4(wa, va)); acc = bg_add4(acc, bg_scale4(wb, vb));
+                acc = bg_add4(acc, bg_scale4(wc, vc)); acc = bg_add4(acc, bg_scale4(wd, vd));
+            } else {
+                acc = bg_add4(acc, va); acc = bg_add4(acc, vb); acc = bg_add4(acc, vc); acc = bg_add4(acc, vd);
+            }
+        }
+        for (; k < k1; k += spb) {
+            int32_t cc = a.col ? a.col[k] : k;
+            float4 v = bg_ld4(xb + (int64_t)cc * a.ldx);
+            if (IS_MAX) {
+                BG_UPD(v, k)
+            } else {
+                float w = a.edge_w ? a.edge_w[a.eperm ? a.eperm[k] : k] : 1.f;
+                acc = bg_add4(acc, bg_scale4(w, v));
+            }
+        }
+    }
+    sval[threadIdx.x] = acc;
+    if (IS_MAX) sarg[threadIdx.x] = ak;
+    __syncthreads();
+    if (grp == 0 && live) {
+        for (int g = 1; g < spb; ++g) {
+            float4 v = sval[g * lpr + sub];
+            if (IS_MAX) {
+                int4 kk = sarg[g * lpr + sub];
+#define BG_CMB(f)                                                                           \
+    if (v.f > acc.f || (v.f == acc.f && kk.f < ak.f)) { acc.f = v.f; ak.f = kk.f; }
+                BG_CMB(x) BG_CMB(y) BG_CMB(z) BG_CMB(w)
+            } else {
+                acc = bg_add4(acc, v);
+            }
+        }
+        float* po = a.partial + (int64_t)c * a.H + hoff + 4 * sub;
+        bg_st4(po, acc);
+        if (IS_MAX) {
+            int4 r;
+            r.x = ak.x == 0x7fffffff ? -1 : (a.col ? a.col[ak.x] : ak.x);
+            r.y = ak.y == 0x7fffffff ? -1 : (a.col ? a.col[ak.y] : ak.y);
+            r.z = ak.z == 0x7fffffff ? -1 : (a.col ? a.col[ak.z] : ak.z);
+            r.w = ak.w == 0x7fffffff ? -1 : (a.col ? a.col[ak.w] : ak.w);
+            *reinterpret_cast<int4*>(a.partial_arg + (int64_t)c * a.H + hoff + 4 * sub) = r;
+        }
+    }
+}
+
+// scalar fallback of the chunk phase (any H / alignment): thread per channel, slots in order
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void k_chunk_reduce_scalar(ChunkArgs a) {
+    const int32_t c = blockIdx.x;
+    if (c >= a.chunk_ptr[a.n_rows]) return;
+    const int64_t row = row_of_chunk(a.chunk_ptr, a.n_rows, c);
+    const int32_t k0 = a.rowptr[row] + (c - a.chunk_ptr[row]) * a.R;
+    const int32_t k1 = min(k0 + a.R, a.rowptr[row + 1]);
+    for (int h = threadIdx.x; h < a.H; h += 256) {
+        float acc = IS_MAX ? -3.402823466e+38f : 0.f;
+        int32_t barg = -1;
+        for (int32_t k = k0; k < k1; ++k) {
+            int32_t cc = a.col ? a.col[k] : k;
+            float v = a.x[(int64_t)cc * a.ldx + h];
+            if (IS_MAX) {
+                if (v > acc || barg < 0) { acc = v; barg = cc; }
+            } else {
+                float w = a.edge_w ? a.edge_w[a.eperm ? a.eperm[k] : k] : 1.f;
+                acc += w * v;
+            }
+        }
+        a.partial[(int64_t)c * a.H + h] = acc;
+        if (IS_MAX) a.partial_arg[(int64_t)c * a.H + h] = barg;
+    }
+}
+
+template <bool IS_MAX>
+int launch_chunk_reduce(const ChunkArgs& a, int64_t n_chunks_ub, hipStream_t s) {
+    bool vec = (a.H % 4 == 0) && (a.ldx % 4 == 0) && bg_aligned16(a.x) && bg_aligned16(a.partial) &&
+               (!IS_MAX || bg_aligned16(a.partial_arg));
+    if (!vec) {
+        k_chunk_reduce_scalar<IS_MAX><<<(int)n_chunks_ub, 256, 0, s>>>(a);
+        BG_LAUNCH_CHECK();
+        return BG_OK;
+    }
+    for (int hoff = 0; hoff < a.H; hoff += 256) {
+        int h4 = (a.H - hoff) / 4 < 64 ? (a.H - hoff) / 4 : 64;
+        int lpr = 1;
+        while (lpr < h4) lpr <<= 1;
+        k_chunk_reduce<IS_MAX><<<(int)n_chunks_ub, 256, 0, s>>>(a, lpr, hoff);
+        BG_LAUNCH_CHECK();
+    }
+    return BG_OK;
+}
+
+// phase 2 of segmax: combine a row's chunk partials in chunk order (strict > keeps the first)
+__global__ void k_segmax_combine(const float* __restrict__ pval, const int32_t* __restrict__ parg,
+                                 const int32_t* __restrict__ chunk_ptr, int64_t n_rows, int H,
+                                 float* __restrict__ out, int64_t ldo, int32_t* __restrict__ arg) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * H) return;
+    int64_t row = t / H; int h = (int)(t % H);
+    float best = -3.402823466e+38f; int32_t barg = -1;
+    for (int32_t c = chunk_ptr[row]; c < chunk_ptr[row + 1]; ++c) {
+        float v = pval[(int64_t)c * H + h]; int32_t ar = parg[(int64_t)c * H + h];
+        if (ar >= 0 && v > best) { best = v; barg = ar; }
+        else if (ar >= 0 && barg < 0) { best = v; barg = ar; }
+    }
+    out[row * ldo + h] = barg >= 0 ? best : 0.f;
+    arg[row * H + h] = barg;
+}
+
+__global__ void k_gather_arg(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ arg,
+                             float* __restrict__ out, int64_t ldo, int64_t n_seg, int H) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seg * H) return;
+    int64_t s = t / H; int h = (int)(t % H);
+    int32_t a = arg[t];
+    out[s * ldo + h] = a >= 0 ? x[(int64_t)a * ldx + h] : 0.f;
+}
+
+__global__ void k_scatter_arg(const float* __restrict__ g, int64_t ldg, const int32_t* __restrict__ arg,
+                              float* __restrict__ out, int64_t ldo, int64_t n_seg, int H) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seg * H) return;
+    int64_t s = t / H; int h = (int)(t % H);
+    int32_t a = arg[t];
+    if (a >= 0) out[(int64_t)a * ldo + h] = g[s * ldg + h];
+}
+
+// one wave per row; 64/LPR slots in flight, LPR lanes per dot product (float4 per lane per step)
+template <int LPR>
+__global__ __launch_bounds__(256) void k_sddmm(const float* __restrict__ A, int64_t lda,
+                                               const float* __restrict__ B, int64_t ldb,
+                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                               const int32_t* __restrict__ eperm, float* __restrict__ out,
+                                               int64_t n_rows, int H4) {
+    constexpr int SPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int32_t b = rowptr[row], e = rowptr[row + 1];
+    for (int32_t k0 = b; k0 < e; k0 += SPW) {
+        int32_t k = k0 + grp;
+        float acc = 0.f;
+        if (k < e) {
+            int32_t c = col ? col[k] : k;
+            for (int j = sub; j < H4; j += LPR) {
+                float4 u = bg_ld4(A + row * lda + 4 * j);
+                float4 v = bg_ld4(B + (int64_t)c * ldb + 4 * j);
+                acc = fmaf(u.x, v.x, acc); acc = fmaf(u.y, v.y, acc);
+                acc = fmaf(u.z, v.z, acc); acc = fmaf(u.w, v.w, acc);
+            }
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (k < e && sub == 0) out[eperm ? eperm[k] : k] = acc;
+    }
+}
+
+__global__ void k_sddmm_scalar(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                               const int32_t* __restrict__ eperm, float* __restrict__ out, int64_t n_rows, int H) {
+    int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    for (int32_t k = rowptr[row]; k < rowptr[row + 1]; ++k) {
+        int32_t c = col ? col[k] : k;
+        float acc = 0.f;
+        for (int h = 0; h < H; ++h) acc = fmaf(A[row * lda + h], B[(int64_t)c * ldb + h], acc);
+        out[eperm ? eperm[k] : k] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bg_spmm_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                const float* edge_w, const int32_t* eperm,
+                const float* row_scale, int row_mode, const float* col_scale, int col_mode,
+                float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream) {
+    if (n_rows < 0 || H < 0) return BG_ERR_ARG;
+    if (n_rows == 0 || H == 0) return BG_OK;
+    if (!x || !rowptr || !out || ldx < H || ldo < H) return BG_ERR_ARG;
+    if ((row_mode && !row_scale) || (col_mode && !col_scale) || (eperm && !edge_w)) return BG_ERR_ARG;
+    SpmmArgs a{x, ldx, rowptr, col, edge_w, eperm, row_scale, row_mode, col_scale, col_mode, out, ldo, n_rows, 0};
+    return spmm_dispatch(a, H, (hipStream_t)stream);
+}
+
+int bg_segreduce_sum_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                         const float* edge_w, const int32_t* eperm,
+                         const float* row_scale, int row_mode,
+                         const int32_t* chunk_ptr, int32_t rows_per_chunk, int64_t n_chunks_ub,
+                         float* partial, float* out, int64_t ldo, int64_t n_rows, int64_t H,
+                         bgStream stream) {
+    if (n_rows < 0 || H < 0 || n_chunks_ub < 0) return BG_ERR_ARG;
+    if (n_rows == 0 || H == 0) return BG_OK;
+    if (!x || !rowptr || !chunk_ptr || !out || rows_per_chunk <= 0 || ldx < H || ldo < H) return BG_ERR_ARG;
+    if ((row_mode && !row_scale) || (eperm && !edge_w) || (n_chunks_ub > 0 && !partial)) return BG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_chunks_ub > 0) {
+        ChunkArgs a{x, ldx, rowptr, col, edge_w, eperm, chunk_ptr, rows_per_chunk, n_rows, partial, nullptr, (int)H};
+        int rc = launch_chunk_reduce<false>(a, n_chunks_ub, s);
+        if (rc != BG_OK) return rc;
+    }
+    // phase 2: out[r,:] = rs(r) * sum of the row's chunk partials, in chunk order
+    SpmmArgs p{partial, H, chunk_ptr, nullptr, nullptr, nullptr, row_scale, row_mode, nullptr, 0, out, ldo, n_rows, 0};
+    return spmm_dispatch(p, H, s);
+}
+
+int bg_segmax_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                  const int32_t* chunk_ptr, int32_t rows_per_chunk, int64_t n_chunks_ub,
+                  float* partial_val, int32_t* partial_arg,
+                  float* out, int64_t ldo, int32_t* arg, int64_t n_rows, int64_t H, bgStream stream) {
+    if (n_rows < 0 || H < 0 || n_chunks_ub < 0) return BG_ERR_ARG;
+    if (n_rows == 0 || H == 0) return BG_OK;
+    if (!x || !rowptr || !chunk_ptr || !out || !arg || rows_per_chunk <= 0 || ldx < H || ldo < H) return BG_ERR_ARG;
+    if (n_chunks_ub > 0 && (!partial_val || !partial_arg)) return BG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_chunks_ub > 0) {
+        ChunkArgs a{x, ldx, rowptr, col, nullptr, nullptr, chunk_ptr, rows_per_chunk, n_rows, partial_val, partial_arg, (int)H};
+        int rc = launch_chunk_reduce<true>(a, n_chunks_ub, s);
+        if (rc != BG_OK) return rc;
+    }
+    k_segmax_combine<<<bg_grid_for(n_rows * H, 256, 0x7fffffff), 256, 0, s>>>(partial_val, partial_arg, chunk_ptr,
+                                                                                n_rows, (int)H, out, ldo, arg);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_gather_arg_f32(const float* x, int64_t ldx, const int32_t* arg, float* out, int64_t ldo,
+                      int64_t n_seg, int64_t H, bgStream stream) {
+    if (n_seg < 0 || H < 0) return BG_ERR_ARG;
+    if (n_seg == 0 || H == 0) return BG_OK;
+    if (!x || !arg || !out || ldo < H) return BG_ERR_ARG;
+    k_gather_arg<<<bg_grid_for(n_seg * H, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(x, ldx, arg, out, ldo, n_seg, (int)H);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, float* out, int64_t ldo,
+                       int64_t n_seg, int64_t n_rows, int64_t H, bgStream stream) {
+    if (n_seg < 0 || H < 0 || n_rows < 0) return BG_ERR_ARG;
+    if (n_rows == 0 || H == 0) return BG_OK;
+    if (!out || ldo < H || (n_seg > 0 && (!g || !arg))) return BG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (ldo == H) {
+        BG_HIP(hipMemsetAsync(out, 0, sizeof(float) * n_rows * H, s));
+    } else {
+        BG_HIP(hipMemset2DAsync(out, sizeof(float) * ldo, 0, sizeof(float) * H, n_rows, s));
+    }
+    if (n_seg == 0) return BG_OK;
+    k_scatter_arg<<<bg_grid_for(n_seg * H, 256, 0x7fffffff), 256, 0, s>>>(g, ldg, arg, out, ldo, n_seg, (int)H);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_sddmm_f32(const float* a, int64_t lda, const float* b, int64_t ldb,
+                 const int32_t* rowptr, const int32_t* col, const int32_t* eperm,
+                 float* out, int64_t n_rows, int64_t H, bgStream stream) {
+    if (n_rows < 0 || H < 0) return BG_ERR_ARG;
+    if (n_rows == 0) return BG_OK;
+    if (!a || !b || !rowptr || !out || lda < H || ldb < H) return BG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    bool vec = (H % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && bg_aligned16(a) && bg_aligned16(b) && H >= 4;
+    if (!vec) {
+        k_sddmm_scalar<<<bg_grid_for(n_rows, 256, 0x7fffffff), 256, 0, s>>>(a, lda, b, ldb, rowptr, col, eperm, out, n_rows, (int)H);
+        BG_LAUNCH_CHECK();
+        return BG_OK;
+    }
+    int H4 = (int)(H / 4);
+    int grid = bg_grid_for(n_rows, 4, 0x7fffffff);
+    if (H4 >= 32) k_sddmm<32><<<grid, 256, 0, s>>>(a, lda, b, ldb, rowptr, col, eperm, out, n_rows, H4);
+    else if (H4 >= 8) k_sddmm<8><<<grid, 256, 0, s>>>(a, lda, b, ldb, rowptr, col, eperm, out, n_rows, H4);
+    else k_sddmm<1><<<grid, 256, 0, s>>>(a, lda, b, ldb, rowptr, col, eperm, out, n_rows, H4);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+}  // extern "C"

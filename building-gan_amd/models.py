@@ -1,0 +1,280 @@
+"""Generator / DiscriminatorVoxel with the reference's module interface, parameter names and
+outputs (/root/reference/Model/models.py:232-264), computed by the HIP kernels of this package.
+
+Differences in *formulation* (not in result, within fp32 rounding; DESIGN.md "refactors"):
+  * messageMLP has no activation (models.py:56,149), so the mean over in-edges of
+    W[x_i; x_j; dpos] + b is computed per NODE as W[x_i; mean_j x_j; mean dpos] + b on nodes
+    with at least one in-edge: one gather-mean + one node-level GEMM instead of an edge-level
+    GEMM and a scatter (an E/N-fold cut in flops and no [E, 2H+3] intermediate);
+  * NN_v / NN_p of the attention (models.py:113-116) are applied per node, then gathered;
+  * torch.cat feeding a Linear is fused into the GEMM's K loop.
+Gumbel / Exp(1) noise can be passed in (``noise``: one (exp_mask[Nv,2], exp_att[Ec]) pair per
+Attention call) so that runs are reproducible against the CPU oracle.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .ops import ACT_LEAKY, ACT_NONE, SpMM, SpMMW, linear
+from .plan import LinOp, build_plan
+
+NUMBER_OF_CLASS = 6  # /root/reference/Data/GraphConstructor.py:9
+
+
+def position_encoder(d_model: int, max_len: int = 20) -> torch.Tensor:
+    """Sinusoid table, /root/reference/Model/models.py:13-19."""
+    pos = torch.arange(max_len, dtype=torch.float32).unsqueeze(1)
+    freq = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * (-math.log(10000.0) / d_model))
+    pe = torch.zeros(max_len, d_model)
+    pe[:, 0::2] = torch.sin(pos * freq)
+    pe[:, 1::2] = torch.cos(pos * freq)
+    return pe
+
+
+def MLP(dims, act: str = "") -> nn.Sequential:
+    """Same container layout as the reference (models.py:29-42) so state_dict keys agree."""
+    mods = []
+    for a, b in zip(dims[:-1], dims[1:]):
+        mods.append(nn.Linear(a, b, bias=True))
+        if "leaky" in act:
+            mods.append(nn.LeakyReLU(negative_slope=0.01))
+        elif "relu" in act:
+            mods.append(nn.ReLU())
+        elif "tanh" in act:
+            mods.append(nn.Tanh())
+        elif "sigmoid" in act:
+            mods.append(nn.Sigmoid())
+    return nn.Sequential(*mods)
+
+
+def run_mlp(seq: nn.Sequential, xs, row_scale=None, pad_to: int = 0):
+    """Evaluate an MLP container on the HIP GEMM; ``xs`` may be a list (fused concatenation)."""
+    mods = list(seq)
+    i = 0
+    x = xs
+    while i < len(mods):
+        lin = mods[i]
+        W = lin.weight
+        if pad_to and W.shape[1] < pad_to:
+            W = F.pad(W, (0, pad_to - W.shape[1]))
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        if isinstance(nxt, nn.LeakyReLU):
+            x = linear(x, W, lin.bias, ACT_LEAKY, nxt.negative_slope, row_scale)
+            i += 2
+        else:
+            x = linear(x, W, lin.bias, ACT_NONE, 0.0, row_scale)
+            i += 1
+            if nxt is not None and not isinstance(nxt, nn.Linear):
+                x = nxt(x)
+                i += 1
+        row_scale, pad_to = None, 0
+    return x
+
+
+def extract_pos(feature):
+    return feature[:, 3:6], torch.cat((feature[:, 0:3], feature[:, 6:]), dim=-1)
+
+
+def _pos_terms(plan, pos):
+    """Per-node mean of (pos_i - pos_j) over in-edges, zero-padded to 4 columns (cached per plan)."""
+    cached = plan.ops.get("pdm4")
+    if cached is None:
+        pos4 = F.pad(pos.detach().float(), (0, 1)).contiguous()
+        cached = plan.vox_has * pos4 - ops.spmm_raw(plan.vox_mean, pos4)
+        plan.ops["pdm4"] = cached
+    return cached
+
+
+def _level_op(plan, max_len: int) -> LinOp:
+    key = ("level_op", max_len)
+    op = plan.ops.get(key)
+    if op is None:
+        from .plan import Csr
+        n = plan.Nv
+        if plan.ops["max_level"] >= max_len:
+            raise IndexError(f"a building has {plan.ops['max_level'] + 1} stories but the position table has "
+                             f"{max_len} rows (reference models.py:13,192)")
+        rowptr = torch.arange(n + 1, dtype=torch.int32, device=plan.device)
+        op = LinOp(Csr(rowptr, plan.level, None, n, max_len, n))
+        plan.ops[key] = op
+    return op
+
+
+class ProgramBlock(nn.Module):
+    def __init__(self, hidden_dim):
+        super().__init__()
+        self.aggr = "mean"
+        self.messageMLP = MLP([2 * hidden_dim, hidden_dim])
+        self.updateMLP = MLP([3 * hidden_dim, hidden_dim], act="leaky")
+
+    def forward(self, feature, plan, class_feature):
+        gm = SpMM.apply(feature, plan.prog_mean)
+        aggr = run_mlp(self.messageMLP, [feature, gm], row_scale=plan.prog_has)
+        pooled = SpMM.apply(feature, plan.slot_mean) * class_feature.view(-1, 1)
+        on_node = SpMM.apply(pooled, plan.slot_gather)
+        return run_mlp(self.updateMLP, [feature, aggr, on_node])
+
+
+class ProgramGNN(nn.Module):
+    def __init__(self, input_dim, hidden_dim, noise_dim, layer_num):
+        super().__init__()
+        self.layer_num = layer_num
+        self.enc = MLP([input_dim + noise_dim, hidden_dim])
+        self.block = ProgramBlock(hidden_dim)
+
+    def forward(self, cf, slf, tr, z, plan):
+        x = run_mlp(self.enc, torch.cat([cf, slf.view(-1, 1), z], dim=-1))
+        for _ in range(self.layer_num):
+            x = x + self.block(x, plan, tr)
+        return x
+
+
+class Attention(nn.Module):
+    def __init__(self, hidden_dim):
+        super().__init__()
+        self.dec = MLP([hidden_dim, hidden_dim // 2, 2])
+        self.NN_v = nn.Linear(hidden_dim, hidden_dim)
+        self.NN_p = nn.Linear(hidden_dim, hidden_dim)
+        self.theta = nn.Parameter(torch.empty(1, hidden_dim))
+        a = math.sqrt(6.0 / (1 + hidden_dim))          # torch_geometric inits.glorot
+        nn.init.uniform_(self.theta, -a, a)
+
+    def forward(self, program_graph_feature, voxel_feature, plan, noise=None):
+        exp_mask, exp_att = (None, None) if noise is None else noise
+        logits = run_mlp(self.dec, voxel_feature)
+        if exp_mask is None:
+            exp_mask = torch.empty_like(logits).exponential_()
+        soft_mask = ((logits - exp_mask.log()) / 1.0).softmax(-1)
+        winner = soft_mask.max(-1, keepdim=True)[1]
+        hard_mask = torch.zeros_like(soft_mask).scatter_(-1, winner, 1.0) - soft_mask.detach() + soft_mask
+        out_mask = {"hard": hard_mask[:, 0].view(-1, 1), "soft": soft_mask[:, 0].view(-1, 1)}
+
+        a = linear(voxel_feature, self.NN_v.weight, self.NN_v.bias)
+        b = linear(program_graph_feature, self.NN_p.weight, self.NN_p.bias)
+        att = ops.CrossLogits.apply(a, b, self.theta, plan)
+        if exp_att is None:
+            exp_att = torch.empty_like(att).exponential_()
+        soft_att, hard_att, _ = ops.SegGumbelSoftmax.apply(att, exp_att, plan, -1.0)
+        out_att = {"hard": hard_att.view(-1, 1), "soft": soft_att.view(-1, 1)}
+
+        gathered = SpMMW.apply(program_graph_feature, soft_att, plan.cross_v_sum)
+        new_voxel_feature = voxel_feature + out_mask["soft"] * gathered
+        return out_mask, out_att, new_voxel_feature
+
+    @staticmethod
+    def construct_output(program_class_feature, num_voxel, att, mask, plan, cross_edge_program_index):
+        on_edge = SpMM.apply(mask["hard"], plan.edge_voxel_gather)
+        arg = ops.seg_argmax(att["hard"] * on_edge, plan)
+        max_out_program_index = cross_edge_program_index[arg.long()]
+        hard_label = mask["hard"] * SpMMW.apply(program_class_feature, att["hard"].view(-1), plan.cross_v_sum)
+        soft_label = mask["hard"] * SpMMW.apply(program_class_feature, att["soft"].view(-1), plan.cross_v_sum)
+        return hard_label, soft_label, max_out_program_index.view(-1)
+
+
+class VoxelBlock(nn.Module):
+    def __init__(self, hidden_dim, if_agg_story_in_update=True):
+        super().__init__()
+        self.aggr = "mean"
+        self.if_agg_story_in_update = if_agg_story_in_update
+        self.messageMLP = MLP([2 * hidden_dim + 3, hidden_dim])
+        self.updateMLP = (MLP([4 * hidden_dim, hidden_dim], act="leaky") if if_agg_story_in_update
+                          else MLP([2 * hidden_dim, hidden_dim]))
+
+    def forward(self, voxel_feature, plan, pdm4):
+        H = voxel_feature.shape[1]
+        gm = SpMM.apply(voxel_feature, plan.vox_mean)
+        aggr = run_mlp(self.messageMLP, [voxel_feature, gm, pdm4], row_scale=plan.vox_has, pad_to=2 * H + 4)
+        if not self.if_agg_story_in_update:
+            return run_mlp(self.updateMLP, [voxel_feature, aggr])
+        story = SpMM.apply(voxel_feature, plan.story_mean)
+        building = SpMM.apply(story, plan.graph_of_story_mean)
+        story_v = SpMM.apply(story, plan.story_gather)
+        building_v = SpMM.apply(building, plan.graph_gather)
+        return run_mlp(self.updateMLP, [voxel_feature, aggr, story_v, building_v - story_v])
+
+
+class VoxelGNN_G(nn.Module):
+    def __init__(self, input_dim, hidden_dim, noise_dim, layer_num, max_len: int = 20):
+        super().__init__()
+        self.layer_num = layer_num
+        self.noise_dim = noise_dim
+        self.register_buffer("pe", position_encoder(hidden_dim, max_len))
+        self.enc = MLP([input_dim - 3 + noise_dim, hidden_dim])
+        self.block = VoxelBlock(hidden_dim, if_agg_story_in_update=True)
+        self.attention = Attention(hidden_dim)
+
+    def forward(self, x, v, z, plan, noise: Optional[Sequence] = None):
+        draws = iter(noise) if noise is not None else None
+        pos, v = extract_pos(v)
+        pdm4 = _pos_terms(plan, pos)
+        v = run_mlp(self.enc, torch.cat((v, z), dim=-1) if self.noise_dim != 0 else v)
+        v = v + ops.spmm_raw(_level_op(plan, self.pe.shape[0]), self.pe)
+        _, _, v = self.attention(x, v, plan, None if draws is None else next(draws))
+        out_mask = out_att = None
+        for i in range(self.layer_num):
+            v = v + self.block(v, plan, pdm4)
+            if i % 2 == 0 and i != 0:
+                out_mask, out_att, v = self.attention(x, v, plan, None if draws is None else next(draws))
+        return out_mask, out_att, v
+
+
+class VoxelGNN_D(nn.Module):
+    def __init__(self, input_feature_dim, input_label_dim, hidden_dim, layer_num, max_len: int = 20):
+        super().__init__()
+        self.layer_num = layer_num
+        self.register_buffer("pe", position_encoder(hidden_dim, max_len))
+        self.feature_enc = MLP([input_feature_dim - 3, hidden_dim])
+        self.label_enc = MLP([input_label_dim, hidden_dim])
+        self.block = VoxelBlock(2 * hidden_dim, if_agg_story_in_update=False)
+
+    def forward(self, v, l, plan):
+        pos, v = extract_pos(v)
+        pdm4 = _pos_terms(plan, pos)
+        v = run_mlp(self.feature_enc, v)
+        v = v + ops.spmm_raw(_level_op(plan, self.pe.shape[0]), self.pe)
+        v = torch.cat([v, run_mlp(self.label_enc, l)], dim=-1)
+        for _ in range(self.layer_num):
+            v = v + self.block(v, plan, pdm4)
+        return v
+
+
+class Generator(nn.Module):
+    def __init__(self, program_input_dim, voxel_input_dim, hidden_dim, noise_dim, program_layer, voxel_layer,
+                 device=None, max_len: int = 20):
+        super().__init__()
+        self.device = device
+        self.hidden_dim = hidden_dim
+        self.noise_dim = noise_dim
+        self.programGNN = ProgramGNN(program_input_dim, hidden_dim, noise_dim, program_layer)
+        self.voxelGNN = VoxelGNN_G(voxel_input_dim, hidden_dim, 0, voxel_layer, max_len)
+
+    def forward(self, graph, program_z, voxel_z, noise: Optional[Sequence] = None):
+        plan = build_plan(graph)
+        x = self.programGNN(graph.program_class_feature, graph.story_level_feature, graph.program_target_ratio,
+                            program_z, plan)
+        mask, att, _ = self.voxelGNN(x, graph.voxel_feature, voxel_z, plan, noise)
+        out, soft_out, idx = Attention.construct_output(graph.program_class_feature, graph.voxel_feature.shape[0],
+                                                        att, mask, plan, graph.cross_edge_program_index_select)
+        return out, soft_out, mask, att, idx
+
+
+class DiscriminatorVoxel(nn.Module):
+    def __init__(self, voxel_input_feature_dim, voxel_input_label_dim, hidden_dim, voxel_layer, act="",
+                 max_len: int = 20):
+        super().__init__()
+        self.voxelGNN_D = VoxelGNN_D(voxel_input_feature_dim, voxel_input_label_dim, hidden_dim, voxel_layer, max_len)
+        self.building_dec = MLP([2 * hidden_dim, hidden_dim, 1], act)
+        self.story_dec = MLP([2 * hidden_dim, hidden_dim, 1], act)
+
+    def forward(self, graph, out_label):
+        plan = build_plan(graph)
+        v = self.voxelGNN_D(graph.voxel_feature, out_label, plan)
+        story, _ = ops.SegMax.apply(v, plan.story_seg)
+        building, _ = ops.SegMax.apply(v, plan.graph_seg)
+        return run_mlp(self.building_dec, building), run_mlp(self.story_dec, story)

@@ -1,0 +1,453 @@
+"""Host wrappers and autograd Functions over the C-ABI kernels (include/bgan.h).
+
+Every Function's backward is written with other Functions of this file (or stock differentiable
+torch glue), so the family is closed under differentiation: the WGAN-GP penalty's double backward
+through the discriminator (/root/reference/Model/losses.py:83-84, create_graph=True) works.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+from .plan import Csr, LinOp, SCALE_NONE
+
+ACT_NONE, ACT_LEAKY = 0, 1
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    """Row-major fp32 with unit inner stride (a row pitch is allowed)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.dim() == 1:
+        return t if t.stride(0) == 1 or t.numel() <= 1 else t.contiguous()
+    if t.stride(-1) != 1 or (t.dim() == 2 and t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        return t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+# ------------------------------------------------------------------------------- raw launchers
+def spmm_raw(op: LinOp, x: torch.Tensor, edge_w: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    _lib.require_device(x, "spmm")
+    squeeze = x.dim() == 1
+    x2 = _f32c(x.view(-1, 1) if squeeze else x)
+    c: Csr = op.csr
+    if x2.shape[0] != c.n_cols:
+        raise _lib.BganError(f"spmm: operand has {x2.shape[0]} rows, plan expects {c.n_cols}")
+    H = x2.shape[1]
+    out = torch.empty(c.n_rows, H, dtype=torch.float32, device=x.device)
+    eperm = None
+    if edge_w is not None:
+        edge_w = _f32c(edge_w.reshape(-1))
+        if edge_w.numel() != c.nnz:
+            raise _lib.BganError("spmm: edge weight count does not match the plan")
+        eperm = c.perm
+    if c.long_rows and op.col_mode == SCALE_NONE:
+        partial = torch.empty(c.n_chunks_ub, H, dtype=torch.float32, device=x.device)
+        check(lib.bg_segreduce_sum_f32(ptr(x2), _ld(x2), ptr(c.rowptr), ptr(c.col), ptr(edge_w), ptr(eperm),
+                                       ptr(op.row_scale), op.row_mode, ptr(c.chunk_ptr), c.rows_per_chunk,
+                                       c.n_chunks_ub, ptr(partial), ptr(out), H, c.n_rows, H, stream()),
+              "bg_segreduce_sum_f32")
+    else:
+        check(lib.bg_spmm_f32(ptr(x2), _ld(x2), ptr(c.rowptr), ptr(c.col), ptr(edge_w), ptr(eperm),
+                              ptr(op.row_scale), op.row_mode, ptr(op.col_scale), op.col_mode,
+                              ptr(out), H, c.n_rows, H, stream()), "bg_spmm_f32")
+    return out.view(-1) if squeeze else out
+
+
+def sddmm_raw(op: LinOp, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """out[e] = <a[row(e)], b[col(e)]> in ORIGINAL edge order of the plan."""
+    lib = _lib.load()
+    c = op.csr
+    a2, b2 = _f32c(a.view(a.shape[0], -1)), _f32c(b.view(b.shape[0], -1))
+    if a2.shape[0] != c.n_rows or b2.shape[0] != c.n_cols or a2.shape[1] != b2.shape[1]:
+        raise _lib.BganError("sddmm: operand shapes do not match the plan")
+    out = torch.empty(c.nnz, dtype=torch.float32, device=a.device)
+    check(lib.bg_sddmm_f32(ptr(a2), _ld(a2), ptr(b2), _ld(b2), ptr(c.rowptr), ptr(c.col), ptr(c.perm), ptr(out),
+                           c.n_rows, a2.shape[1], stream()), "bg_sddmm_f32")
+    return out
+
+
+def segmax_raw(c: Csr, x: torch.Tensor):
+    lib = _lib.load()
+    x2 = _f32c(x)
+    if x2.shape[0] != c.n_cols or c.chunk_ptr is None:
+        raise _lib.BganError("segmax: operand rows / chunk table do not match the plan")
+    H = x2.shape[1]
+    dev = x.device
+    out = torch.empty(c.n_rows, H, dtype=torch.float32, device=dev)
+    arg = torch.empty(c.n_rows, H, dtype=torch.int32, device=dev)
+    pv = torch.empty(c.n_chunks_ub, H, dtype=torch.float32, device=dev)
+    pa = torch.empty(c.n_chunks_ub, H, dtype=torch.int32, device=dev)
+    check(lib.bg_segmax_f32(ptr(x2), _ld(x2), ptr(c.rowptr), ptr(c.col), ptr(c.chunk_ptr), c.rows_per_chunk,
+                            c.n_chunks_ub, ptr(pv), ptr(pa), ptr(out), H, ptr(arg), c.n_rows, H, stream()),
+          "bg_segmax_f32")
+    return out, arg
+
+
+def gather_arg_raw(x: torch.Tensor, arg: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    x2 = _f32c(x)
+    S, H = arg.shape
+    out = torch.empty(S, H, dtype=torch.float32, device=x.device)
+    check(lib.bg_gather_arg_f32(ptr(x2), _ld(x2), ptr(arg), ptr(out), H, S, H, stream()), "bg_gather_arg_f32")
+    return out
+
+
+def scatter_arg_raw(g: torch.Tensor, arg: torch.Tensor, n_rows: int) -> torch.Tensor:
+    lib = _lib.load()
+    g2 = _f32c(g)
+    S, H = arg.shape
+    out = torch.empty(n_rows, H, dtype=torch.float32, device=g.device)
+    check(lib.bg_scatter_arg_f32(ptr(g2), _ld(g2), ptr(arg), ptr(out), H, S, n_rows, H, stream()),
+          "bg_scatter_arg_f32")
+    return out
+
+
+_PtrArr4 = C.c_void_p * 4
+_I64Arr4 = C.c_int64 * 4
+
+
+def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: bool,
+             bias: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
+             act: int = ACT_NONE, slope: float = 0.01, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = epilogue(cat(A, -1 (or 0 when transA)) (x) B); see bg_gemm_f32."""
+    lib = _lib.load()
+    if len(A) < 1 or len(A) > 4:
+        raise _lib.BganError("gemm: 1..4 A segments")
+    As = [_f32c(a) for a in A]
+    B2 = _f32c(B)
+    _lib.require_device(B2, "gemm")
+    M = As[0].shape[1] if transA else As[0].shape[0]
+    Ks = [a.shape[0] if transA else a.shape[1] for a in As]
+    for a in As:
+        if (a.shape[1] if transA else a.shape[0]) != M:
+            raise _lib.BganError("gemm: A segments disagree on M")
+    Ktot = sum(Ks)
+    N = B2.shape[0] if transB else B2.shape[1]
+    if (B2.shape[1] if transB else B2.shape[0]) != Ktot:
+        raise _lib.BganError(f"gemm: reduction sizes differ ({Ktot} vs {tuple(B2.shape)}, transB={transB})")
+    out = torch.empty(M, N, dtype=torch.float32, device=B2.device)
+    if M == 0 or N == 0:
+        return out
+    pa = _PtrArr4(*([a.data_ptr() for a in As] + [None] * (4 - len(As))))
+    la = _I64Arr4(*([_ld(a) for a in As] + [0] * (4 - len(As))))
+    ka = _I64Arr4(*(Ks + [0] * (4 - len(As))))
+    if bias is not None:
+        bias = _f32c(bias)
+    if row_scale is not None:
+        row_scale = _f32c(row_scale.reshape(-1))
+    if residual is not None:
+        residual = _f32c(residual)
+    check(lib.bg_gemm_f32(int(transA), int(transB), M, N, len(As), pa, la, ka, ptr(B2), _ld(B2), ptr(out), N,
+                          ptr(bias), ptr(row_scale), act, slope, ptr(residual),
+                          _ld(residual) if residual is not None else 0, stream()), "bg_gemm_f32")
+    return out
+
+
+def gemm_tn_raw(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """C[M,N] = A^T B for A [R,M], B [R,N] with a long R: split-K, deterministic order."""
+    lib = _lib.load()
+    A2, B2 = _f32c(A), _f32c(B)
+    R, M = A2.shape
+    N = B2.shape[1]
+    if B2.shape[0] != R:
+        raise _lib.BganError("gemm_tn: reduction sizes differ")
+    out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    if M == 0 or N == 0:
+        return out
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    steps = (R + 31) // 32
+    splits = max(1, min(steps, (1024 + tiles - 1) // tiles, 256))
+    partial = torch.empty(splits, M, N, dtype=torch.float32, device=A.device)
+    check(lib.bg_gemm_tn_splitk_f32(M, N, R, ptr(A2), _ld(A2), ptr(B2), _ld(B2), ptr(out), N, ptr(partial), splits,
+                                    stream()), "bg_gemm_tn_splitk_f32")
+    return out
+
+
+def colsum_raw(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    x2 = _f32c(x)
+    M, N = x2.shape
+    nb = max(1, min(256, (M + 63) // 64))
+    partial = torch.empty(nb, N, dtype=torch.float32, device=x.device)
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    check(lib.bg_colsum_f32(ptr(x2), _ld(x2), M, N, ptr(partial), nb, ptr(out), stream()), "bg_colsum_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------- autograd family
+class SpMM(torch.autograd.Function):
+    """y = op(x) for a fixed sparse LinOp; backward is the transposed LinOp."""
+
+    @staticmethod
+    def forward(ctx, x, op: LinOp):
+        ctx.op = op
+        return spmm_raw(op, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return SpMM.apply(g, ctx.op.T), None
+
+
+class SpMMW(torch.autograd.Function):
+    """y[i] = sum_e w[e] x[col(e)] with differentiable per-edge weights (original edge order)."""
+
+    @staticmethod
+    def forward(ctx, x, w, op: LinOp):
+        ctx.op = op
+        ctx.save_for_backward(x, w)
+        return spmm_raw(op, x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = SpMMW.apply(g, w, ctx.op.T) if ctx.needs_input_grad[0] else None
+        gw = SDDMM.apply(g, x, ctx.op).view_as(w) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+class SDDMM(torch.autograd.Function):
+    """out[e] = <a[row(e)], b[col(e)]>."""
+
+    @staticmethod
+    def forward(ctx, a, b, op: LinOp):
+        ctx.op = op
+        ctx.save_for_backward(a, b)
+        return sddmm_raw(op, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = SpMMW.apply(b, g, ctx.op) if ctx.needs_input_grad[0] else None
+        gb = SpMMW.apply(a, g, ctx.op.T) if ctx.needs_input_grad[1] else None
+        return ga, gb, None
+
+
+class MatMul(torch.autograd.Function):
+    """C = op(A) op(B) on the fp32 matrix cores; closed under differentiation."""
+
+    @staticmethod
+    def forward(ctx, A, B, ta: bool, tb: bool):
+        ctx.ta, ctx.tb = ta, tb
+        ctx.save_for_backward(A, B)
+        if ta and not tb:
+            return gemm_tn_raw(A, B)
+        return gemm_raw([A], B, ta, tb)
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.saved_tensors
+        ta, tb = ctx.ta, ctx.tb
+        gA = gB = None
+        if ctx.needs_input_grad[0]:
+            if not ta:
+                gA = MatMul.apply(g, B, False, not tb)      # g B^T (tb=False) / g B (tb=True)
+            else:
+                gA = MatMul.apply(B, g, tb, True)           # B g^T / B^T g^T
+        if ctx.needs_input_grad[1]:
+            if not tb:
+                gB = MatMul.apply(A, g, not ta, False)      # A^T g / A g
+            else:
+                gB = MatMul.apply(g, A, True, ta)           # g^T A / g^T A^T
+        return gA, gB, None, None
+
+
+class ColSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.rows = x.shape[0]
+        return colsum_raw(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.unsqueeze(0).expand(ctx.rows, -1)
+
+
+class LinearCat(torch.autograd.Function):
+    """y = act(row_scale * (cat(xs, -1) @ W^T + b)) (+ residual): the fused nn.Linear of the hot path.
+
+    Inputs: W, b, n (number of x segments), act, slope, row_scale(or None), residual(or None), *xs.
+    """
+
+    @staticmethod
+    def forward(ctx, W, b, act, slope, row_scale, residual, *xs):
+        y = gemm_raw(list(xs), W, False, True, bias=b, row_scale=row_scale, act=act, slope=slope, residual=residual)
+        ctx.act, ctx.slope = act, slope
+        ctx.has_res = residual is not None
+        ctx.widths = [x.shape[1] for x in xs]
+        if act == ACT_LEAKY:
+            # sign of the pre-activation == sign of (y - residual)
+            pre = y if residual is None else y - residual
+            ctx.save_for_backward(W, row_scale, pre > 0, *xs)
+        else:
+            ctx.save_for_backward(W, row_scale, None, *xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        W, row_scale, pos, *xs = ctx.saved_tensors
+        g_res = g if ctx.has_res and ctx.needs_input_grad[5] else None
+        if ctx.act == ACT_LEAKY:
+            g = torch.where(pos, g, g * ctx.slope)
+        if row_scale is not None:
+            g = g * row_scale.view(-1, 1)
+        gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gW = torch.cat([MatMul.apply(g, x, True, False) for x in xs], dim=1) if len(xs) > 1 \
+                else MatMul.apply(g, xs[0], True, False)
+        if ctx.needs_input_grad[1]:
+            gb = ColSum.apply(g)
+        gxs: List[Optional[torch.Tensor]] = [None] * len(xs)
+        if any(ctx.needs_input_grad[6:]):
+            gx = MatMul.apply(g, W, False, False)
+            off = 0
+            for i, wdt in enumerate(ctx.widths):
+                if ctx.needs_input_grad[6 + i]:
+                    gxs[i] = gx[:, off:off + wdt]
+                off += wdt
+        return (gW, gb, None, None, None, g_res, *gxs)
+
+
+def linear(xs, W, b=None, act=ACT_NONE, slope=0.01, row_scale=None, residual=None):
+    if torch.is_tensor(xs):
+        xs = [xs]
+    return LinearCat.apply(W, b, act, slope, row_scale, residual, *xs)
+
+
+class SegMax(torch.autograd.Function):
+    """Segment max over a pooling Csr; the gradient goes to the (first) arg-max row only."""
+
+    @staticmethod
+    def forward(ctx, x, csr: Csr):
+        out, arg = segmax_raw(csr, x)
+        ctx.n_rows = x.shape[0]
+        ctx.save_for_backward(arg)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, g, _garg):
+        (arg,) = ctx.saved_tensors
+        return ScatterArg.apply(g, arg, ctx.n_rows), None
+
+
+class ScatterArg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, arg, n_rows):
+        ctx.save_for_backward(arg)
+        return scatter_arg_raw(g, arg, n_rows)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (arg,) = ctx.saved_tensors
+        return GatherArg.apply(gg, arg), None, None
+
+
+class GatherArg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, arg):
+        ctx.n_rows = x.shape[0]
+        ctx.save_for_backward(arg)
+        return gather_arg_raw(x, arg)
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        return ScatterArg.apply(g, arg, ctx.n_rows), None
+
+
+# ------------------------------------------------------------------------------- attention ops
+class CrossLogits(torch.autograd.Function):
+    """att[e] = theta . tanh(a[cev[e]] + b[cep[e]])  (first-order autograd only)."""
+
+    @staticmethod
+    def forward(ctx, a, b, theta, plan):
+        lib = _lib.load()
+        cv = plan.cross_v
+        a2, b2, th = _f32c(a), _f32c(b), _f32c(theta.reshape(-1))
+        att = torch.empty(cv.nnz, dtype=torch.float32, device=a.device)
+        check(lib.bg_cross_logits_f32(ptr(a2), _ld(a2), ptr(b2), _ld(b2), ptr(th), ptr(cv.rowptr), ptr(cv.col),
+                                      ptr(att), cv.n_rows, a2.shape[1], stream()), "bg_cross_logits_f32")
+        ctx.plan = plan
+        ctx.save_for_backward(a2, b2, th)
+        ctx.theta_shape = theta.shape
+        return att
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        a2, b2, th = ctx.saved_tensors
+        plan = ctx.plan
+        cv = plan.cross_v
+        H = a2.shape[1]
+        dev = a2.device
+        g = _f32c(g.reshape(-1))
+        nb = max(1, min(1024, (cv.n_rows + 3) // 4))
+        dpre = torch.empty(cv.nnz, H, dtype=torch.float32, device=dev)
+        da = torch.empty(cv.n_rows, H, dtype=torch.float32, device=dev)
+        dth_p = torch.empty(nb, H, dtype=torch.float32, device=dev)
+        check(lib.bg_cross_logits_bwd_f32(ptr(a2), _ld(a2), ptr(b2), _ld(b2), ptr(th), ptr(cv.rowptr), ptr(cv.col),
+                                          ptr(g), ptr(dpre), ptr(da), H, ptr(dth_p), nb, cv.n_rows, H, stream()),
+              "bg_cross_logits_bwd_f32")
+        db = spmm_raw(plan.edge_program_gather.T, dpre)
+        dth = colsum_raw(dth_p).view(ctx.theta_shape)
+        return da, db, dth, None
+
+
+class SegGumbelSoftmax(torch.autograd.Function):
+    """(soft, hard, arg) of the segment Gumbel-softmax pointer; hard carries the straight-through
+    gradient of soft (reference util.py:26)."""
+
+    @staticmethod
+    def forward(ctx, att, expn, plan, tau):
+        lib = _lib.load()
+        cv = plan.cross_v
+        att2, e2 = _f32c(att.reshape(-1)), _f32c(expn.reshape(-1))
+        if att2.numel() != cv.nnz or e2.numel() != cv.nnz:
+            raise _lib.BganError("segment gumbel softmax: logits / noise length differ from the plan")
+        soft = torch.empty_like(att2)
+        hard = torch.empty_like(att2)
+        arg = torch.empty(cv.n_rows, dtype=torch.int32, device=att.device)
+        check(lib.bg_seg_gumbel_softmax_f32(ptr(att2), ptr(e2), ptr(cv.rowptr), float(tau), ptr(soft), ptr(hard),
+                                            ptr(arg), cv.n_rows, stream()), "bg_seg_gumbel_softmax_f32")
+        ctx.plan, ctx.tau = plan, float(tau)
+        ctx.save_for_backward(soft)
+        ctx.mark_non_differentiable(arg)
+        return soft, hard, arg
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_soft, g_hard, _g_arg):
+        lib = _lib.load()
+        (soft,) = ctx.saved_tensors
+        cv = ctx.plan.cross_v
+        g = _f32c((g_soft + g_hard).reshape(-1))
+        d_att = torch.empty_like(soft)
+        check(lib.bg_seg_softmax_bwd_f32(ptr(soft), ptr(g), ptr(cv.rowptr), ctx.tau, ptr(d_att), cv.n_rows, stream()),
+              "bg_seg_softmax_bwd_f32")
+        return d_att, None, None, None
+
+
+def seg_argmax(logit: torch.Tensor, plan) -> torch.Tensor:
+    lib = _lib.load()
+    cv = plan.cross_v
+    l2 = _f32c(logit.reshape(-1))
+    arg = torch.empty(cv.n_rows, dtype=torch.int32, device=logit.device)
+    check(lib.bg_seg_argmax_f32(ptr(l2), ptr(cv.rowptr), ptr(arg), cv.n_rows, stream()), "bg_seg_argmax_f32")
+    return arg
+
+
+def adam_step(param, grad, m, v, lr, beta1, beta2, eps, step):
+    lib = _lib.load()
+    check(lib.bg_adam_f32(ptr(param), ptr(grad), ptr(m), ptr(v), param.numel(), lr, beta1, beta2, eps, step,
+                          stream()), "bg_adam_f32")

@@ -1,0 +1,250 @@
+"""Per-batch segment plans, built once on the device and reused by every layer and every
+generator / discriminator pass over the batch.
+
+A plan replaces the COO bookkeeping the reference redoes inside every torch_scatter /
+torch_geometric call (index_select + scatter pairs, ``torch.unique`` in avg_pool_x,
+``batch.max().item()`` in global_max_pool: /root/reference/Model/models.py:24,65,71,158,166-167,
+262-263).  Building it costs ONE host synchronisation per batch (reading back the validity flags).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+SCALE_NONE, SCALE_MUL, SCALE_DIV = 0, 1, 2
+LONG_ROW = 32          # average row length above which the two-phase (chunked) kernels are used
+
+
+@dataclass
+class Csr:
+    """CSR over ``n_rows`` segments whose slots point at rows of an ``n_cols``-row matrix."""
+    rowptr: torch.Tensor                 # int32 [n_rows + 1]
+    col: Optional[torch.Tensor]          # int32 [nnz]; None = slot k points at row k
+    perm: Optional[torch.Tensor]         # int32 [nnz] original (COO) id of each slot; None = identity
+    n_rows: int
+    n_cols: int
+    nnz: int
+    count: Optional[torch.Tensor] = None       # float32 [n_rows] = max(len, 1)
+    chunk_ptr: Optional[torch.Tensor] = None   # int32 [n_rows + 1]
+    rows_per_chunk: int = 0
+    n_chunks_ub: int = 0
+
+    @property
+    def long_rows(self) -> bool:
+        return self.chunk_ptr is not None
+
+
+class LinOp:
+    """A sparse linear map  y = diag(rs) * P * diag(cs) * x  given by a Csr, with its transpose."""
+
+    def __init__(self, csr: Csr, row_scale=None, row_mode=SCALE_NONE, col_scale=None, col_mode=SCALE_NONE):
+        self.csr = csr
+        self.row_scale, self.row_mode = row_scale, row_mode
+        self.col_scale, self.col_mode = col_scale, col_mode
+        self.T: Optional["LinOp"] = None
+
+    @staticmethod
+    def pair(fwd_csr: Csr, rev_csr: Csr, row_scale=None, row_mode=SCALE_NONE):
+        """fwd = diag(rs) P (rows of fwd_csr); its transpose runs over rev_csr with a column scale."""
+        a = LinOp(fwd_csr, row_scale, row_mode)
+        b = LinOp(rev_csr, None, SCALE_NONE, row_scale, row_mode)
+        a.T, b.T = b, a
+        return a
+
+
+def _i32(n, device):
+    return torch.empty(n, dtype=torch.int32, device=device)
+
+
+class _Builder:
+    def __init__(self, device, max_builds=24):
+        self.device = device
+        self.lib = _lib.load()
+        self.flags = torch.zeros(max_builds, 2, dtype=torch.int32, device=device)
+        self.names = []
+
+    def _slot(self, name):
+        i = len(self.names)
+        self.names.append(name)
+        return self.flags[i]
+
+    def csr(self, name, key, other, n_rows, n_cols, counts=False) -> Csr:
+        """Stable sort of the COO list (key -> row, other -> col)."""
+        E = int(key.numel())
+        key = key.contiguous()
+        other = other.contiguous()
+        rowptr = _i32(n_rows + 1, self.device)
+        col, perm, cursor = _i32(E, self.device), _i32(E, self.device), _i32(n_rows + 1, self.device)
+        fl = self._slot(name)
+        check(self.lib.bg_plan_csr(ptr(key), ptr(other), E, n_rows, ptr(rowptr), ptr(col), ptr(perm), ptr(cursor),
+                                   ptr(fl), stream()), "bg_plan_csr")
+        c = Csr(rowptr, col, perm, n_rows, n_cols, E)
+        if counts:
+            self.counts(c)
+        self.maybe_chunks(c)
+        return c
+
+    def gather_csr(self, idx32: torch.Tensor, n_cols: int) -> Csr:
+        """One slot per row: y[i] = x[idx[i]] (an index_select as a Csr)."""
+        n = int(idx32.numel())
+        rowptr = torch.arange(n + 1, dtype=torch.int32, device=self.device)
+        return Csr(rowptr, idx32, None, n, n_cols, n)
+
+    def segptr(self, name, seg_id, nseg) -> torch.Tensor:
+        p = _i32(nseg + 1, self.device)
+        fl = self._slot(name)
+        check(self.lib.bg_plan_segptr(ptr(seg_id.contiguous()), int(seg_id.numel()), nseg, ptr(p), ptr(fl), stream()),
+              "bg_plan_segptr")
+        return p
+
+    def counts(self, c: Csr) -> None:
+        c.count = torch.empty(c.n_rows, dtype=torch.float32, device=self.device)
+        check(self.lib.bg_plan_counts(ptr(c.rowptr), c.n_rows, ptr(c.count), stream()), "bg_plan_counts")
+
+    def maybe_chunks(self, c: Csr, force: bool = False) -> None:
+        if c.n_rows == 0 or (not force and c.nnz <= LONG_ROW * c.n_rows):
+            return
+        avg = c.nnz / max(c.n_rows, 1)
+        R = 64 if avg <= 2048 else (256 if avg <= 32768 else 1024)
+        c.chunk_ptr = _i32(c.n_rows + 1, self.device)
+        c.rows_per_chunk = R
+        c.n_chunks_ub = c.nnz // R + c.n_rows
+        check(self.lib.bg_plan_chunks(ptr(c.rowptr), c.n_rows, R, ptr(c.chunk_ptr), stream()), "bg_plan_chunks")
+
+    def finish(self, extra: torch.Tensor):
+        """The one host synchronisation of a plan build: read the validity flags (and a few
+        extra int32 scalars) back."""
+        n = len(self.names)
+        host = torch.cat([self.flags[:n].reshape(-1), extra.reshape(-1).to(torch.int32)]).cpu()
+        fl = host[: 2 * n].view(n, 2)
+        return {nm: (int(fl[i, 0]), int(fl[i, 1])) for i, nm in enumerate(self.names)}, host[2 * n:].tolist()
+
+
+@dataclass
+class GraphPlan:
+    B: int = 0
+    S: int = 0
+    Np: int = 0
+    Nv: int = 0
+    Ep: int = 0
+    Ev: int = 0
+    Ec: int = 0
+    device: Optional[torch.device] = None
+    ops: dict = field(default_factory=dict)
+
+    def __getattr__(self, name):
+        ops = self.__dict__.get("ops", {})
+        if name in ops:
+            return ops[name]
+        raise AttributeError(name)
+
+
+def _max_plus_one(t: torch.Tensor) -> int:
+    return int(t.max().item()) + 1 if t.numel() else 0
+
+
+def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
+    """Build (or fetch the cached) plan for a batch that exposes the row-a0 attributes."""
+    cached = graph.__dict__.get("_bg_plan") if hasattr(graph, "__dict__") else None
+    if cached is not None:
+        return cached
+    vf = graph.voxel_feature
+    _lib.require_device(vf, "build_plan")
+    dev = vf.device
+    b = _Builder(dev)
+    pe, ve = graph.program_edge, graph.voxel_edge
+    cep, cev = graph.cross_edge_program_index_select, graph.cross_edge_voxel_index_select
+    vfc, vbi = graph.voxel_floor_cluster, graph.voxel_feature_batch
+    pcc = graph.program_class_cluster
+    Np, Nv = int(graph.program_class_feature.shape[0]), int(vf.shape[0])
+    B = int(graph.FAR.shape[0])
+    n_slot = int(graph.program_target_ratio.shape[0])
+    S = num_stories if num_stories is not None else getattr(graph, "num_stories", None)
+    if S is None:
+        S = _max_plus_one(vfc)          # host sync, as the reference's own pooling does per call
+    p = GraphPlan(B=B, S=S, Np=Np, Nv=Nv, Ep=int(pe.shape[1]), Ev=int(ve.shape[1]), Ec=int(cev.numel()), device=dev)
+    o = p.ops
+
+    # ---- program graph: mean over in-edges (target = edge[1]); class slots -----------------
+    pf = b.csr("program_by_target", pe[1], pe[0], Np, Np, counts=True)
+    pr = b.csr("program_by_source", pe[0], pe[1], Np, Np)
+    o["prog_mean"] = LinOp.pair(pf, pr, pf.count, SCALE_DIV)
+    ar_p = torch.arange(Np, dtype=torch.int64, device=dev)
+    slot = b.csr("class_slot", pcc, ar_p, n_slot, Np, counts=True)
+    slot_gather = b.gather_csr(pcc.to(torch.int32), n_slot)
+    o["slot_mean"] = LinOp.pair(slot, slot_gather, slot.count, SCALE_DIV)      # avg_pool_x(size=6)
+    o["slot_sum"] = LinOp.pair(slot, slot_gather)
+    o["slot_gather"] = o["slot_sum"].T                                         # index_select(0, class_index)
+    slot_graph = graph.program_target_ratio_batch
+    ar_s = torch.arange(n_slot, dtype=torch.int64, device=dev)
+    sg = b.csr("slot_by_graph", slot_graph, ar_s, B, n_slot)
+    o["slot_graph_sum"] = LinOp.pair(sg, b.gather_csr(slot_graph.to(torch.int32), B))
+    o["slot_graph_gather"] = o["slot_graph_sum"].T
+
+    # ---- voxel graph ------------------------------------------------------------------------
+    vfw = b.csr("voxel_by_target", ve[1], ve[0], Nv, Nv, counts=True)
+    vrv = b.csr("voxel_by_source", ve[0], ve[1], Nv, Nv)
+    o["vox_mean"] = LinOp.pair(vfw, vrv, vfw.count, SCALE_DIV)
+
+    # stories / graphs: pooling segments over voxels (general CSR; contiguous when sorted)
+    ar_v = torch.arange(Nv, dtype=torch.int64, device=dev)
+    st = b.csr("voxel_by_story", vfc, ar_v, S, Nv, counts=True)
+    b.maybe_chunks(st, force=True)
+    st_gather = b.gather_csr(vfc.to(torch.int32), S)
+    o["story_mean"] = LinOp.pair(st, st_gather, st.count, SCALE_DIV)
+    o["story_gather"] = LinOp.pair(st_gather, st)
+    gr = b.csr("voxel_by_graph", vbi, ar_v, B, Nv)
+    b.maybe_chunks(gr, force=True)
+    gr_gather = b.gather_csr(vbi.to(torch.int32), B)
+    o["graph_gather"] = LinOp.pair(gr_gather, gr)
+    o["story_seg"], o["graph_seg"] = st, gr
+    # graph id of a story = graph of (any) member voxel, as avg_pool_x's batch[perm]
+    story_graph = torch.zeros(S, dtype=torch.int64, device=dev)
+    story_graph.scatter_(0, vfc, vbi)
+    ar_st = torch.arange(S, dtype=torch.int64, device=dev)
+    sgr = b.csr("story_by_graph", story_graph, ar_st, B, S, counts=True)
+    o["graph_of_story_mean"] = LinOp.pair(sgr, b.gather_csr(story_graph.to(torch.int32), B), sgr.count, SCALE_DIV)
+
+    # floor level of every voxel inside its own building
+    first = _i32(max(B, 1), dev)
+    level = _i32(Nv, dev)
+    check(b.lib.bg_plan_floor_level(ptr(vfc.contiguous()), ptr(vbi.contiguous()), Nv, B, ptr(first), ptr(level),
+                                    stream()), "bg_plan_floor_level")
+    o["level"] = level
+    lvl_max = level.max() if Nv > 0 else torch.zeros((), dtype=torch.int32, device=dev)
+
+    # ---- cross edges ------------------------------------------------------------------------
+    cv = b.csr("cross_by_voxel", cev, cep, Nv, Np)
+    cp = b.csr("cross_by_program", cep, cev, Np, Nv)
+    o["cross_v"], o["cross_p"] = cv, cp
+    o["cross_v_sum"] = LinOp.pair(cv, cp)                     # rows = voxels, cols = program nodes
+    # edge -> voxel / program gathers (y[e] = x[cev[e]]) and their transposes (segment sums over edges)
+    edge_by_voxel = Csr(cv.rowptr, cv.perm, None, Nv, p.Ec, p.Ec)
+    edge_by_program = Csr(cp.rowptr, cp.perm, None, Np, p.Ec, p.Ec, chunk_ptr=cp.chunk_ptr,
+                          rows_per_chunk=cp.rows_per_chunk, n_chunks_ub=cp.n_chunks_ub)
+    o["edge_voxel_gather"] = LinOp.pair(b.gather_csr(cev.to(torch.int32), Nv), edge_by_voxel)
+    o["edge_program_gather"] = LinOp.pair(b.gather_csr(cep.to(torch.int32), Np), edge_by_program)
+
+    flags, (max_level,) = b.finish(lvl_max)
+    o["max_level"] = int(max_level)
+    for name, (bad, moved) in flags.items():
+        if bad:
+            raise _lib.BganError(f"plan '{name}': {bad} index values out of range")
+    p.ops["flags"] = flags
+    if flags["cross_by_voxel"][1] != 0:
+        raise _lib.BganError("cross_edge_voxel_index_select must be non-decreasing (reference "
+                             "GraphConstructor.py:81-88 builds it voxel-major)")
+    if cv.nnz and int(flags["cross_by_voxel"][0]) == 0 and bool((cv.rowptr[1:] == cv.rowptr[:-1]).any().item()):
+        raise _lib.BganError("every voxel needs at least one cross edge (reference util.py:24-25 indexes the "
+                             "arg-max of each voxel segment)")
+    has = (vfw.rowptr[1:] > vfw.rowptr[:-1]).to(torch.float32).view(-1, 1)
+    o["vox_has"] = has
+    o["prog_has"] = (pf.rowptr[1:] > pf.rowptr[:-1]).to(torch.float32).view(-1, 1)
+    if hasattr(graph, "__dict__"):
+        graph.__dict__["_bg_plan"] = p
+    return p

@@ -1,0 +1,195 @@
+/* libbgan_hip.so -- C ABI of the MI355X (gfx950) kernels behind Building-GAN's message-passing
+ * hot path.  Plain pointers and sizes only; every pointer is a DEVICE pointer owned by the
+ * caller; the library never allocates, frees or synchronises; every function enqueues its
+ * kernels on `stream` (a hipStream_t passed as void*) and returns BG_OK or a negative code.
+ *
+ * The reference (AutodeskAILab/Building-GAN) has no native code: each entry point below
+ * replaces a call the reference makes into torch_scatter / torch_geometric / torch.nn.  The
+ * "replaces:" lines cite that call site under /root/reference/.
+ *
+ * Conventions: matrices are row-major float32 with an explicit row pitch `ld*` (in floats);
+ * CSR plans are int32 (rowptr[n_rows+1], col[nnz]); "first index wins" on arg-max ties.
+ */
+#ifndef BGAN_H
+#define BGAN_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BG_OK 0
+#define BG_ERR_ARG (-1)      /* null pointer / negative size / inconsistent sizes        */
+#define BG_ERR_SHAPE (-2)    /* shape not supported by the kernel (see each function)   */
+#define BG_ERR_ALIGN (-3)    /* pointer or pitch not aligned as required                */
+#define BG_ERR_LAUNCH (-4)   /* HIP reported a launch / enqueue error                   */
+
+typedef void* bgStream;
+
+int bg_version(void);
+const char* bg_error_string(int code);
+
+/* ------------------------------------------------------------------ integer plans ------- */
+
+/* Stable counting sort of E edges by key[e] in [0,N): rowptr[N+1], perm[E] (original edge id
+ * of each CSR slot, ascending inside a row) and col[E] = other[perm].  cursor: int32[N+1]
+ * scratch.  flags[0] += number of keys outside [0,N); flags[1] += number of slots with
+ * perm[k] != k (0 => the COO list was already sorted).  flags must be zeroed by the caller.
+ * replaces: the COO->segment bookkeeping inside torch_scatter that every scatter call of
+ * Model/models.py:65,158 (MessagePassing.propagate), :71,:166-167 (avg_pool_x) performs.   */
+int bg_plan_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N,
+                int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* cursor, int32_t* flags,
+                bgStream stream);
+
+/* Pointer array of a non-decreasing id vector: ptr[s] = first i with seg_id[i] >= s, ptr[nseg]=n.
+ * flags[0] += 1 if the ids are not non-decreasing or fall outside [0,nseg).
+ * replaces: consecutive_cluster / torch.unique inside avg_pool_x, Model/models.py:166-167.  */
+int bg_plan_segptr(const int64_t* seg_id, int64_t n, int64_t nseg, int32_t* ptr, int32_t* flags,
+                   bgStream stream);
+
+/* level[i] = vfc[i] - min{vfc[j] : vbi[j] == vbi[i]}.  first: int32[B] scratch.
+ * replaces: get_voxel_floor_level (max_pool_x on -vfc), Model/models.py:22-25.              */
+int bg_plan_floor_level(const int64_t* vfc, const int64_t* vbi, int64_t n, int64_t B,
+                        int32_t* first, int32_t* level, bgStream stream);
+
+/* count[i] = (float)max(rowptr[i+1]-rowptr[i], 1): the divisor of scatter-mean.
+ * replaces: the clamp(count,1) of torch_scatter.scatter_mean (aggr='mean', models.py:55,147). */
+int bg_plan_counts(const int32_t* rowptr, int64_t n_rows, float* count, bgStream stream);
+
+/* Chunk pointer of a CSR / segment pointer: chunk_ptr[r+1]-chunk_ptr[r] = ceil(len_r / rows_per_chunk).
+ * Used by the two-phase reductions over long segments (stories, graphs, program nodes).     */
+int bg_plan_chunks(const int32_t* rowptr, int64_t n_rows, int32_t rows_per_chunk,
+                   int32_t* chunk_ptr, bgStream stream);
+
+/* ------------------------------------------------------------------ segment kernels ----- */
+
+/* Scale modes for bg_spmm_f32 / bg_segreduce_f32 */
+#define BG_SCALE_NONE 0
+#define BG_SCALE_MUL 1
+#define BG_SCALE_DIV 2
+
+/* out[i,:] = rs(i) * sum_{k=rowptr[i]}^{rowptr[i+1]-1} w(k) * cs(c_k) * x[c_k,:],  c_k = col ? col[k] : k,
+ * w(k) = edge_w ? edge_w[eperm ? eperm[k] : k] : 1; rs / cs multiply or divide by row_scale[i] /
+ * col_scale[c] according to row_mode / col_mode.  Terms are added in slot order (the order
+ * torch_scatter's CPU kernels use), one wave per few rows, 16-byte gathers.  H % 4 == 0 uses the
+ * vector path (x, out 16-byte aligned, pitches % 4 == 0); any other H a scalar path.
+ * replaces: x.index_select + scatter(mean|sum) pairs: Model/models.py:65-68,158-161 (K1,K3),
+ * :71-72 (K4), :122-123 (K11), :133-138 (K12), :168-169; util_graph.py:28-40 (K14).         */
+int bg_spmm_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                const float* edge_w, const int32_t* eperm,
+                const float* row_scale, int row_mode, const float* col_scale, int col_mode,
+                float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream);
+
+/* Same contraction for LONG rows, two phases: phase 1 reduces chunks of at most rows_per_chunk
+ * slots (chunk_ptr from bg_plan_chunks, n_chunks_ub >= chunk_ptr[n_rows]) into
+ * partial[n_chunks_ub, H]; phase 2 adds a row's partials in chunk order.  Deterministic.
+ * replaces: avg_pool_x over stories / graphs, Model/models.py:166-167 (K5); the program-node
+ * side of the cross-edge scatters in util_graph.py:32 and the backward of models.py:113,122. */
+int bg_segreduce_sum_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                         const float* edge_w, const int32_t* eperm,
+                         const float* row_scale, int row_mode,
+                         const int32_t* chunk_ptr, int32_t rows_per_chunk, int64_t n_chunks_ub,
+                         float* partial, float* out, int64_t ldo, int64_t n_rows, int64_t H,
+                         bgStream stream);
+
+/* Segment max with arg: out[s,h] = max_{k in seg s} x[c_k,h], arg[s,h] = c_k of the FIRST maximum
+ * (slot order); an empty segment gives 0 and arg = -1.  Two phases as above;
+ * partial_val / partial_arg: [n_chunks_ub, H].
+ * replaces: tg.nn.global_max_pool, Model/models.py:262-263 (K13) incl. its scatter_max arg. */
+int bg_segmax_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                  const int32_t* chunk_ptr, int32_t rows_per_chunk, int64_t n_chunks_ub,
+                  float* partial_val, int32_t* partial_arg,
+                  float* out, int64_t ldo, int32_t* arg, int64_t n_rows, int64_t H, bgStream stream);
+
+/* out[s,h] = arg[s,h] >= 0 ? x[arg[s,h], h] : 0   (gather along the saved arg-max)
+ * replaces: the backward of torch_scatter.scatter_max used by global_max_pool's double backward. */
+int bg_gather_arg_f32(const float* x, int64_t ldx, const int32_t* arg, float* out, int64_t ldo,
+                      int64_t n_seg, int64_t H, bgStream stream);
+
+/* out (n_rows x H, zero-filled here) ; out[arg[s,h], h] = g[s,h] where arg >= 0.
+ * replaces: torch_scatter.scatter_max backward (gradient to the arg element only).          */
+int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, float* out, int64_t ldo,
+                       int64_t n_seg, int64_t n_rows, int64_t H, bgStream stream);
+
+/* out[k] = dot(a[r_k,:], b[c_k,:]) for every CSR slot k (r_k = the row owning slot k),
+ * written to out[eperm ? eperm[k] : k].   The weight-gradient of bg_spmm_f32.                */
+int bg_sddmm_f32(const float* a, int64_t lda, const float* b, int64_t ldb,
+                 const int32_t* rowptr, const int32_t* col, const int32_t* eperm,
+                 float* out, int64_t n_rows, int64_t H, bgStream stream);
+
+/* ------------------------------------------------------------------ cross attention ----- */
+
+/* att[k] = sum_h theta[h] * tanh(a[v,h] + b[c_k,h]) for the cross edges k of voxel v (CSR by
+ * voxel).  H % 64 == 0, H <= 512.
+ * replaces: Model/models.py:113-116 (K9) with NN_v / NN_p applied per node beforehand.      */
+int bg_cross_logits_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* theta,
+                        const int32_t* rowptr, const int32_t* col, float* att,
+                        int64_t n_vox, int64_t H, bgStream stream);
+
+/* Backward of bg_cross_logits_f32 given g[k]: dpre[k,h] = g[k]*theta[h]*(1-t^2) (written, [nnz,H]),
+ * da[v,:] = sum over v's edges of dpre, dtheta_partial[block,h] = sum g[k]*t[k,h] over the
+ * block's voxels (n_blocks rows; add them up with bg_segreduce_sum_f32 / a column sum).      */
+int bg_cross_logits_bwd_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* theta,
+                            const int32_t* rowptr, const int32_t* col, const float* g,
+                            float* dpre, float* da, int64_t ldda, float* dtheta_partial, int32_t n_blocks,
+                            int64_t n_vox, int64_t H, bgStream stream);
+
+/* Segment Gumbel-softmax pointer over CSR segments (one segment per voxel, slots contiguous):
+ * y = (att - log(expn)) / tau; soft = exp(y - max y) / (sum + 1e-16); arg[v] = slot of the first
+ * maximum of soft; hard = (onehot - soft) + soft.
+ * replaces: util.py:13-28 gumbel_softmax (K10), called at Model/models.py:118.               */
+int bg_seg_gumbel_softmax_f32(const float* att, const float* expn, const int32_t* rowptr, float tau,
+                              float* soft, float* hard, int32_t* arg, int64_t n_seg, bgStream stream);
+
+/* d_att[k] = soft[k] * (g[k] - sum_seg soft*g) / tau    (backward of the soft output)        */
+int bg_seg_softmax_bwd_f32(const float* soft, const float* g, const int32_t* rowptr, float tau,
+                           float* d_att, int64_t n_seg, bgStream stream);
+
+/* arg[v] = slot of the first maximum of logit over v's slots (-1 if none).
+ * replaces: util_graph.py:44-48 find_max_out_program_index's scatter_max (K12).              */
+int bg_seg_argmax_f32(const float* logit, const int32_t* rowptr, int32_t* arg, int64_t n_seg,
+                      bgStream stream);
+
+/* ------------------------------------------------------------------ dense (fp32 MFMA) --- */
+
+#define BG_ACT_NONE 0
+#define BG_ACT_LEAKY 1
+
+/* C[M,N] = epilogue( sum_s opA(A_s) * opB(B)[koff_s : koff_s+K_s, :] ),  koff_s = K_0+..+K_{s-1}
+ *   transA == 0: A_s is [M, K_s] (pitch lda[s]);  transA == 1: A_s is [K_s, M]
+ *   transB == 0: B is [K, N] (pitch ldb);         transB == 1: B is [N, K]  (nn.Linear weight)
+ *   epilogue(v)[m,n] = act(row_scale[m] * (v + bias[n])) + residual[m,n]; each part optional.
+ * n_seg in 1..4 fuses torch.cat((A_0,..), -1) into the product.  Exact fp32 (v_mfma_f32_32x32x2_f32).
+ * Vector path needs 16-byte aligned bases and pitches / K_s % 4 == 0; anything else runs a
+ * scalar-load path of the same kernel.
+ * replaces: nn.Linear / torch.cat at Model/models.py:68,73,89,161,170,172,191,221,224,257-258 (K2,K15). */
+int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
+                const float* const* A, const int64_t* lda, const int64_t* Ks,
+                const float* B, int64_t ldb, float* C, int64_t ldc,
+                const float* bias, const float* row_scale, int act, float slope,
+                const float* residual, int64_t ldr, bgStream stream);
+
+/* C[M,N] = A^T[M,R] * B[R,N] with the long reduction R split over `splits` workgroups per tile:
+ * A is [R, M] (pitch lda), B is [R, N] (pitch ldb); partial: [splits, M, N] workspace.
+ * Partials are added in split order (deterministic).  The weight-gradient GEMM.
+ * replaces: the grad-weight product of nn.Linear's autograd for the layers listed above.     */
+int bg_gemm_tn_splitk_f32(int64_t M, int64_t N, int64_t R, const float* A, int64_t lda,
+                          const float* B, int64_t ldb, float* C, int64_t ldc,
+                          float* partial, int32_t splits, bgStream stream);
+
+/* out[n] = sum_m x[m,n]   (bias gradient); partial: [n_blocks, N] workspace                  */
+int bg_colsum_f32(const float* x, int64_t ldx, int64_t M, int64_t N, float* partial, int32_t n_blocks,
+                  float* out, bgStream stream);
+
+/* ------------------------------------------------------------------ optimiser ----------- */
+
+/* One Adam step on a flat fp32 buffer (torch.optim.Adam semantics, no weight decay/amsgrad):
+ * m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * replaces: optimizer_G.step() / optimizer_D.step(), train.py:101,114.                       */
+int bg_adam_f32(float* param, const float* grad, float* m, float* v, int64_t n,
+                float lr, float beta1, float beta2, float eps, int32_t step, bgStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGAN_H */

@@ -1,0 +1,297 @@
+"""Kernel-level parity of the HIP path (through the C-ABI) against the CPU oracle.
+
+Bar: bit-exact for integer plans and arg-max indices; fp32 results within the stated tolerance
+(rtol 1e-4 from BASELINE.json's north_star, tighter where the summation order is identical).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def _batch(preset="small", seed=0, ragged=True):
+    from building_gan_amd.synthetic import make_batch
+    return make_batch(preset, seed=seed, ragged=ragged)
+
+
+def _plan(batch, dev):
+    from building_gan_amd.plan import build_plan
+    g = batch.to(dev)
+    return g, build_plan(g)
+
+
+@pytest.mark.parametrize("preset,ragged", [("tiny", False), ("small", True), ("dataset", False)])
+def test_plans_bit_exact(cuda, preset, ragged):
+    from oracle import plan as oplan
+    cpu = _batch(preset, 1, ragged)
+    import copy
+    g, p = _plan(copy.deepcopy(cpu), cuda)
+    ve = cpu.voxel_edge.numpy()
+    rp, col, perm = oplan.csr_by_key(ve[1], ve[0], p.Nv)
+    c = p.vox_mean.csr
+    assert np.array_equal(c.rowptr.cpu().numpy(), rp)
+    assert np.array_equal(c.col.cpu().numpy(), col)
+    assert np.array_equal(c.perm.cpu().numpy(), perm)
+    rp, col, perm = oplan.csr_by_key(ve[0], ve[1], p.Nv)
+    c = p.vox_mean.T.csr
+    assert np.array_equal(c.rowptr.cpu().numpy(), rp) and np.array_equal(c.col.cpu().numpy(), col)
+    assert np.array_equal(c.perm.cpu().numpy(), perm)
+    deg = np.diff(oplan.csr_by_key(ve[1], ve[0], p.Nv)[0])
+    assert np.array_equal(p.vox_mean.csr.count.cpu().numpy(), np.maximum(deg, 1).astype(np.float32))
+    cep = cpu.cross_edge_program_index_select.numpy()
+    cev = cpu.cross_edge_voxel_index_select.numpy()
+    rp, col, perm = oplan.csr_by_key(cep, cev, p.Np)          # long rows: exercises the bitonic row sort
+    c = p.cross_p
+    assert np.array_equal(c.rowptr.cpu().numpy(), rp) and np.array_equal(c.col.cpu().numpy(), col)
+    assert np.array_equal(c.perm.cpu().numpy(), perm)
+    rp, col, perm = oplan.csr_by_key(cev, cep, p.Nv)
+    assert np.array_equal(p.cross_v.rowptr.cpu().numpy(), rp) and np.array_equal(p.cross_v.col.cpu().numpy(), col)
+    assert np.array_equal(p.story_seg.rowptr.cpu().numpy(), oplan.segment_ptr(cpu.voxel_floor_cluster.numpy(), p.S))
+    assert np.array_equal(p.graph_seg.rowptr.cpu().numpy(), oplan.segment_ptr(cpu.voxel_feature_batch.numpy(), p.B))
+    assert np.array_equal(p.level.cpu().numpy(),
+                          oplan.floor_level(cpu.voxel_floor_cluster.numpy(), cpu.voxel_feature_batch.numpy()))
+    for csr in (p.story_seg, p.cross_p):
+        seg, st, en, cptr = oplan.chunk_table(csr.rowptr.cpu().numpy(), csr.rows_per_chunk)
+        assert np.array_equal(csr.chunk_ptr.cpu().numpy(), cptr)
+        assert csr.n_chunks_ub >= cptr[-1]
+
+
+def test_plan_unsorted_random_keys(cuda):
+    """Random (unsorted, skewed) keys incl. empty rows and one very long row (> LDS sort size)."""
+    from building_gan_amd.plan import _Builder
+    from oracle import plan as oplan
+    rng = np.random.default_rng(3)
+    N, E = 1000, 60000
+    key = rng.integers(0, N, size=E)
+    key[rng.random(E) < 0.15] = 7            # ~9000 edges in one row -> global-memory bitonic path
+    key[key == 11] = 12                      # an empty row
+    other = rng.integers(0, 500, size=E)
+    b = _Builder(cuda)
+    c = b.csr("t", torch.from_numpy(key).to(cuda), torch.from_numpy(other).to(cuda), N, 500)
+    flags, _ = b.finish(torch.zeros(1, dtype=torch.int32, device=cuda))
+    rp, col, perm = oplan.csr_by_key(key, other, N)
+    assert flags["t"][0] == 0
+    assert np.array_equal(c.rowptr.cpu().numpy(), rp)
+    assert np.array_equal(c.perm.cpu().numpy(), perm)
+    assert np.array_equal(c.col.cpu().numpy(), col)
+
+
+@pytest.mark.parametrize("H", [128, 256, 8, 6, 1])
+def test_gather_mean_matches_scatter_mean(cuda, H):
+    from building_gan_amd import ops
+    from oracle.scatter import scatter_mean
+    import copy
+    cpu = _batch("small", 2, True)
+    g, p = _plan(copy.deepcopy(cpu), cuda)
+    torch.manual_seed(0)
+    x = torch.rand(p.Nv, H) * 2 - 1
+    ref = scatter_mean(x.index_select(0, cpu.voxel_edge[0]), cpu.voxel_edge[1], p.Nv)
+    out = ops.spmm_raw(p.vox_mean, x.to(cuda)).cpu()
+    # same summation order + IEEE division: expected to agree to the last bit
+    assert torch.equal(out, ref)
+    # transposed operator against autograd of the oracle
+    xg = x.clone().requires_grad_(True)
+    go = torch.rand(p.Nv, H) * 2 - 1
+    scatter_mean(xg.index_select(0, cpu.voxel_edge[0]), cpu.voxel_edge[1], p.Nv).backward(go)
+    outT = ops.spmm_raw(p.vox_mean.T, go.to(cuda)).cpu()
+    torch.testing.assert_close(outT, xg.grad, rtol=RTOL, atol=ATOL)
+
+
+def test_pooling_and_segmax(cuda):
+    from building_gan_amd import ops
+    from oracle.scatter import avg_pool_x, global_max_pool, scatter_max
+    import copy
+    cpu = _batch("small", 4, True)
+    g, p = _plan(copy.deepcopy(cpu), cuda)
+    torch.manual_seed(1)
+    H = 256
+    x = torch.rand(p.Nv, H) * 2 - 1
+    x[3] = x[5]                                   # ties inside a segment -> first index must win
+    xd = x.to(cuda)
+    story_ref, story_batch = avg_pool_x(cpu.voxel_floor_cluster, x, cpu.voxel_feature_batch)
+    story = ops.spmm_raw(p.story_mean, xd)
+    torch.testing.assert_close(story.cpu(), story_ref, rtol=RTOL, atol=ATOL)
+    bld_ref = avg_pool_x(story_batch, story_ref, torch.zeros(story_ref.shape[0], dtype=torch.long))[0]
+    bld = ops.spmm_raw(p.graph_of_story_mean, story)
+    torch.testing.assert_close(bld.cpu(), bld_ref, rtol=RTOL, atol=ATOL)
+    sv = ops.spmm_raw(p.story_gather, story).cpu()
+    torch.testing.assert_close(sv, story_ref.index_select(0, cpu.voxel_floor_cluster), rtol=RTOL, atol=ATOL)
+    for csr, idx, n in ((p.story_seg, cpu.voxel_floor_cluster, p.S), (p.graph_seg, cpu.voxel_feature_batch, p.B)):
+        val, arg = ops.segmax_raw(csr, xd)
+        rv, ra = scatter_max(x, idx, n)
+        assert torch.equal(val.cpu(), rv)                      # max is exact
+        assert torch.equal(arg.cpu().long(), ra)               # first index on ties, bit-exact
+        assert torch.equal(global_max_pool(x, idx), val.cpu())
+
+
+def test_segmax_empty_segment(cuda):
+    from building_gan_amd import ops
+    from building_gan_amd.plan import _Builder
+    from oracle.scatter import scatter_max
+    seg = torch.tensor([0, 0, 2, 2, 2, 4], dtype=torch.long)       # segments 1 and 3 are empty
+    x = torch.tensor([[1., -2.], [1., 5.], [-3., -3.], [-1., -4.], [-1., -3.], [0., 0.]])
+    b = _Builder(cuda)
+    c = b.csr("s", seg.to(cuda), torch.arange(6).to(cuda), 5, 6)
+    b.maybe_chunks(c, force=True)
+    val, arg = ops.segmax_raw(c, x.to(cuda))
+    rv, ra = scatter_max(x, seg, 5)
+    assert torch.equal(val.cpu(), rv)
+    ra = torch.where(ra == 6, torch.full_like(ra, -1), ra)         # oracle sentinel E -> library sentinel -1
+    assert torch.equal(arg.cpu().long(), ra)
+
+
+@pytest.mark.parametrize("shape", [(300, 128, [128, 128, 4]), (1000, 256, [256, 256, 4]), (77, 2, [64]),
+                                   (513, 128, [39]), (2000, 128, [128, 128, 128, 128]), (130, 64, [128]),
+                                   (20000, 128, [128, 128, 4])])
+def test_gemm_linear_cat(cuda, shape):
+    from building_gan_amd import ops
+    M, N, Ks = shape
+    torch.manual_seed(M)
+    xs = [torch.rand(M, k) * 2 - 1 for k in Ks]
+    W = torch.rand(N, sum(Ks)) * 2 - 1
+    b = torch.rand(N) * 2 - 1
+    rs = (torch.rand(M) > 0.2).float()
+    ref = (torch.cat(xs, 1).double() @ W.double().t() + b.double()) * rs.double().view(-1, 1)
+    ref = torch.nn.functional.leaky_relu(ref, 0.01)
+    out = ops.gemm_raw([x.to(cuda) for x in xs], W.to(cuda), False, True, bias=b.to(cuda), row_scale=rs.to(cuda),
+                       act=ops.ACT_LEAKY, slope=0.01)
+    scale = torch.cat(xs, 1).abs().double() @ W.abs().double().t()
+    err = (out.cpu().double() - ref).abs()
+    assert float((err / (scale + 1.0)).max()) < 2e-6          # fp32 fma chain vs fp64
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_layouts(cuda, ta, tb):
+    from building_gan_amd import ops
+    torch.manual_seed(5)
+    M, N, K = 333, 200, 1028
+    A = torch.rand(K, M) * 2 - 1 if ta else torch.rand(M, K) * 2 - 1
+    B = torch.rand(N, K) * 2 - 1 if tb else torch.rand(K, N) * 2 - 1
+    ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double()
+    out = ops.MatMul.apply(A.to(cuda), B.to(cuda), ta, tb).cpu().double()
+    assert float((out - ref).abs().max()) < 1e-3 * 1e-1 * K ** 0.5
+    # asymmetric identity check (catches transposed C writes)
+    eye = torch.eye(64)
+    Bm = torch.arange(64 * 48, dtype=torch.float32).view(64, 48)
+    out = ops.gemm_raw([eye.to(cuda)], Bm.to(cuda), False, False).cpu()
+    assert torch.equal(out, Bm)
+
+
+def test_gemm_tn_splitk_and_colsum(cuda):
+    from building_gan_amd import ops
+    torch.manual_seed(6)
+    R, M, N = 11520, 256, 516
+    A = torch.rand(R, M) * 2 - 1
+    B = torch.rand(R, N) * 2 - 1
+    out = ops.gemm_tn_raw(A.to(cuda), B.to(cuda)).cpu().double()
+    ref = A.double().t() @ B.double()
+    assert float((out - ref).abs().max()) < 2e-3
+    cs = ops.colsum_raw(A.to(cuda)).cpu().double()
+    assert float((cs - A.double().sum(0)).abs().max()) < 2e-3
+
+
+def test_segment_gumbel_softmax_and_argmax(cuda):
+    from building_gan_amd import ops
+    from oracle.pointer import segment_gumbel_softmax, find_max_out_program_index
+    import copy
+    cpu = _batch("dataset", 7, False)
+    g, p = _plan(copy.deepcopy(cpu), cuda)
+    cev, cep = cpu.cross_edge_voxel_index_select, cpu.cross_edge_program_index_select
+    torch.manual_seed(7)
+    att = (torch.rand(p.Ec) * 2 - 1).requires_grad_(True)
+    noise = torch.empty(p.Ec).exponential_()
+    soft_ref, hard_ref = segment_gumbel_softmax(att, cev, exp_noise=noise)
+    attd = att.detach().to(cuda).requires_grad_(True)
+    soft, hard, arg = ops.SegGumbelSoftmax.apply(attd, noise.to(cuda), p, -1.0)
+    torch.testing.assert_close(soft.cpu(), soft_ref.detach(), rtol=RTOL, atol=1e-7)
+    torch.testing.assert_close(hard.cpu(), hard_ref.detach(), rtol=RTOL, atol=1e-6)
+    # the pointer itself: bit-exact
+    from oracle.scatter import scatter_max
+    arg_ref = scatter_max(soft_ref.detach(), cev, p.Nv)[1]
+    assert torch.equal(arg.cpu().long(), arg_ref)
+    # backward of (soft, hard) with random cotangents
+    g1, g2 = torch.rand(p.Ec), torch.rand(p.Ec)
+    (soft_ref * g1 + hard_ref * g2).sum().backward()
+    (soft * g1.to(cuda) + hard * g2.to(cuda)).sum().backward()
+    torch.testing.assert_close(attd.grad.cpu(), att.grad, rtol=1e-3, atol=1e-6)
+    # arg-max program index with masked voxels (all-zero segments tie -> first edge)
+    mask = (torch.rand(p.Nv, 1) > 0.5).float()
+    logit = hard_ref.detach().view(-1, 1) * mask.index_select(0, cev)
+    idx_ref = find_max_out_program_index(logit, cev, cep, p.Nv).view(-1)
+    a2 = ops.seg_argmax(logit.to(cuda), p)
+    idx = g.cross_edge_program_index_select[a2.long()]
+    assert torch.equal(idx.cpu(), idx_ref)
+
+
+def test_cross_logits_forward_backward(cuda):
+    from building_gan_amd import ops
+    import copy
+    cpu = _batch("small", 8, True)
+    g, p = _plan(copy.deepcopy(cpu), cuda)
+    cev, cep = cpu.cross_edge_voxel_index_select, cpu.cross_edge_program_index_select
+    torch.manual_seed(8)
+    H = 128
+    a = (torch.rand(p.Nv, H) * 2 - 1).requires_grad_(True)
+    b = (torch.rand(p.Np, H) * 2 - 1).requires_grad_(True)
+    th = (torch.rand(1, H) * 2 - 1).requires_grad_(True)
+    ref = (th.view(1, -1) * torch.tanh(a.index_select(0, cev) + b.index_select(0, cep))).sum(-1)
+    go = torch.rand(p.Ec) * 2 - 1
+    ref.backward(go)
+    ad, bd, thd = (t.detach().to(cuda).requires_grad_(True) for t in (a, b, th))
+    out = ops.CrossLogits.apply(ad, bd, thd, p)
+    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=RTOL, atol=1e-5)
+    out.backward(go.to(cuda))
+    torch.testing.assert_close(ad.grad.cpu(), a.grad, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(thd.grad.cpu(), th.grad, rtol=1e-3, atol=1e-4)
+
+
+def test_weighted_sum_and_sddmm(cuda):
+    from building_gan_amd import ops
+    from oracle.scatter import scatter_sum
+    import copy
+    cpu = _batch("small", 9, True)
+    g, p = _plan(copy.deepcopy(cpu), cuda)
+    cev, cep = cpu.cross_edge_voxel_index_select, cpu.cross_edge_program_index_select
+    torch.manual_seed(9)
+    for H in (128, 6):
+        x = (torch.rand(p.Np, H) * 2 - 1).requires_grad_(True)
+        w = torch.rand(p.Ec).requires_grad_(True)
+        ref = scatter_sum(w.view(-1, 1) * x[cep], cev, p.Nv)
+        go = torch.rand(p.Nv, H) * 2 - 1
+        ref.backward(go)
+        xd, wd = x.detach().to(cuda).requires_grad_(True), w.detach().to(cuda).requires_grad_(True)
+        out = ops.SpMMW.apply(xd, wd, p.cross_v_sum)
+        torch.testing.assert_close(out.cpu(), ref.detach(), rtol=RTOL, atol=1e-5)
+        out.backward(go.to(cuda))
+        torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=1e-3, atol=1e-5)
+
+
+def test_adam_matches_torch(cuda):
+    from building_gan_amd import ops
+    torch.manual_seed(10)
+    n = 10007
+    p0 = torch.rand(n) * 2 - 1
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-4, betas=(0.5, 0.999))
+    p, m, v = p0.to(cuda), torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+    for step in range(1, 4):
+        gr = torch.rand(n) * 2 - 1
+        ref.grad = gr.clone()
+        opt.step()
+        ops.adam_step(p, gr.to(cuda), m, v, 1e-4, 0.5, 0.999, 1e-8, step)
+    torch.testing.assert_close(p.cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_bad_arguments_are_rejected(cuda):
+    from building_gan_amd import _lib
+    lib = _lib.load()
+    assert lib.bg_spmm_f32(None, 4, None, None, None, None, None, 0, None, 0, None, 4, 10, 4, None) == -1
+    assert lib.bg_cross_logits_f32(1, 100, 1, 100, 1, 1, 1, 1, 10, 100, None) == -2   # H % 64 != 0
+    with pytest.raises(_lib.BganError):
+        from building_gan_amd import ops
+        ops.gemm_raw([torch.zeros(4, 4)], torch.zeros(4, 4), False, True)            # CPU tensors: no fallback

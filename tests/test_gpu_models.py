@@ -1,0 +1,133 @@
+"""End-to-end parity of the HIP-backed networks against the CPU oracle on identical weights,
+inputs and noise: generator forward, discriminator forward, first-order gradients, the WGAN-GP
+double backward, and one full training iteration.  fp32 tolerance: rtol 1e-4 on activations
+(north_star), a looser bound on gradients that pass through 12-16 layers.
+"""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(preset, seed, ragged, dev, layers=(4, 12)):
+    from building_gan_amd import models as hm
+    from building_gan_amd.synthetic import batch_sizes, make_batch
+    from oracle import networks as om
+    cpu = make_batch(preset, seed=seed, ragged=ragged)
+    sz = batch_sizes(cpu)
+    torch.manual_seed(seed)
+    Go = om.Generator(7, 7, 128, 32, layers[0], layers[1])
+    Do = om.DiscriminatorVoxel(7, 6, 128, layers[1])
+    Gh = hm.Generator(7, 7, 128, 32, layers[0], layers[1], dev).to(dev)
+    Dh = hm.DiscriminatorVoxel(7, 6, 128, layers[1]).to(dev)
+    Gh.load_state_dict(Go.state_dict())
+    Dh.load_state_dict(Do.state_dict())
+    n_att = 1 + sum(1 for i in range(layers[1]) if i % 2 == 0 and i != 0)
+    noise = [(torch.empty(sz["Nv"], 2).exponential_(), torch.empty(sz["Ec"]).exponential_()) for _ in range(n_att)]
+    pz, vz = torch.rand(sz["Np"], 32), torch.rand(sz["Nv"], 32)
+    gpu = copy.deepcopy(cpu).to(dev)
+    return cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz
+
+
+def _to(noise, dev):
+    return [(a.to(dev), b.to(dev)) for a, b in noise]
+
+
+def test_state_dict_keys_match_reference_checkpoint_layout(cuda):
+    from building_gan_amd import models as hm
+    G = hm.Generator(7, 7, 128, 32, 4, 12, cuda)
+    keys = set(G.state_dict().keys())
+    expect = {"programGNN.enc.0.weight", "programGNN.block.messageMLP.0.weight", "programGNN.block.updateMLP.0.bias",
+              "voxelGNN.pe", "voxelGNN.enc.0.weight", "voxelGNN.attention.theta", "voxelGNN.attention.dec.1.weight",
+              "voxelGNN.attention.NN_v.weight", "voxelGNN.attention.NN_p.bias", "voxelGNN.block.messageMLP.0.weight",
+              "voxelGNN.block.updateMLP.0.weight"}
+    assert expect <= keys
+    assert sum(p.numel() for p in G.parameters()) == 228418
+    D = hm.DiscriminatorVoxel(7, 6, 128, 12)
+    assert sum(p.numel() for p in D.parameters()) == 331010
+
+
+@pytest.mark.parametrize("preset,ragged", [("tiny", False), ("small", True)])
+def test_generator_forward_parity(cuda, preset, ragged):
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup(preset, 11, ragged, cuda)
+    with torch.no_grad():
+        ro = Go(cpu, pz, vz, noise)
+        rh = Gh(gpu, pz.to(cuda), vz.to(cuda), _to(noise, cuda))
+    out_o, soft_o, mask_o, att_o, idx_o = ro
+    out_h, soft_h, mask_h, att_h, idx_h = rh
+    torch.testing.assert_close(mask_h["soft"].cpu(), mask_o["soft"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(att_h["soft"].cpu(), att_o["soft"], rtol=1e-4, atol=1e-5)
+    # discrete outputs: identical unless a near-tie flips (none at these sizes / seeds)
+    assert torch.equal(idx_h.cpu(), idx_o)
+    torch.testing.assert_close(out_h.cpu(), out_o, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(soft_h.cpu(), soft_o, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(mask_h["hard"].cpu(), mask_o["hard"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("preset,ragged", [("tiny", False), ("small", True)])
+def test_discriminator_forward_backward_parity(cuda, preset, ragged):
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup(preset, 12, ragged, cuda)
+    lab_o = cpu.voxel_label.clone().requires_grad_(True)
+    lab_h = gpu.voxel_label.clone().requires_grad_(True)
+    bo, so = Do(cpu, lab_o)
+    bh, sh = Dh(gpu, lab_h)
+    torch.testing.assert_close(bh.cpu(), bo, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(sh.cpu(), so, rtol=1e-4, atol=1e-4)
+    (bo.sum() + 2 * so.sum()).backward()
+    (bh.sum() + 2 * sh.sum()).backward()
+    torch.testing.assert_close(lab_h.grad.cpu(), lab_o.grad, rtol=1e-3, atol=1e-4)
+    for (n, po), (_, ph) in zip(Do.named_parameters(), Dh.named_parameters()):
+        scale = float(po.grad.abs().max()) + 1e-6
+        assert float((ph.grad.cpu() - po.grad).abs().max()) <= 2e-3 * scale, n
+
+
+def test_gradient_penalty_double_backward_parity(cuda):
+    from building_gan_amd.graph import detach_batch
+    from building_gan_amd.losses import compute_gradient_penalty as gp_h
+    from oracle.objectives import compute_gradient_penalty as gp_o
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 13, True, cuda)
+    torch.manual_seed(13)
+    u = torch.rand(sz["Nv"], 1)
+    soft = torch.rand(sz["Nv"], 6).softmax(-1) * (torch.rand(sz["Nv"], 1) > 0.3).float()
+    go, _, _ = gp_o(Do, detach_batch(cpu), cpu.voxel_label, soft, u)
+    gh, _, _ = gp_h(Dh, detach_batch(gpu), gpu.voxel_label, soft.to(cuda), u.to(cuda))
+    torch.testing.assert_close(gh.cpu(), go, rtol=1e-3, atol=1e-5)
+    go.backward()
+    gh.backward()
+    for (n, po), (_, ph) in zip(Do.named_parameters(), Dh.named_parameters()):
+        if po.grad is None:
+            assert ph.grad is None or float(ph.grad.abs().max()) == 0.0, n
+            continue
+        scale = float(po.grad.abs().max()) + 1e-6
+        assert float((ph.grad.cpu() - po.grad).abs().max()) <= 5e-3 * scale, n
+
+
+def test_generator_backward_through_discriminator(cuda):
+    from oracle.objectives import g_loss_fn
+    from building_gan_amd.losses import VolumetricDesignLoss_G
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 14, True, cuda)
+    out_o, soft_o, mask_o, att_o, _ = Go(cpu, pz, vz, noise)
+    lo = g_loss_fn(Do(cpu, out_o), cpu, att_o["hard"], mask_o["hard"], 6)[0]
+    lo.backward()
+    out_h, soft_h, mask_h, att_h, _ = Gh(gpu, pz.to(cuda), vz.to(cuda), _to(noise, cuda))
+    lh = VolumetricDesignLoss_G()(Dh(gpu, out_h), gpu, att_h["hard"], mask_h["hard"], 6)[0]
+    lh.backward()
+    torch.testing.assert_close(lh.cpu(), lo, rtol=1e-4, atol=1e-4)
+    for (n, po), (_, ph) in zip(Go.named_parameters(), Gh.named_parameters()):
+        scale = float(po.grad.abs().max()) + 1e-6
+        assert float((ph.grad.cpu() - po.grad).abs().max()) <= 1e-2 * scale, n
+
+
+def test_program_ratio_parity(cuda):
+    from building_gan_amd.util_graph import get_program_ratio as h
+    from oracle.pointer import get_program_ratio as o
+    cpu, gpu, sz, *_ = _setup("small", 15, True, cuda)
+    torch.manual_seed(15)
+    att = torch.rand(sz["Ec"], 1)
+    mask = (torch.rand(sz["Nv"], 1) > 0.4).float()
+    ro = o(cpu, att, mask, 6)
+    rh = h(gpu, att.to(cuda), mask.to(cuda), 6)
+    for a, b in zip(rh, ro):
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-4, atol=1e-6)
