@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--preset", default="dataset")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of hipGraph replay")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,14 +155,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.no_graph:
+        step_fn = lambda it: trainer.train_iteration(batch, it)
+    else:
+        trainer.capture(batch)
+        step_fn = trainer.train_iteration_graphed
     i = 0
     for _ in range(args.warmup):
-        trainer.train_iteration(batch, i)
+        step_fn(i)
         i += 1
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.train_iteration(batch, i)
+        step_fn(i)
         i += 1
     sync()
     dt = time.perf_counter() - t0
@@ -180,7 +186,8 @@ def main():
                                    "(10 stories x 12x12 voxels, 4 program nodes/story)" % sz["B"],
                        "preset": args.preset, "graphs_per_gpu": sz["B"], "Nv": sz["Nv"], "Ev": sz["Ev"], "Ec": sz["Ec"],
                        "Np": sz["Np"], "hidden": 128, "voxel_layer": 12, "program_layer": 4,
-                       "n_critic_g": 5, "parallelism": "dp%d" % world},
+                       "n_critic_g": 5, "parallelism": "dp%d" % world,
+                       "launch": "eager" if args.no_graph else "hipGraph segments + eager RCCL all-reduce"},
         }
         line["roofline"] = roofline_dominant_gemm(dev, sz["Nv"])
         if world == 1 and not args.no_microbench:

@@ -11,6 +11,7 @@
 // Both feed the same k order to the MFMA: step j of an 8-deep group multiplies k = 8g+j (lanes
 // 0-31) and k = 8g+4+j (lanes 32-63) -- a permutation of k that both operands share.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -217,6 +218,25 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 
 __global__ void k_splitk_reduce(const float* __restrict__ partial, int splits, int64_t M, int64_t N,
                                 float* __restrict__ C, int64_t ldc) {
+    // one float4 of C per thread (M*N % 4 == 0 checked by the launcher), splits added in order
+    const int64_t MN = M * N;
+    int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (t >= MN) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {
+        float4 a = bg_ld4(partial + (int64_t)z * MN + t), b = bg_ld4(partial + (int64_t)(z + 1) * MN + t);
+        float4 c = bg_ld4(partial + (int64_t)(z + 2) * MN + t), d = bg_ld4(partial + (int64_t)(z + 3) * MN + t);
+        acc = bg_add4(acc, a); acc = bg_add4(acc, b); acc = bg_add4(acc, c); acc = bg_add4(acc, d);
+    }
+    for (; z < splits; ++z) acc = bg_add4(acc, bg_ld4(partial + (int64_t)z * MN + t));
+    float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) C[((t + j) / N) * ldc + ((t + j) % N)] = v[j];
+}
+
+__global__ void k_splitk_reduce_scalar(const float* __restrict__ partial, int splits, int64_t M, int64_t N,
+                                       float* __restrict__ C, int64_t ldc) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M * N) return;
     float acc = 0.f;
@@ -224,22 +244,42 @@ __global__ void k_splitk_reduce(const float* __restrict__ partial, int splits, i
     C[(t / N) * ldc + (t % N)] = acc;
 }
 
+// Column sums, phase 1: workgroup (bx, by) owns 64 columns x rows [by*RPB, (by+1)*RPB); its 4 waves
+// take every 4th row, 8 loads in flight per lane; the waves' sums are combined through LDS.
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ x, int64_t ldx, int64_t M, int64_t N,
-                                                        float* __restrict__ partial) {
-    // block b sums rows b, b+grid, ...; thread t owns columns t, t+256, ...
-    for (int64_t n = threadIdx.x; n < N; n += 256) {
-        float acc = 0.f;
-        for (int64_t m = blockIdx.x; m < M; m += gridDim.x) acc += x[m * ldx + n];
-        partial[(int64_t)blockIdx.x * N + n] = acc;
+                                                        int rows_per_block, float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(r0 + rows_per_block, M);
+    float acc = 0.f;
+    if (n < N) {
+        int64_t m = r0 + wave;
+        for (; m + 28 < r1; m += 32) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = x[(m + 4 * j) * ldx + n];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+        for (; m < r1; m += 4) acc += x[m * ldx + n];
     }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && n < N) partial[(int64_t)blockIdx.y * N + n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-__global__ void k_colsum_final(const float* __restrict__ partial, int n_blocks, int64_t N, float* __restrict__ out) {
-    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// phase 2: one wave per column adds the row-block partials (fixed shuffle tree: deterministic)
+__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ partial, int n_blocks, int64_t N,
+                                                      float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     float acc = 0.f;
-    for (int b = 0; b < n_blocks; ++b) acc += partial[(int64_t)b * N + n];
-    out[n] = acc;
+    for (int b = lane; b < n_blocks; b += 64) acc += partial[(int64_t)b * N + n];
+    acc = bg_wave_sum(acc);
+    if (lane == 0) out[n] = acc;
 }
 
 template <int BM, int BN, bool SPLIT>
@@ -267,6 +307,17 @@ int launch_gemm(int transA, int transB, bool vec, const GemmArgs& g, int splits,
 bool operand_vec_ok(const float* p, int64_t ld, bool kc, int64_t K, int64_t rows) {
     if (!bg_aligned16(p) || ld % 4 != 0) return false;
     return kc ? (K % 4 == 0) : (rows % 4 == 0);
+}
+
+// tuning hook: BG_GEMM_TILE = 1..4 forces 64x64 / 128x64 / 64x128 / 128x128 (unset: heuristic)
+int tile_override() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char* e = getenv("BG_GEMM_TILE");
+        cached = e ? atoi(e) : 0;
+        if (cached < 0 || cached > 4) cached = 0;
+    }
+    return cached;
 }
 
 }  // namespace
@@ -304,9 +355,19 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
     g.residual = residual; g.ldr = ldr; g.M = M; g.N = N;
     g.total_steps = steps; g.steps_per_split = steps; g.partial = nullptr;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    if (big_tiles >= 256) return launch_gemm<128, 128, false>(transA, transB, vec, g, 1, st);
-    return launch_gemm<64, 64, false>(transA, transB, vec, g, 1, st);
+    int tile = tile_override();
+    if (tile == 0) {
+        const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
+        tile = big_tiles >= 256 ? 3 : 0;
+    } else {
+        tile -= 1;
+    }
+    switch (tile) {
+        case 3: return launch_gemm<128, 128, false>(transA, transB, vec, g, 1, st);
+        case 2: return launch_gemm<64, 128, false>(transA, transB, vec, g, 1, st);
+        case 1: return launch_gemm<128, 64, false>(transA, transB, vec, g, 1, st);
+        default: return launch_gemm<64, 64, false>(transA, transB, vec, g, 1, st);
+    }
 }
 
 int bg_gemm_tn_splitk_f32(int64_t M, int64_t N, int64_t R, const float* A, int64_t lda,
@@ -326,7 +387,10 @@ int bg_gemm_tn_splitk_f32(int64_t M, int64_t N, int64_t R, const float* A, int64
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_gemm<64, 64, true>(1, 0, vec, g, splits, st);
     if (rc != BG_OK) return rc;
-    k_splitk_reduce<<<bg_grid_for(M * N, 256, 0x7fffffff), 256, 0, st>>>(partial, splits, M, N, C, ldc);
+    if ((M * N) % 4 == 0 && bg_aligned16(partial))
+        k_splitk_reduce<<<bg_grid_for((M * N) / 4, 256, 0x7fffffff), 256, 0, st>>>(partial, splits, M, N, C, ldc);
+    else
+        k_splitk_reduce_scalar<<<bg_grid_for(M * N, 256, 0x7fffffff), 256, 0, st>>>(partial, splits, M, N, C, ldc);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }
@@ -337,9 +401,11 @@ int bg_colsum_f32(const float* x, int64_t ldx, int64_t M, int64_t N, float* part
     if (N == 0) return BG_OK;
     if (!out || !partial || (M > 0 && (!x || ldx < N))) return BG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    k_colsum_partial<<<n_blocks, 256, 0, s>>>(x, ldx, M, N, partial);
+    const int rows_per_block = (int)((M + n_blocks - 1) / n_blocks);
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)n_blocks);
+    k_colsum_partial<<<grid, 256, 0, s>>>(x, ldx, M, N, rows_per_block > 0 ? rows_per_block : 1, partial);
     BG_LAUNCH_CHECK();
-    k_colsum_final<<<bg_grid_for(N, 256), 256, 0, s>>>(partial, n_blocks, N, out);
+    k_colsum_final<<<bg_grid_for(N, 4), 256, 0, s>>>(partial, n_blocks, N, out);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -166,7 +166,7 @@ def gemm_tn_raw(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
         return out
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     steps = (R + 31) // 32
-    splits = max(1, min(steps, (1024 + tiles - 1) // tiles, 256))
+    splits = max(1, min(steps, (512 + tiles - 1) // tiles, 256))
     partial = torch.empty(splits, M, N, dtype=torch.float32, device=A.device)
     check(lib.bg_gemm_tn_splitk_f32(M, N, R, ptr(A2), _ld(A2), ptr(B2), _ld(B2), ptr(out), N, ptr(partial), splits,
                                     stream()), "bg_gemm_tn_splitk_f32")
@@ -177,7 +177,7 @@ def colsum_raw(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x2 = _f32c(x)
     M, N = x2.shape
-    nb = max(1, min(256, (M + 63) // 64))
+    nb = max(1, min(256, (M + 127) // 128))
     partial = torch.empty(nb, N, dtype=torch.float32, device=x.device)
     out = torch.empty(N, dtype=torch.float32, device=x.device)
     check(lib.bg_colsum_f32(ptr(x2), _ld(x2), M, N, ptr(partial), nb, ptr(out), stream()), "bg_colsum_f32")
@@ -447,7 +447,8 @@ def seg_argmax(logit: torch.Tensor, plan) -> torch.Tensor:
     return arg
 
 
-def adam_step(param, grad, m, v, lr, beta1, beta2, eps, step):
+def adam_step(param, grad, m, v, lr, beta1, beta2, eps, step, step_dev=None):
+    """``step`` (host int) or ``step_dev`` (int32 device tensor holding the step count)."""
     lib = _lib.load()
-    check(lib.bg_adam_f32(ptr(param), ptr(grad), ptr(m), ptr(v), param.numel(), lr, beta1, beta2, eps, step,
-                          stream()), "bg_adam_f32")
+    check(lib.bg_adam_f32(ptr(param), ptr(grad), ptr(m), ptr(v), param.numel(), lr, beta1, beta2, eps,
+                          int(step) if step_dev is None else 0, ptr(step_dev), stream()), "bg_adam_f32")

@@ -7,6 +7,10 @@ The reference has no multi-GPU path (util_graph.py:149-158 is marked "Not used")
 are means over graphs, stories and voxels, so with ``world_size > 1`` each rank divides its local
 sums by the GLOBAL counts (all-reduced once per batch) and gradients are summed: the result equals
 a single-device step over the union batch.
+
+For fixed-shape batches the iteration can be captured into hipGraphs (``Trainer.capture``): the
+compute between two collectives is one graph, the all-reduce stays an eager RCCL call between
+graph launches, so the same structure runs on 1..8 GPUs.
 """
 from __future__ import annotations
 
@@ -20,6 +24,10 @@ from .graph import detach_batch
 from .losses import VolumetricDesignLoss_G
 from .models import DiscriminatorVoxel, Generator
 from .util import softmax_to_hard
+
+
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
 class FlatAdam:
@@ -41,7 +49,8 @@ class FlatAdam:
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.lr, self.betas, self.eps = lr, betas, eps
-        self.t = 0
+        self.t = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
+        self.t_host = 0
 
     def zero_grad(self):
         self.grad.zero_()
@@ -53,12 +62,21 @@ class FlatAdam:
             off += k
 
     def all_reduce(self, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if _world(group) > 1:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
 
     def step(self):
-        self.t += 1
-        ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
+        self.t_host += 1
+        self.t += 1                                # device-side count: valid under hipGraph replay
+        ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
+                      0, self.t)
+
+    def state(self):
+        return [self.flat.clone(), self.m.clone(), self.v.clone(), self.t.clone(), self.t_host]
+
+    def restore(self, st):
+        self.flat.copy_(st[0]); self.m.copy_(st[1]); self.v.copy_(st[2]); self.t.copy_(st[3])
+        self.t_host = st[4]
 
 
 def global_counts(batch, group=None):
@@ -67,7 +85,7 @@ def global_counts(batch, group=None):
     Nv = int(batch.voxel_feature.shape[0])
     plan = batch.__dict__.get("_bg_plan")
     S = plan.S if plan is not None else int(batch.voxel_floor_cluster.max().item()) + 1
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _world(group) > 1:
         t = torch.tensor([B, S, Nv], dtype=torch.float64, device=batch.voxel_feature.device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         B, S, Nv = (int(x) for x in t.tolist())
@@ -89,16 +107,14 @@ class Trainer:
         self.gp_lambda, self.n_critic_d, self.n_critic_g = gp_lambda, n_critic_d, n_critic_g
         self.g_loss_fn = VolumetricDesignLoss_G(gan_loss=gan_loss)
         self.group = group
+        self._graphs = None
 
     def broadcast_parameters(self, src: int = 0):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if _world(self.group) > 1:
             dist.broadcast(self.opt_g.flat, src, group=self.group)
             dist.broadcast(self.opt_d.flat, src, group=self.group)
 
-    @staticmethod
-    def _mean(x, n_global):
-        return x.sum() / n_global
-
+    # ------------------------------------------------------------------ pieces of one iteration
     def _gradient_penalty(self, batch, label, out, u, Nv_g):
         """reference losses.py:73-89 with the voxel mean taken over the global voxel count."""
         if u is None:
@@ -113,11 +129,11 @@ class Trainer:
         gp_s = ((grad_s.norm(2, 1) - 1) ** 2).sum() / Nv_g
         return gp_b + gp_s
 
-    def train_iteration(self, batch, i: int, program_z=None, voxel_z=None, noise: Optional[Sequence] = None,
-                        u: Optional[torch.Tensor] = None):
-        """Iteration ``i`` of an epoch (reference train.py:74-114).  Returns a dict of detached losses."""
+    def _phase_d(self, batch, counts, do_d, program_z=None, voxel_z=None, noise=None, u=None):
+        """train.py:80-99: generator forward, discriminator losses, d_loss.backward()."""
         G, D = self.generator, self.discriminator
         dev = self.device
+        Bg, Sg, Nvg = counts
         stats = {}
         for p in self.opt_d.params:
             p.requires_grad = True
@@ -126,32 +142,115 @@ class Trainer:
             program_z = torch.rand(batch.program_class_feature.shape[0], self.noise_dim, device=dev)
         if voxel_z is None:
             voxel_z = torch.rand(batch.voxel_feature.shape[0], self.noise_dim, device=dev)
-        out, soft_out, mask, att, max_out_program_index = G(batch, program_z, voxel_z, noise)
-        Bg, Sg, Nvg = global_counts(batch, self.group)
-
-        if i % self.n_critic_d == 0:
+        gen = G(batch, program_z, voxel_z, noise)
+        out, soft_out = gen[0], gen[1]
+        if do_d:
             fake_b, fake_s = D(detach_batch(batch), out.detach())
             real_b, real_s = D(batch, batch.voxel_label)
-            d_loss = (-self._mean(real_b, Bg) - self._mean(real_s, Sg) + self._mean(fake_b, Bg) + self._mean(fake_s, Sg))
+            d_loss = -real_b.sum() / Bg - real_s.sum() / Sg + fake_b.sum() / Bg + fake_s.sum() / Sg
             if self.gp_lambda != 0:
                 gp = self._gradient_penalty(detach_batch(batch), batch.voxel_label.detach(), soft_out.detach(), u, Nvg)
                 d_loss = d_loss + self.gp_lambda * gp
                 stats["gp"] = gp.detach()
             d_loss.backward()
-            self.opt_d.all_reduce(self.group)
-            self.opt_d.step()
             stats["d_loss"] = d_loss.detach()
+        return gen, stats
 
+    def _phase_g(self, batch, counts, gen):
+        """train.py:106-113: D frozen, generator loss through D, g_loss.backward()."""
+        Bg, Sg, _ = counts
+        out, soft_out, mask, att, _ = gen
         for p in self.opt_d.params:
             p.requires_grad = False
         self.opt_g.zero_grad()
+        val_b, val_s = self.discriminator(batch, out)
+        # get_program_ratio runs in every G step although its losses have zero weight (losses.py:65)
+        self.g_loss_fn((val_b, val_s), batch, att["hard"], mask["hard"], 6)
+        g_loss = -val_b.sum() / Bg - val_s.sum() / Sg
+        g_loss.backward()
+        return {"g_loss": g_loss.detach()}
+
+    # ------------------------------------------------------------------ eager iteration
+    def train_iteration(self, batch, i: int, program_z=None, voxel_z=None, noise: Optional[Sequence] = None,
+                        u: Optional[torch.Tensor] = None):
+        """Iteration ``i`` of an epoch (reference train.py:74-114).  Returns a dict of detached losses."""
+        counts = global_counts(batch, self.group)
+        do_d = i % self.n_critic_d == 0
+        gen, stats = self._phase_d(batch, counts, do_d, program_z, voxel_z, noise, u)
+        if do_d:
+            self.opt_d.all_reduce(self.group)
+            self.opt_d.step()
         if i % self.n_critic_g == 0:
-            val_b, val_s = D(batch, out)
-            # adversarial term with global means; auxiliary terms have zero weight by default (train_args.py:40-42)
-            self.g_loss_fn(( val_b, val_s), batch, att["hard"], mask["hard"], 6)   # runs get_program_ratio as the reference does
-            g_loss = -self._mean(val_b, Bg) - self._mean(val_s, Sg)
-            g_loss.backward()
+            stats.update(self._phase_g(batch, counts, gen))
             self.opt_g.all_reduce(self.group)
             self.opt_g.step()
-            stats["g_loss"] = g_loss.detach()
+        else:
+            for p in self.opt_d.params:
+                p.requires_grad = False
+        return stats
+
+    # ------------------------------------------------------------------ hipGraph iteration
+    def capture(self, batch, warmup: int = 2):
+        """Capture the iteration for THIS batch (fixed shapes) into hipGraphs.
+
+        Segments: A = phase D (G forward ... d_loss.backward); B = Adam(D) + phase G; C = Adam(G);
+        A2/B2 = the same without a generator update.  Collectives run eagerly between segments.
+        Parameters and optimizer state are restored afterwards, so capturing does not train.
+        """
+        if self.n_critic_d != 1:
+            raise NotImplementedError("graph capture assumes n_critic_d == 1 (the reference default)")
+        saved = (self.opt_g.state(), self.opt_d.state())
+        counts = global_counts(batch, self.group)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(warmup):
+                self.train_iteration(batch, i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs = {}
+        pool = None
+
+        def cap(fn):
+            nonlocal pool
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                res = fn()
+            pool = g.pool()
+            return g, res
+
+        # iteration WITH generator update
+        gA, (gen, statsA) = cap(lambda: self._phase_d(batch, counts, True))
+
+        def seg_b():
+            self.opt_d.step()
+            return self._phase_g(batch, counts, gen)
+        gB, statsB = cap(seg_b)
+        gC, _ = cap(lambda: self.opt_g.step())
+        graphs["with_g"] = (gA, gB, gC, {**statsA, **statsB})
+        # iteration WITHOUT generator update
+        gA2, (gen2, statsA2) = cap(lambda: self._phase_d(batch, counts, True))
+        gB2, _ = cap(lambda: self.opt_d.step())
+        graphs["no_g"] = (gA2, gB2, statsA2)
+        self._graphs = graphs
+        self._keep = (gen, gen2)
+        self.opt_g.restore(saved[0])
+        self.opt_d.restore(saved[1])
+        torch.cuda.synchronize()
+
+    def train_iteration_graphed(self, i: int):
+        if self._graphs is None:
+            raise RuntimeError("call capture(batch) first")
+        if i % self.n_critic_g == 0:
+            gA, gB, gC, stats = self._graphs["with_g"]
+            gA.replay()
+            self.opt_d.all_reduce(self.group)
+            gB.replay()
+            self.opt_g.all_reduce(self.group)
+            gC.replay()
+        else:
+            gA, gB, stats = self._graphs["no_g"]
+            gA.replay()
+            self.opt_d.all_reduce(self.group)
+            gB.replay()
         return stats

@@ -185,9 +185,12 @@ int bg_colsum_f32(const float* x, int64_t ldx, int64_t M, int64_t N, float* part
 
 /* One Adam step on a flat fp32 buffer (torch.optim.Adam semantics, no weight decay/amsgrad):
  * m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * t = step, or *step_dev (a device int32) when step_dev is not NULL, so that a captured hipGraph
+ * replays with the current step count.
  * replaces: optimizer_G.step() / optimizer_D.step(), train.py:101,114.                       */
 int bg_adam_f32(float* param, const float* grad, float* m, float* v, int64_t n,
-                float lr, float beta1, float beta2, float eps, int32_t step, bgStream stream);
+                float lr, float beta1, float beta2, float eps, int32_t step, const int32_t* step_dev,
+                bgStream stream);
 
 #ifdef __cplusplus
 }

@@ -131,3 +131,52 @@ def test_program_ratio_parity(cuda):
     rh = h(gpu, att.to(cuda), mask.to(cuda), 6)
     for a, b in zip(rh, ro):
         torch.testing.assert_close(a.cpu(), b, rtol=1e-4, atol=1e-6)
+
+
+def test_trainer_matches_oracle_iterations(cuda):
+    """Two full iterations (i=0 with the generator update, i=1 without) against the CPU oracle."""
+    from building_gan_amd.graph import detach_batch
+    from building_gan_amd.train import Trainer
+    from oracle.objectives import train_iteration
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 21, True, cuda)
+    tr = Trainer(cuda)
+    tr.generator.load_state_dict(Go.state_dict())
+    tr.discriminator.load_state_dict(Do.state_dict())
+    og = torch.optim.Adam(Go.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    od = torch.optim.Adam(Do.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    torch.manual_seed(21)
+    for i in (0, 1):
+        u = torch.rand(sz["Nv"], 1)
+        so = train_iteration(Go, Do, og, od, cpu, detach_batch, i, pz, vz, noise, u)
+        sh = tr.train_iteration(gpu, i, pz.to(cuda), vz.to(cuda), _to(noise, cuda), u.to(cuda))
+        # iteration 1 runs on weights that already took one (sign-like) Adam step on each side
+        tol = 2e-3 if i == 0 else 2e-2
+        torch.testing.assert_close(sh["d_loss"].cpu(), so["d_loss"], rtol=tol, atol=1e-3)
+        torch.testing.assert_close(sh["gp"].cpu(), so["gp"], rtol=tol, atol=1e-4)
+        if i == 0:
+            torch.testing.assert_close(sh["g_loss"].cpu().view(-1), so["g_loss"].view(-1), rtol=2e-3, atol=1e-3)
+    # Adam's first steps move every weight by ~lr regardless of gradient scale: compare updates loosely
+    for (n, po), (_, ph) in zip(list(Do.named_parameters()) + list(Go.named_parameters()),
+                                list(tr.discriminator.named_parameters()) + list(tr.generator.named_parameters())):
+        assert float((ph.detach().cpu() - po.detach()).abs().max()) <= 2.5e-4, n
+
+
+def test_graph_capture_replays_and_restores_state(cuda):
+    from building_gan_amd.synthetic import make_batch
+    from building_gan_amd.train import Trainer
+    batch = make_batch("small", seed=3, ragged=True).to(cuda)
+    torch.manual_seed(0)
+    tr = Trainer(cuda)
+    before_g, before_d = tr.opt_g.flat.clone(), tr.opt_d.flat.clone()
+    tr.capture(batch)
+    assert torch.equal(tr.opt_g.flat, before_g) and torch.equal(tr.opt_d.flat, before_d)
+    assert int(tr.opt_d.t.item()) == 0
+    for i in range(6):
+        stats = tr.train_iteration_graphed(i)
+    torch.cuda.synchronize()
+    assert int(tr.opt_d.t.item()) == 6 and int(tr.opt_g.t.item()) == 2
+    assert torch.isfinite(stats["d_loss"]).all() and torch.isfinite(tr.opt_d.flat).all()
+    assert not torch.equal(tr.opt_g.flat, before_g) and not torch.equal(tr.opt_d.flat, before_d)
+    # an eager iteration on the same trainer still works after replays
+    s2 = tr.train_iteration(batch, 7)
+    assert torch.isfinite(s2["d_loss"]).all()
