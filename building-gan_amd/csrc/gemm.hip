@@ -26,6 +26,7 @@ struct GemmArgs {
     float* C; int64_t ldc;
     const float* bias; const float* row_scale; int act; float slope;
     const float* residual; int64_t ldr;
+    const float* pre_add; int64_t ldp;
     int64_t M, N;
     int total_steps;      // sum over segments of ceil(K_s / 32)
     int steps_per_split;  // == total_steps when not split
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
                 } else {
                     v += bv;
                     if (g.row_scale) v *= g.row_scale[row];
+                    if (g.pre_add) v += g.pre_add[row * g.ldp + col];
                     if (g.act == BG_ACT_LEAKY) v = v > 0.f ? v : v * g.slope;
                     if (g.residual) v += g.residual[row * g.ldr + col];
                     g.C[row * g.ldc + col] = v;
@@ -328,12 +330,13 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
                 const float* const* A, const int64_t* lda, const int64_t* Ks,
                 const float* B, int64_t ldb, float* C, int64_t ldc,
                 const float* bias, const float* row_scale, int act, float slope,
-                const float* residual, int64_t ldr, bgStream stream) {
+                const float* residual, int64_t ldr, const float* pre_add, int64_t ldp, bgStream stream) {
     if (M < 0 || N < 0 || n_seg < 1 || n_seg > 4 || !A || !lda || !Ks) return BG_ERR_ARG;
     if (M == 0 || N == 0) return BG_OK;
-    if (!B || !C || ldc < N || (residual && ldr < N)) return BG_ERR_ARG;
+    if (!B || !C || ldc < N || (residual && ldr < N) || (pre_add && ldp < N)) return BG_ERR_ARG;
     GemmArgs g{};
     g.n_seg = n_seg;
+    g.pre_add = pre_add; g.ldp = ldp;
     int64_t Ktot = 0;
     bool vec = true;
     int steps = 0;
@@ -358,7 +361,7 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
     int tile = tile_override();
     if (tile == 0) {
         const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
-        tile = big_tiles >= 256 ? 3 : 0;
+        tile = big_tiles >= 512 ? 3 : 0;
     } else {
         tile -= 1;
     }

@@ -25,6 +25,7 @@ from .ops import ACT_LEAKY, ACT_NONE, SpMM, SpMMW, linear
 from .plan import LinOp, build_plan
 
 NUMBER_OF_CLASS = 6  # /root/reference/Data/GraphConstructor.py:9
+COMPOSE_BLOCKS = True  # collapse messageMLP into updateMLP where legal (VoxelBlock.compose)
 
 
 def position_encoder(d_model: int, max_len: int = 20) -> torch.Tensor:
@@ -186,6 +187,36 @@ class VoxelBlock(nn.Module):
         self.updateMLP = (MLP([4 * hidden_dim, hidden_dim], act="leaky") if if_agg_story_in_update
                           else MLP([2 * hidden_dim, hidden_dim]))
 
+    def compose(self):
+        """messageMLP has no activation, so on graphs where every voxel has an in-edge the block's
+        two Linears collapse into one:  Wu[v; Wm[v; Av; p] + bm; ...] = Wc[v; Av; p] + bc (+ story terms)
+        with Wc = [Wu1 + Wu2 Wm1 | Wu2 Wm2 | Wu2 Wm3], bc = Wu2 bm + bu.  Halves (D) / thirds (G) the
+        flops of every pass; the small weight products are differentiable GEMMs, so gradients reach
+        messageMLP / updateMLP through the chain rule.  Returns (Wc [H,2H+4], bc, Ws, Wb)."""
+        Wm, bm = self.messageMLP[0].weight, self.messageMLP[0].bias
+        Wu, bu = self.updateMLP[0].weight, self.updateMLP[0].bias
+        H = Wm.shape[0]
+        Wm_ext = torch.cat([F.pad(Wm, (0, 1)), bm.view(-1, 1)], dim=1)          # [H, 2H+5]
+        P = ops.MatMul.apply(Wu[:, H:2 * H], Wm_ext, False, False)              # Wu2 @ [Wm | 0 | bm]
+        Wc = P[:, :2 * H + 4] + F.pad(Wu[:, :H], (0, H + 4))
+        bc = P[:, 2 * H + 4] + bu
+        if self.if_agg_story_in_update:
+            return Wc, bc, Wu[:, 2 * H:3 * H] - Wu[:, 3 * H:], Wu[:, 3 * H:]
+        return Wc, bc, None, None
+
+    def forward_composed(self, voxel_feature, plan, pdm4, composed):
+        """v + block(v) with the collapsed weights (valid when plan.vox_all_has)."""
+        Wc, bc, Ws, Wb = composed
+        gm = SpMM.apply(voxel_feature, plan.vox_mean)
+        if not self.if_agg_story_in_update:
+            return linear([voxel_feature, gm, pdm4], Wc, bc, residual=voxel_feature)
+        story = SpMM.apply(voxel_feature, plan.story_mean)                      # [S, H]
+        building = SpMM.apply(story, plan.graph_of_story_mean)                  # [B, H]
+        # (Wu3 - Wu4) story + Wu4 building, evaluated per story and gathered to the voxels
+        term = linear(story, Ws) + SpMM.apply(linear(building, Wb), plan.story_graph_gather)
+        pre = SpMM.apply(term, plan.story_gather)
+        return voxel_feature + linear([voxel_feature, gm, pdm4], Wc, bc, ACT_LEAKY, 0.01, pre_add=pre)
+
     def forward(self, voxel_feature, plan, pdm4):
         H = voxel_feature.shape[1]
         gm = SpMM.apply(voxel_feature, plan.vox_mean)
@@ -217,8 +248,12 @@ class VoxelGNN_G(nn.Module):
         v = v + ops.spmm_raw(_level_op(plan, self.pe.shape[0]), self.pe)
         _, _, v = self.attention(x, v, plan, None if draws is None else next(draws))
         out_mask = out_att = None
+        composed = self.block.compose() if (COMPOSE_BLOCKS and plan.vox_all_has) else None
         for i in range(self.layer_num):
-            v = v + self.block(v, plan, pdm4)
+            if composed is not None:
+                v = self.block.forward_composed(v, plan, pdm4, composed)
+            else:
+                v = v + self.block(v, plan, pdm4)
             if i % 2 == 0 and i != 0:
                 out_mask, out_att, v = self.attention(x, v, plan, None if draws is None else next(draws))
         return out_mask, out_att, v
@@ -239,8 +274,12 @@ class VoxelGNN_D(nn.Module):
         v = run_mlp(self.feature_enc, v)
         v = v + ops.spmm_raw(_level_op(plan, self.pe.shape[0]), self.pe)
         v = torch.cat([v, run_mlp(self.label_enc, l)], dim=-1)
+        composed = self.block.compose() if (COMPOSE_BLOCKS and plan.vox_all_has) else None
         for _ in range(self.layer_num):
-            v = v + self.block(v, plan, pdm4)
+            if composed is not None:
+                v = self.block.forward_composed(v, plan, pdm4, composed)
+            else:
+                v = v + self.block(v, plan, pdm4)
         return v
 
 

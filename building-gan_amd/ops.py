@@ -118,7 +118,8 @@ _I64Arr4 = C.c_int64 * 4
 
 def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: bool,
              bias: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
-             act: int = ACT_NONE, slope: float = 0.01, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+             act: int = ACT_NONE, slope: float = 0.01, residual: Optional[torch.Tensor] = None,
+             pre_add: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C = epilogue(cat(A, -1 (or 0 when transA)) (x) B); see bg_gemm_f32."""
     lib = _lib.load()
     if len(A) < 1 or len(A) > 4:
@@ -147,9 +148,12 @@ def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: b
         row_scale = _f32c(row_scale.reshape(-1))
     if residual is not None:
         residual = _f32c(residual)
+    if pre_add is not None:
+        pre_add = _f32c(pre_add)
     check(lib.bg_gemm_f32(int(transA), int(transB), M, N, len(As), pa, la, ka, ptr(B2), _ld(B2), ptr(out), N,
                           ptr(bias), ptr(row_scale), act, slope, ptr(residual),
-                          _ld(residual) if residual is not None else 0, stream()), "bg_gemm_f32")
+                          _ld(residual) if residual is not None else 0, ptr(pre_add),
+                          _ld(pre_add) if pre_add is not None else 0, stream()), "bg_gemm_f32")
     return out
 
 
@@ -273,23 +277,21 @@ class ColSum(torch.autograd.Function):
 
 
 class LinearCat(torch.autograd.Function):
-    """y = act(row_scale * (cat(xs, -1) @ W^T + b)) (+ residual): the fused nn.Linear of the hot path.
-
-    Inputs: W, b, n (number of x segments), act, slope, row_scale(or None), residual(or None), *xs.
-    """
+    """y = act(row_scale * (cat(xs, -1) @ W^T + b) + pre_add) + residual: the fused nn.Linear of the
+    hot path (every epilogue term optional; pre_add and residual are differentiable inputs)."""
 
     @staticmethod
-    def forward(ctx, W, b, act, slope, row_scale, residual, *xs):
-        y = gemm_raw(list(xs), W, False, True, bias=b, row_scale=row_scale, act=act, slope=slope, residual=residual)
+    def forward(ctx, W, b, act, slope, row_scale, residual, pre_add, *xs):
+        fuse_res = residual if act != ACT_LEAKY else None
+        y = gemm_raw(list(xs), W, False, True, bias=b, row_scale=row_scale, act=act, slope=slope,
+                     residual=fuse_res, pre_add=pre_add)
         ctx.act, ctx.slope = act, slope
-        ctx.has_res = residual is not None
+        ctx.has_res, ctx.has_pre = residual is not None, pre_add is not None
         ctx.widths = [x.shape[1] for x in xs]
-        if act == ACT_LEAKY:
-            # sign of the pre-activation == sign of (y - residual)
-            pre = y if residual is None else y - residual
-            ctx.save_for_backward(W, row_scale, pre > 0, *xs)
-        else:
-            ctx.save_for_backward(W, row_scale, None, *xs)
+        pos = (y > 0) if act == ACT_LEAKY else None      # sign of the pre-activation
+        if act == ACT_LEAKY and residual is not None:
+            y = y + residual
+        ctx.save_for_backward(W, row_scale, pos, *xs)
         return y
 
     @staticmethod
@@ -298,6 +300,7 @@ class LinearCat(torch.autograd.Function):
         g_res = g if ctx.has_res and ctx.needs_input_grad[5] else None
         if ctx.act == ACT_LEAKY:
             g = torch.where(pos, g, g * ctx.slope)
+        g_pre = g if ctx.has_pre and ctx.needs_input_grad[6] else None
         if row_scale is not None:
             g = g * row_scale.view(-1, 1)
         gW = gb = None
@@ -307,20 +310,20 @@ class LinearCat(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gb = ColSum.apply(g)
         gxs: List[Optional[torch.Tensor]] = [None] * len(xs)
-        if any(ctx.needs_input_grad[6:]):
+        if any(ctx.needs_input_grad[7:]):
             gx = MatMul.apply(g, W, False, False)
             off = 0
             for i, wdt in enumerate(ctx.widths):
-                if ctx.needs_input_grad[6 + i]:
+                if ctx.needs_input_grad[7 + i]:
                     gxs[i] = gx[:, off:off + wdt]
                 off += wdt
-        return (gW, gb, None, None, None, g_res, *gxs)
+        return (gW, gb, None, None, None, g_res, g_pre, *gxs)
 
 
-def linear(xs, W, b=None, act=ACT_NONE, slope=0.01, row_scale=None, residual=None):
+def linear(xs, W, b=None, act=ACT_NONE, slope=0.01, row_scale=None, residual=None, pre_add=None):
     if torch.is_tensor(xs):
         xs = [xs]
-    return LinearCat.apply(W, b, act, slope, row_scale, residual, *xs)
+    return LinearCat.apply(W, b, act, slope, row_scale, residual, pre_add, *xs)
 
 
 class SegMax(torch.autograd.Function):

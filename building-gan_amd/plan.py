@@ -208,7 +208,9 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     story_graph.scatter_(0, vfc, vbi)
     ar_st = torch.arange(S, dtype=torch.int64, device=dev)
     sgr = b.csr("story_by_graph", story_graph, ar_st, B, S, counts=True)
-    o["graph_of_story_mean"] = LinOp.pair(sgr, b.gather_csr(story_graph.to(torch.int32), B), sgr.count, SCALE_DIV)
+    sgr_gather = b.gather_csr(story_graph.to(torch.int32), B)
+    o["graph_of_story_mean"] = LinOp.pair(sgr, sgr_gather, sgr.count, SCALE_DIV)
+    o["story_graph_gather"] = LinOp.pair(sgr_gather, sgr)
 
     # floor level of every voxel inside its own building
     first = _i32(max(B, 1), dev)
@@ -230,8 +232,12 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     o["edge_voxel_gather"] = LinOp.pair(b.gather_csr(cev.to(torch.int32), Nv), edge_by_voxel)
     o["edge_program_gather"] = LinOp.pair(b.gather_csr(cep.to(torch.int32), Np), edge_by_program)
 
-    flags, (max_level,) = b.finish(lvl_max)
+    def _min_len(c):
+        return (c.rowptr[1:] - c.rowptr[:-1]).min() if c.n_rows > 0 else torch.ones((), dtype=torch.int32, device=dev)
+    extra = torch.stack([lvl_max.to(torch.int32), _min_len(vfw), _min_len(pf), _min_len(cv)])
+    flags, (max_level, min_vdeg, min_pdeg, min_cross) = b.finish(extra)
     o["max_level"] = int(max_level)
+    o["vox_all_has"], o["prog_all_has"] = min_vdeg > 0, min_pdeg > 0
     for name, (bad, moved) in flags.items():
         if bad:
             raise _lib.BganError(f"plan '{name}': {bad} index values out of range")
@@ -239,7 +245,7 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     if flags["cross_by_voxel"][1] != 0:
         raise _lib.BganError("cross_edge_voxel_index_select must be non-decreasing (reference "
                              "GraphConstructor.py:81-88 builds it voxel-major)")
-    if cv.nnz and int(flags["cross_by_voxel"][0]) == 0 and bool((cv.rowptr[1:] == cv.rowptr[:-1]).any().item()):
+    if Nv > 0 and min_cross <= 0:
         raise _lib.BganError("every voxel needs at least one cross edge (reference util.py:24-25 indexes the "
                              "arg-max of each voxel segment)")
     has = (vfw.rowptr[1:] > vfw.rowptr[:-1]).to(torch.float32).view(-1, 1)

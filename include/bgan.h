@@ -158,7 +158,7 @@ int bg_seg_argmax_f32(const float* logit, const int32_t* rowptr, int32_t* arg, i
 /* C[M,N] = epilogue( sum_s opA(A_s) * opB(B)[koff_s : koff_s+K_s, :] ),  koff_s = K_0+..+K_{s-1}
  *   transA == 0: A_s is [M, K_s] (pitch lda[s]);  transA == 1: A_s is [K_s, M]
  *   transB == 0: B is [K, N] (pitch ldb);         transB == 1: B is [N, K]  (nn.Linear weight)
- *   epilogue(v)[m,n] = act(row_scale[m] * (v + bias[n])) + residual[m,n]; each part optional.
+ *   epilogue(v)[m,n] = act(row_scale[m] * (v + bias[n]) + pre_add[m,n]) + residual[m,n]; each part optional.
  * n_seg in 1..4 fuses torch.cat((A_0,..), -1) into the product.  Exact fp32 (v_mfma_f32_32x32x2_f32).
  * Vector path needs 16-byte aligned bases and pitches / K_s % 4 == 0; anything else runs a
  * scalar-load path of the same kernel.
@@ -167,7 +167,7 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
                 const float* const* A, const int64_t* lda, const int64_t* Ks,
                 const float* B, int64_t ldb, float* C, int64_t ldc,
                 const float* bias, const float* row_scale, int act, float slope,
-                const float* residual, int64_t ldr, bgStream stream);
+                const float* residual, int64_t ldr, const float* pre_add, int64_t ldp, bgStream stream);
 
 /* C[M,N] = A^T[M,R] * B[R,N] with the long reduction R split over `splits` workgroups per tile:
  * A is [R, M] (pitch lda), B is [R, N] (pitch ldb); partial: [splits, M, N] workspace.

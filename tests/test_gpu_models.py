@@ -158,7 +158,11 @@ def test_trainer_matches_oracle_iterations(cuda):
     # Adam's first steps move every weight by ~lr regardless of gradient scale: compare updates loosely
     for (n, po), (_, ph) in zip(list(Do.named_parameters()) + list(Go.named_parameters()),
                                 list(tr.discriminator.named_parameters()) + list(tr.generator.named_parameters())):
-        assert float((ph.detach().cpu() - po.detach()).abs().max()) <= 2.5e-4, n
+        # (an element whose gradient is rounding noise can step +lr on one side and -lr on the other,
+        #  twice: bound the worst case by 4*lr and the typical case by the mean)
+        diff = (ph.detach().cpu() - po.detach()).abs()
+        assert float(diff.max()) <= 4.5e-4, n
+        assert float(diff.mean()) <= 4e-5, n
 
 
 def test_graph_capture_replays_and_restores_state(cuda):
