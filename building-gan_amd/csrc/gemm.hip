@@ -31,6 +31,8 @@ struct GemmArgs {
     int total_steps;      // sum over segments of ceil(K_s / 32)
     int steps_per_split;  // == total_steps when not split
     float* partial;       // split-K: [splits, M, N]
+    // split-K (TN) only: B may be given as column segments  B = [B_0 | B_1 | ..]  (fused cat of the inputs)
+    const float* Bseg[4]; int64_t ldbseg[4]; int64_t Nseg[4]; int n_bseg;
 };
 
 template <int ROWS, bool KC, bool VEC>
@@ -114,7 +116,19 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    const int64_t m0 = (int64_t)blockIdx.y * BM;
+    int64_t n0 = (int64_t)blockIdx.x * BN;
+    // TN mode: locate the B segment this column tile belongs to (tiles never straddle segments)
+    const float* Bp = g.B; int64_t ldb = g.ldb, n_lim = g.N, col_base = 0;
+    if (SPLIT) {
+        int t = blockIdx.x, s = 0;
+        while (s < g.n_bseg - 1) {
+            int nt = (int)((g.Nseg[s] + BN - 1) / BN);
+            if (t < nt) break;
+            t -= nt; col_base += g.Nseg[s]; ++s;
+        }
+        Bp = g.Bseg[s]; ldb = g.ldbseg[s]; n_lim = g.Nseg[s]; n0 = (int64_t)t * BN;
+    }
 
     int step_begin = 0, step_end = g.total_steps;
     if (SPLIT) {
@@ -149,8 +163,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         locate(step, seg, k0, koff);
         sa.load(g.A[seg], g.lda[seg], m0, g.M, k0, g.Ks[seg]);
         // B rows of this step: concatenated k in [koff + k0, koff + K_seg)
-        const float* bb = B_KC ? g.B + koff : g.B + koff * g.ldb;
-        sb.load(bb, g.ldb, n0, g.N, k0, g.Ks[seg]);
+        const float* bb = B_KC ? Bp + koff : Bp + koff * ldb;
+        sb.load(bb, ldb, n0, n_lim, k0, g.Ks[seg]);
     };
 
     if (step_begin < step_end) {
@@ -196,8 +210,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int64_t col = n0 + (wn * TN + j) * 32 + r;
-            if (col >= g.N) continue;
+            int64_t col = n0 + (wn * TN + j) * 32 + r;
+            if (col >= n_lim) continue;
+            col += col_base;
             const float bv = (!SPLIT && g.bias) ? g.bias[col] : 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -285,8 +300,8 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
 }
 
 template <int BM, int BN, bool SPLIT>
-int launch_gemm(int transA, int transB, bool vec, const GemmArgs& g, int splits, hipStream_t s) {
-    dim3 grid((unsigned)((g.N + BN - 1) / BN), (unsigned)((g.M + BM - 1) / BM), (unsigned)splits);
+int launch_gemm(int transA, int transB, bool vec, const GemmArgs& g, int splits, hipStream_t s, int64_t n_tiles = 0) {
+    dim3 grid((unsigned)(n_tiles > 0 ? n_tiles : (g.N + BN - 1) / BN), (unsigned)((g.M + BM - 1) / BM), (unsigned)splits);
     const bool akc = !transA, bkc = transB != 0;
 #define BG_GEMM_CASE(AKC, BKC, VEC)                                                     \
     if (akc == AKC && bkc == BKC && vec == VEC) {                                       \
@@ -373,22 +388,34 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
     }
 }
 
-int bg_gemm_tn_splitk_f32(int64_t M, int64_t N, int64_t R, const float* A, int64_t lda,
-                          const float* B, int64_t ldb, float* C, int64_t ldc,
-                          float* partial, int32_t splits, bgStream stream) {
-    if (M < 0 || N < 0 || R < 0 || splits < 1) return BG_ERR_ARG;
+int bg_gemm_tn_splitk_f32(int64_t M, int64_t R, const float* A, int64_t lda,
+                          int n_seg, const float* const* B, const int64_t* ldb, const int64_t* Ns,
+                          float* C, int64_t ldc, float* partial, int32_t splits, bgStream stream) {
+    if (M < 0 || R < 0 || splits < 1 || n_seg < 1 || n_seg > 4 || !B || !ldb || !Ns) return BG_ERR_ARG;
+    int64_t N = 0;
+    for (int s = 0; s < n_seg; ++s) {
+        if (Ns[s] < 0 || (Ns[s] > 0 && (!B[s] || ldb[s] < Ns[s]))) return BG_ERR_ARG;
+        N += Ns[s];
+    }
     if (M == 0 || N == 0) return BG_OK;
-    if (!A || !B || !C || !partial || lda < M || ldb < N || ldc < N) return BG_ERR_ARG;
+    if (!A || !C || !partial || lda < M || ldc < N) return BG_ERR_ARG;
     GemmArgs g{};
     g.n_seg = 1; g.A[0] = A; g.lda[0] = lda; g.Ks[0] = R;
-    g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N;
+    g.B = B[0]; g.ldb = ldb[0]; g.C = C; g.ldc = ldc; g.M = M; g.N = N;
+    g.n_bseg = n_seg;
+    int64_t n_tiles = 0;
+    bool vec = operand_vec_ok(A, lda, false, R, M);
+    for (int s = 0; s < n_seg; ++s) {
+        g.Bseg[s] = B[s]; g.ldbseg[s] = ldb[s]; g.Nseg[s] = Ns[s];
+        n_tiles += (Ns[s] + 63) / 64;
+        if (Ns[s] > 0) vec = vec && operand_vec_ok(B[s], ldb[s], false, R, Ns[s]);
+    }
     g.total_steps = (int)((R + BK - 1) / BK);
     g.steps_per_split = (g.total_steps + splits - 1) / splits;
     if (g.steps_per_split < 1) g.steps_per_split = 1;
     g.partial = partial;
-    bool vec = operand_vec_ok(A, lda, false, R, M) && operand_vec_ok(B, ldb, false, R, N);
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_gemm<64, 64, true>(1, 0, vec, g, splits, st);
+    int rc = launch_gemm<64, 64, true>(1, 0, vec, g, splits, st, n_tiles);
     if (rc != BG_OK) return rc;
     if ((M * N) % 4 == 0 && bg_aligned16(partial))
         k_splitk_reduce<<<bg_grid_for((M * N) / 4, 256, 0x7fffffff), 256, 0, st>>>(partial, splits, M, N, C, ldc);

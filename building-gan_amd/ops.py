@@ -157,22 +157,27 @@ def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: b
     return out
 
 
-def gemm_tn_raw(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
-    """C[M,N] = A^T B for A [R,M], B [R,N] with a long R: split-K, deterministic order."""
+def gemm_tn_raw(A: torch.Tensor, B) -> torch.Tensor:
+    """C[M,N] = A^T [B_0|B_1|..] for A [R,M], B_s [R,N_s] with a long R: split-K, deterministic order."""
     lib = _lib.load()
-    A2, B2 = _f32c(A), _f32c(B)
+    A2 = _f32c(A)
+    Bs = [_f32c(b) for b in ([B] if torch.is_tensor(B) else list(B))]
     R, M = A2.shape
-    N = B2.shape[1]
-    if B2.shape[0] != R:
-        raise _lib.BganError("gemm_tn: reduction sizes differ")
+    if len(Bs) < 1 or len(Bs) > 4 or any(b.shape[0] != R for b in Bs):
+        raise _lib.BganError("gemm_tn: 1..4 B segments with the same reduction length as A")
+    Ns = [b.shape[1] for b in Bs]
+    N = sum(Ns)
     out = torch.empty(M, N, dtype=torch.float32, device=A.device)
     if M == 0 or N == 0:
         return out
-    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    tiles = ((M + 63) // 64) * sum((n + 63) // 64 for n in Ns)
     steps = (R + 31) // 32
     splits = max(1, min(steps, (512 + tiles - 1) // tiles, 256))
     partial = torch.empty(splits, M, N, dtype=torch.float32, device=A.device)
-    check(lib.bg_gemm_tn_splitk_f32(M, N, R, ptr(A2), _ld(A2), ptr(B2), _ld(B2), ptr(out), N, ptr(partial), splits,
+    pb = _PtrArr4(*([b.data_ptr() for b in Bs] + [None] * (4 - len(Bs))))
+    lb = _I64Arr4(*([_ld(b) for b in Bs] + [0] * (4 - len(Bs))))
+    nb = _I64Arr4(*(Ns + [0] * (4 - len(Bs))))
+    check(lib.bg_gemm_tn_splitk_f32(M, R, ptr(A2), _ld(A2), len(Bs), pb, lb, nb, ptr(out), N, ptr(partial), splits,
                                     stream()), "bg_gemm_tn_splitk_f32")
     return out
 
@@ -265,6 +270,30 @@ class MatMul(torch.autograd.Function):
         return gA, gB, None, None
 
 
+class CatTN(torch.autograd.Function):
+    """dW = g^T [x_0 | x_1 | ..]  (the weight gradient of LinearCat) in ONE split-K launch."""
+
+    @staticmethod
+    def forward(ctx, g, *xs):
+        ctx.widths = [x.shape[1] for x in xs]
+        ctx.save_for_backward(g, *xs)
+        return gemm_tn_raw(g, list(xs))
+
+    @staticmethod
+    def backward(ctx, G2):
+        g, *xs = ctx.saved_tensors
+        gg = LinearCat.apply(G2, None, ACT_NONE, 0.0, None, None, None, *xs) if ctx.needs_input_grad[0] else None
+        gxs: List[Optional[torch.Tensor]] = [None] * len(xs)
+        if any(ctx.needs_input_grad[1:]):
+            gx = MatMul.apply(g, G2, False, False)
+            off = 0
+            for i, wdt in enumerate(ctx.widths):
+                if ctx.needs_input_grad[1 + i]:
+                    gxs[i] = gx[:, off:off + wdt]
+                off += wdt
+        return (gg, *gxs)
+
+
 class ColSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -305,8 +334,7 @@ class LinearCat(torch.autograd.Function):
             g = g * row_scale.view(-1, 1)
         gW = gb = None
         if ctx.needs_input_grad[0]:
-            gW = torch.cat([MatMul.apply(g, x, True, False) for x in xs], dim=1) if len(xs) > 1 \
-                else MatMul.apply(g, xs[0], True, False)
+            gW = CatTN.apply(g, *xs)
         if ctx.needs_input_grad[1]:
             gb = ColSum.apply(g)
         gxs: List[Optional[torch.Tensor]] = [None] * len(xs)

@@ -169,13 +169,14 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
                 const float* bias, const float* row_scale, int act, float slope,
                 const float* residual, int64_t ldr, const float* pre_add, int64_t ldp, bgStream stream);
 
-/* C[M,N] = A^T[M,R] * B[R,N] with the long reduction R split over `splits` workgroups per tile:
- * A is [R, M] (pitch lda), B is [R, N] (pitch ldb); partial: [splits, M, N] workspace.
+/* C[M,N] = A^T[M,R] * [B_0 | B_1 | ..][R,N] with the long reduction R split over `splits`
+ * workgroups per tile: A is [R, M] (pitch lda), B_s is [R, Ns[s]] (pitch ldb[s]), N = sum Ns
+ * (n_seg in 1..4: the concatenation of the layer inputs is never built); partial: [splits, M, N].
  * Partials are added in split order (deterministic).  The weight-gradient GEMM.
  * replaces: the grad-weight product of nn.Linear's autograd for the layers listed above.     */
-int bg_gemm_tn_splitk_f32(int64_t M, int64_t N, int64_t R, const float* A, int64_t lda,
-                          const float* B, int64_t ldb, float* C, int64_t ldc,
-                          float* partial, int32_t splits, bgStream stream);
+int bg_gemm_tn_splitk_f32(int64_t M, int64_t R, const float* A, int64_t lda,
+                          int n_seg, const float* const* B, const int64_t* ldb, const int64_t* Ns,
+                          float* C, int64_t ldc, float* partial, int32_t splits, bgStream stream);
 
 /* out[n] = sum_m x[m,n]   (bias gradient); partial: [n_blocks, N] workspace                  */
 int bg_colsum_f32(const float* x, int64_t ldx, int64_t M, int64_t N, float* partial, int32_t n_blocks,
