@@ -95,13 +95,16 @@ def global_counts(batch, group=None):
 class Trainer:
     def __init__(self, device, hidden_dim=128, noise_dim=32, program_layer=4, voxel_layer=12,
                  g_lr=1e-4, d_lr=1e-4, b1=0.5, b2=0.999, gp_lambda=10.0, n_critic_d=1, n_critic_g=5,
-                 gan_loss="WGANGP", max_len=20, group=None):
+                 gan_loss="WGANGP", max_len=20, group=None, generator=None, discriminator=None):
         if gan_loss != "WGANGP":
             raise NotImplementedError("the data-parallel step implements the default WGANGP objective")
         self.device = device
         self.noise_dim = noise_dim
-        self.generator = Generator(7, 7, hidden_dim, noise_dim, program_layer, voxel_layer, device, max_len).to(device)
-        self.discriminator = DiscriminatorVoxel(7, 6, hidden_dim, voxel_layer, act="", max_len=max_len).to(device)
+        # networks can be injected (same call signature) -- the multi-process CPU tests do that
+        self.generator = generator if generator is not None else \
+            Generator(7, 7, hidden_dim, noise_dim, program_layer, voxel_layer, device, max_len).to(device)
+        self.discriminator = discriminator if discriminator is not None else \
+            DiscriminatorVoxel(7, 6, hidden_dim, voxel_layer, act="", max_len=max_len).to(device)
         self.opt_g = FlatAdam(self.generator, g_lr, (b1, b2))
         self.opt_d = FlatAdam(self.discriminator, d_lr, (b1, b2))
         self.gp_lambda, self.n_critic_d, self.n_critic_g = gp_lambda, n_critic_d, n_critic_g
