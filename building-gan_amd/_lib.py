@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbgan_hip.so")
+LIB_PATH = os.environ.get("BG_LIB_PATH") or os.path.join(_HERE, "csrc", "libbgan_hip.so")  # env: tuning A/B only
 
 _p = C.c_void_p
 _i64 = C.c_int64

@@ -95,6 +95,56 @@ struct Stage {
     }
 };
 
+// Vector-path tile loader with incremental addressing: the per-thread pointers are set up once per
+// A segment and advanced by a constant per K step, so the steady-state loop issues bare
+// global_load_dwordx4 (no 64-bit index arithmetic, no exec-masked branches).  Rows / columns past
+// the matrix edge are clamped to a valid row: they only feed accumulators that are never stored.
+template <int ROWS, bool KC>
+struct FastLoader {
+    static constexpr int NF4 = ROWS * BK / 4 / 256;
+    const float* p[NF4];
+    const float* safe;
+    int64_t stride;
+
+    __device__ __forceinline__ int kofs(int i) const {
+        const int f = threadIdx.x + 256 * i;
+        return KC ? 4 * (f % (BK / 4)) : f / (ROWS / 4);
+    }
+    __device__ __forceinline__ void init(const float* base, int64_t ld, int64_t row0, int64_t n_rows, int64_t k0) {
+        safe = base;
+        stride = KC ? BK : BK * ld;
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            const int f = threadIdx.x + 256 * i;
+            if (KC) {
+                int64_t gr = row0 + f / (BK / 4);
+                gr = gr < n_rows ? gr : n_rows - 1;
+                p[i] = base + gr * ld + k0 + 4 * (f % (BK / 4));
+            } else {
+                int64_t gr = row0 + 4 * (f % (ROWS / 4));
+                gr = gr < n_rows ? gr : n_rows - 4;
+                p[i] = base + (k0 + f / (ROWS / 4)) * ld + gr;
+            }
+        }
+    }
+    // k_rem = K - k0 of the tile being loaded (> 0)
+    __device__ __forceinline__ void load(float4 (&r)[NF4], int64_t k_rem) {
+        if (k_rem >= BK) {
+#pragma unroll
+            for (int i = 0; i < NF4; ++i) r[i] = bg_ld4(p[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NF4; ++i) {
+                const bool in_k = kofs(i) < k_rem;
+                float4 v = bg_ld4(in_k ? p[i] : safe);
+                r[i] = in_k ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) p[i] += stride;
+    }
+};
+
 // fragment of one 32-row tile for the 8-deep k group g: 4 values, value j feeds MFMA step j
 template <int ROWS, bool KC>
 __device__ __forceinline__ float4 read_frag(const float* lds, int tile_row0, int g, int r, int h) {
@@ -146,6 +196,13 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 
     Stage<BM, A_KC, VEC> sa;
     Stage<BN, B_KC, VEC> sb;
+    FastLoader<BM, A_KC> fa;
+    FastLoader<BN, B_KC> fb;
+    int it_seg = 0; int64_t it_k0 = (int64_t)step_begin * BK, it_koff = 0;   // position of the NEXT tile to fetch
+    if (VEC && step_begin < step_end) {
+        fa.init(g.A[0], g.lda[0], m0, g.M, it_k0);
+        fb.init(Bp, ldb, n0, n_lim, it_k0);
+    }
 
     // step -> (segment, k offset inside the segment, k offset inside the concatenated K)
     auto locate = [&](int step, int& seg, int64_t& k0, int64_t& koff) {
@@ -159,6 +216,18 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         k0 = (int64_t)s * BK;
     };
     auto fetch = [&](int step) {
+        if (VEC) {
+            const int64_t k_rem = g.Ks[it_seg] - it_k0;
+            fa.load(sa.r, k_rem);
+            fb.load(sb.r, k_rem);
+            it_k0 += BK;
+            if (it_k0 >= g.Ks[it_seg] && it_seg + 1 < g.n_seg) {       // next tile starts a new A segment
+                it_koff += g.Ks[it_seg]; ++it_seg; it_k0 = 0;
+                fa.init(g.A[it_seg], g.lda[it_seg], m0, g.M, 0);
+                fb.init(B_KC ? Bp + it_koff : Bp + it_koff * ldb, ldb, n0, n_lim, 0);
+            }
+            return;
+        }
         int seg; int64_t k0, koff;
         locate(step, seg, k0, koff);
         sa.load(g.A[seg], g.lda[seg], m0, g.M, k0, g.Ks[seg]);
