@@ -152,8 +152,8 @@ class Trainer:
             # The three discriminator passes (fake, real, gradient-penalty sample) are independent
             # chains of medium-sized kernels; on separate HIP streams their ramp-up / tail phases
             # overlap and the chip stays full (autograd replays each chain's backward on its stream).
-            cur = torch.cuda.current_stream()
             side = self._side_streams
+            cur = torch.cuda.current_stream() if side is not None else None
 
             def on(k, fn):
                 if side is None:
