@@ -1,16 +1,38 @@
 // Integer segment plans: stable CSR build, segment pointers, floor levels, chunk tables.
 // All results are bit-exact against oracle/plan.py (numpy stable argsort / searchsorted).
+//
+// CSR build = counting sort: histogram -> scan -> placement -> per-row ordering.  Keys that are
+// already non-decreasing (stories, graphs, cross edges by voxel: the reference's batches are built
+// that way) are detected on the device and take the identity permutation without any sorting;
+// otherwise slots are claimed with atomics and every row is then put back into COO order
+// (insertion sort for short rows, a work list of long rows sorted by whole workgroups).
 #include "common.h"
 
 namespace {
 
+// flags layout per build: [0] keys out of range, [1] slots with perm != identity,
+//                         [2] order violations (key[e] < key[e-1]), [3] long-row work list length
+constexpr int kSmallRow = 16;
+constexpr int kLdsRow = 4096;
+
 __global__ void k_hist(const int64_t* __restrict__ key, int64_t E, int64_t N,
                        int32_t* __restrict__ count, int32_t* __restrict__ flags) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride) {
-        int64_t k = key[e];
-        if (k < 0 || k >= N) atomicAdd(&flags[0], 1);
-        else atomicAdd(&count[k + 1], 1);
+    int64_t base = (int64_t)blockIdx.x * blockDim.x;
+    for (; base < E; base += stride) {            // workgroup-uniform trip count
+        int64_t e = base + threadIdx.x;
+        const bool live = e < E;
+        int64_t k = live ? key[e] : -1;
+        const bool ok = live && k >= 0 && k < N;
+        if (live && !ok) atomicAdd(&flags[0], 1);
+        if (live && e > 0 && key[e - 1] > k) atomicAdd(&flags[2], 1);
+        // wave-aggregated when the whole wave holds one key (sorted / clustered inputs)
+        const int64_t k0 = __shfl(k, 0, 64);
+        if (__all(ok && k == k0)) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(&count[k0 + 1], 64);
+        } else if (ok) {
+            atomicAdd(&count[k + 1], 1);
+        }
     }
 }
 
@@ -39,18 +61,18 @@ __global__ __launch_bounds__(1024) void k_scan_inplace(int32_t* __restrict__ a, 
 }
 
 __global__ void k_place(const int64_t* __restrict__ key, int64_t E, int64_t N,
-                        int32_t* __restrict__ cursor, int32_t* __restrict__ perm) {
+                        int32_t* __restrict__ cursor, int32_t* __restrict__ perm,
+                        const int32_t* __restrict__ flags) {
+    const bool sorted = flags[2] == 0 && flags[0] == 0;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride) {
+        if (sorted) { perm[e] = (int32_t)e; continue; }      // stable sort of sorted keys = identity
         int64_t k = key[e];
         if (k < 0 || k >= N) continue;
         int32_t pos = atomicAdd(&cursor[k], 1);
         perm[pos] = (int32_t)e;
     }
 }
-
-constexpr int kSmallRow = 16;
-constexpr int kLdsRow = 4096;
 
 // all-ascending bitonic network on p[0..n): valid for any n (partners beyond n are +inf)
 __device__ void block_bitonic(int32_t* p, int n) {
@@ -78,31 +100,37 @@ __device__ void block_bitonic(int32_t* p, int n) {
     }
 }
 
-// Each workgroup owns 256 consecutive rows.  Short rows: one thread, insertion sort.
-// Long rows: the whole workgroup sorts the row (through LDS when it fits).
-__global__ __launch_bounds__(256) void k_rowsort(const int32_t* __restrict__ rowptr, int64_t N,
-                                                 int32_t* __restrict__ perm) {
-    __shared__ int32_t buf[kLdsRow];
-    const int64_t row0 = (int64_t)blockIdx.x * 256;
-    const int64_t r = row0 + threadIdx.x;
-    if (r < N) {
-        int32_t b = rowptr[r], e = rowptr[r + 1];
-        int d = e - b;
-        if (d > 1 && d <= kSmallRow) {
-            for (int i = b + 1; i < e; ++i) {
-                int32_t v = perm[i];
-                int j = i - 1;
-                while (j >= b && perm[j] > v) { perm[j + 1] = perm[j]; --j; }
-                perm[j + 1] = v;
-            }
+// one thread per row: short rows are sorted here, long rows go to the work list (worklist[0..))
+__global__ void k_rowsort_short(const int32_t* __restrict__ rowptr, int64_t N, int32_t* __restrict__ perm,
+                                int32_t* __restrict__ flags, int32_t* __restrict__ worklist) {
+    if (flags[2] == 0 && flags[0] == 0) return;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const int32_t b = rowptr[r], e = rowptr[r + 1];
+    const int d = e - b;
+    if (d <= 1) return;
+    if (d <= kSmallRow) {
+        for (int i = b + 1; i < e; ++i) {
+            int32_t v = perm[i];
+            int j = i - 1;
+            while (j >= b && perm[j] > v) { perm[j + 1] = perm[j]; --j; }
+            perm[j + 1] = v;
         }
+    } else {
+        worklist[atomicAdd(&flags[3], 1)] = (int32_t)r;
     }
-    __syncthreads();
-    const int64_t rend = (row0 + 256 < N) ? row0 + 256 : N;
-    for (int64_t rr = row0; rr < rend; ++rr) {   // workgroup-uniform loop
-        int32_t b = rowptr[rr], e = rowptr[rr + 1];
-        int d = e - b;
-        if (d <= kSmallRow) continue;
+}
+
+// workgroups walk the work list; one row at a time per workgroup (LDS when it fits)
+__global__ __launch_bounds__(256) void k_rowsort_long(const int32_t* __restrict__ rowptr, int32_t* __restrict__ perm,
+                                                      const int32_t* __restrict__ flags,
+                                                      const int32_t* __restrict__ worklist) {
+    __shared__ int32_t buf[kLdsRow];
+    const int n = flags[3];
+    for (int w = blockIdx.x; w < n; w += gridDim.x) {      // workgroup-uniform
+        const int32_t r = worklist[w];
+        const int32_t b = rowptr[r], e = rowptr[r + 1];
+        const int d = e - b;
         if (d <= kLdsRow) {
             for (int i = threadIdx.x; i < d; i += blockDim.x) buf[i] = perm[b + i];
             __syncthreads();
@@ -110,7 +138,6 @@ __global__ __launch_bounds__(256) void k_rowsort(const int32_t* __restrict__ row
             for (int i = threadIdx.x; i < d; i += blockDim.x) perm[b + i] = buf[i];
             __syncthreads();
         } else {
-            __syncthreads();
             block_bitonic(perm + b, d);
         }
     }
@@ -131,10 +158,7 @@ __global__ void k_fill_col(const int64_t* __restrict__ other, const int32_t* __r
 __global__ void k_segptr(const int64_t* __restrict__ seg, int64_t n, int64_t nseg,
                          int32_t* __restrict__ ptr, int32_t* __restrict__ flags) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) {
-        if (i == n && n == 0) for (int64_t s = 0; s <= nseg; ++s) ptr[s] = 0;
-        return;
-    }
+    if (i >= n) return;
     int64_t cur = seg[i];
     int64_t prev = (i > 0) ? seg[i - 1] : -1;
     if (cur < prev || cur < 0 || cur >= nseg) { atomicAdd(&flags[0], 1); return; }
@@ -147,12 +171,27 @@ __global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
     if (i < n) p[i] = v;
 }
 
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
 __global__ void k_floor_min(const int64_t* __restrict__ vfc, const int64_t* __restrict__ vbi, int64_t n, int64_t B,
                             int32_t* __restrict__ first) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int64_t g = vbi[i];
-    if (g >= 0 && g < B) atomicMin(&first[g], (int32_t)vfc[i]);
+    int64_t base = (int64_t)blockIdx.x * blockDim.x;
+    int64_t i = base + threadIdx.x;
+    const bool live = i < n;
+    int64_t g = live ? vbi[i] : -1;
+    const bool ok = live && g >= 0 && g < B;
+    int32_t v = ok ? (int32_t)vfc[i] : 0x7fffffff;
+    const int64_t g0 = __shfl(g, 0, 64);
+    if (__all(ok && g == g0)) {                    // one graph per wave: one atomic per wave
+        v = wave_min_i32(v);
+        if ((threadIdx.x & 63) == 0) atomicMin(&first[g0], v);
+    } else if (ok) {
+        atomicMin(&first[g], v);
+    }
 }
 
 __global__ void k_floor_level(const int64_t* __restrict__ vfc, const int64_t* __restrict__ vbi, int64_t n, int64_t B,
@@ -212,9 +251,12 @@ int bg_plan_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N,
     BG_LAUNCH_CHECK();
     if (E > 0) {
         BG_HIP(hipMemcpyAsync(cursor, rowptr, sizeof(int32_t) * (N + 1), hipMemcpyDeviceToDevice, s));
-        k_place<<<bg_grid_for(E, 256, 2048), 256, 0, s>>>(key, E, N, cursor, perm);
+        k_place<<<bg_grid_for(E, 256, 2048), 256, 0, s>>>(key, E, N, cursor, perm, flags);
         BG_LAUNCH_CHECK();
-        k_rowsort<<<bg_grid_for(N, 256), 256, 0, s>>>(rowptr, N, perm);
+        // cursor is free again after placement: it becomes the work list of long rows
+        k_rowsort_short<<<bg_grid_for(N, 256), 256, 0, s>>>(rowptr, N, perm, flags, cursor);
+        BG_LAUNCH_CHECK();
+        k_rowsort_long<<<512, 256, 0, s>>>(rowptr, perm, flags, cursor);
         BG_LAUNCH_CHECK();
         k_fill_col<<<bg_grid_for(E, 256, 2048), 256, 0, s>>>(other, perm, E, col, flags);
         BG_LAUNCH_CHECK();

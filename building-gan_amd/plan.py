@@ -65,7 +65,7 @@ class _Builder:
     def __init__(self, device, max_builds=24):
         self.device = device
         self.lib = _lib.load()
-        self.flags = torch.zeros(max_builds, 2, dtype=torch.int32, device=device)
+        self.flags = torch.zeros(max_builds, 4, dtype=torch.int32, device=device)
         self.names = []
 
     def _slot(self, name):
@@ -121,8 +121,8 @@ class _Builder:
         extra int32 scalars) back."""
         n = len(self.names)
         host = torch.cat([self.flags[:n].reshape(-1), extra.reshape(-1).to(torch.int32)]).cpu()
-        fl = host[: 2 * n].view(n, 2)
-        return {nm: (int(fl[i, 0]), int(fl[i, 1])) for i, nm in enumerate(self.names)}, host[2 * n:].tolist()
+        fl = host[: 4 * n].view(n, 4)
+        return {nm: tuple(int(x) for x in fl[i]) for i, nm in enumerate(self.names)}, host[4 * n:].tolist()
 
 
 @dataclass
@@ -238,7 +238,8 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     flags, (max_level, min_vdeg, min_pdeg, min_cross) = b.finish(extra)
     o["max_level"] = int(max_level)
     o["vox_all_has"], o["prog_all_has"] = min_vdeg > 0, min_pdeg > 0
-    for name, (bad, moved) in flags.items():
+    for name, fl in flags.items():
+        bad = fl[0]
         if bad:
             raise _lib.BganError(f"plan '{name}': {bad} index values out of range")
     p.ops["flags"] = flags

@@ -33,8 +33,9 @@ const char* bg_error_string(int code);
 
 /* Stable counting sort of E edges by key[e] in [0,N): rowptr[N+1], perm[E] (original edge id
  * of each CSR slot, ascending inside a row) and col[E] = other[perm].  cursor: int32[N+1]
- * scratch.  flags[0] += number of keys outside [0,N); flags[1] += number of slots with
- * perm[k] != k (0 => the COO list was already sorted).  flags must be zeroed by the caller.
+ * scratch.  flags: int32[4], zeroed by the caller: [0] += keys outside [0,N); [1] += slots with
+ * perm[k] != k; [2] += order violations key[e] < key[e-1] (0 => identity permutation, no sorting
+ * is done); [3] = number of long rows that were sorted by whole workgroups.
  * replaces: the COO->segment bookkeeping inside torch_scatter that every scatter call of
  * Model/models.py:65,158 (MessagePassing.propagate), :71,:166-167 (avg_pool_x) performs.   */
 int bg_plan_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N,
