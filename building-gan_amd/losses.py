@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .util import softmax_to_hard
 from .util_graph import get_program_ratio
 
@@ -71,7 +72,11 @@ def compute_gradient_penalty(Dv, batch, label, out, u: Optional[torch.Tensor] = 
     mixed = (label * u + out * (1 - u)).detach().requires_grad_(True)
     nonzero = (mixed.max(dim=-1)[0] != 0).type(torch.float32).view(-1, 1)
     sample = softmax_to_hard(mixed, -1) * nonzero
-    val_b, val_s = Dv(batch, sample)
+    if getattr(Dv, "piecewise_linear", False):
+        with ops.input_grads_only():
+            val_b, val_s = Dv(batch, sample)
+    else:
+        val_b, val_s = Dv(batch, sample)
     grad_b = torch.autograd.grad(val_b, sample, torch.ones_like(val_b), retain_graph=True, create_graph=True)[0]
     grad_s = torch.autograd.grad(val_s, sample, torch.ones_like(val_s), retain_graph=True, create_graph=True)[0]
     gp_b = ((grad_b.norm(2, 1) - 1) ** 2).mean()

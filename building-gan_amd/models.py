@@ -310,6 +310,10 @@ class DiscriminatorVoxel(nn.Module):
         self.voxelGNN_D = VoxelGNN_D(voxel_input_feature_dim, voxel_input_label_dim, hidden_dim, voxel_layer, max_len)
         self.building_dec = MLP([2 * hidden_dim, hidden_dim, 1], act)
         self.story_dec = MLP([2 * hidden_dim, hidden_dim, 1], act)
+        # no activation anywhere (the WGAN-GP configuration): outputs depend on the forward
+        # activations only through arg-max choices, so a gradient penalty reaches the parameters
+        # through the double-backward graph alone (see ops.input_grads_only)
+        self.piecewise_linear = not any(k in act for k in ("relu", "tanh", "sigmoid"))
 
     def forward(self, graph, out_label):
         plan = build_plan(graph)

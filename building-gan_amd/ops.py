@@ -6,6 +6,7 @@ through the discriminator (/root/reference/Model/losses.py:83-84, create_graph=T
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import List, Optional, Sequence
 
@@ -16,6 +17,25 @@ from ._lib import check, ptr, stream
 from .plan import Csr, LinOp, SCALE_NONE
 
 ACT_NONE, ACT_LEAKY = 0, 1
+
+_INPUT_GRADS_ONLY = False
+
+
+@contextlib.contextmanager
+def input_grads_only():
+    """Linears evaluated inside this context will not produce weight / bias gradients when they
+    are differentiated: only the gradient with respect to their inputs (which still depends
+    differentiably on the weights).  Used for the gradient-penalty pass, where the discriminator's
+    forward graph is differentiated with respect to the sample only (reference losses.py:83-84) and
+    the parameter gradients arrive through the double-backward graph; autograd would otherwise
+    compute -- and discard -- a weight-gradient GEMM per layer in each of the two grad calls."""
+    global _INPUT_GRADS_ONLY
+    prev = _INPUT_GRADS_ONLY
+    _INPUT_GRADS_ONLY = True
+    try:
+        yield
+    finally:
+        _INPUT_GRADS_ONLY = prev
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -315,6 +335,7 @@ class LinearCat(torch.autograd.Function):
         y = gemm_raw(list(xs), W, False, True, bias=b, row_scale=row_scale, act=act, slope=slope,
                      residual=fuse_res, pre_add=pre_add)
         ctx.act, ctx.slope = act, slope
+        ctx.inputs_only = _INPUT_GRADS_ONLY
         ctx.has_res, ctx.has_pre = residual is not None, pre_add is not None
         ctx.widths = [x.shape[1] for x in xs]
         pos = (y > 0) if act == ACT_LEAKY else None      # sign of the pre-activation
@@ -333,9 +354,9 @@ class LinearCat(torch.autograd.Function):
         if row_scale is not None:
             g = g * row_scale.view(-1, 1)
         gW = gb = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and not ctx.inputs_only:
             gW = CatTN.apply(g, *xs)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not ctx.inputs_only:
             gb = ColSum.apply(g)
         gxs: List[Optional[torch.Tensor]] = [None] * len(xs)
         if any(ctx.needs_input_grad[7:]):
