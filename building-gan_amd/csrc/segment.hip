@@ -13,6 +13,8 @@ struct SpmmArgs {
     const float* col_scale; int col_mode;
     float* out; int64_t ldo;
     int64_t n_rows; int H4;   // H4 = H / 4 float4 columns (<= 64 per launch)
+    const float* add1; int64_t ld1;   // optional addends: out = rs * sum + add1 + add2
+    const float* add2; int64_t ld2;
 };
 
 __device__ __forceinline__ float apply_scale(float v, float s, int mode) {
@@ -64,6 +66,8 @@ __global__ __launch_bounds__(256) void k_spmm_vec(SpmmArgs a) {
         acc.x = apply_scale(acc.x, s, a.row_mode); acc.y = apply_scale(acc.y, s, a.row_mode);
         acc.z = apply_scale(acc.z, s, a.row_mode); acc.w = apply_scale(acc.w, s, a.row_mode);
     }
+    if (a.add1) acc = bg_add4(acc, bg_ld4(a.add1 + row * a.ld1 + 4 * sub));
+    if (a.add2) acc = bg_add4(acc, bg_ld4(a.add2 + row * a.ld2 + 4 * sub));
     bg_st4(a.out + row * a.ldo + 4 * sub, acc);
 }
 
@@ -81,6 +85,8 @@ __global__ void k_spmm_scalar(SpmmArgs a, int H) {
         acc += w * a.x[(int64_t)c * a.ldx + h];
     }
     if (a.row_mode) acc = apply_scale(acc, a.row_scale[row], a.row_mode);
+    if (a.add1) acc += a.add1[row * a.ld1 + h];
+    if (a.add2) acc += a.add2[row * a.ld2 + h];
     a.out[row * a.ldo + h] = acc;
 }
 
@@ -105,7 +111,8 @@ int launch_spmm_vec(const SpmmArgs& a, hipStream_t s) {
 
 int spmm_dispatch(SpmmArgs a, int64_t H, hipStream_t s) {
     if (a.n_rows == 0 || H == 0) return BG_OK;
-    bool vec = (H % 4 == 0) && (a.ldx % 4 == 0) && (a.ldo % 4 == 0) && bg_aligned16(a.x) && bg_aligned16(a.out);
+    bool vec = (H % 4 == 0) && (a.ldx % 4 == 0) && (a.ldo % 4 == 0) && bg_aligned16(a.x) && bg_aligned16(a.out) &&
+               (!a.add1 || (bg_aligned16(a.add1) && a.ld1 % 4 == 0)) && (!a.add2 || (bg_aligned16(a.add2) && a.ld2 % 4 == 0));
     if (!vec) {
         k_spmm_scalar<<<bg_grid_for(a.n_rows * H, 256, 0x7fffffff), 256, 0, s>>>(a, (int)H);
         BG_LAUNCH_CHECK();
@@ -115,6 +122,8 @@ int spmm_dispatch(SpmmArgs a, int64_t H, hipStream_t s) {
     for (int64_t h0 = 0; h0 < H; h0 += 256) {   // panels of 64 float4 columns
         SpmmArgs p = a;
         p.x = a.x + h0; p.out = a.out + h0;
+        if (a.add1) p.add1 = a.add1 + h0;
+        if (a.add2) p.add2 = a.add2 + h0;
         p.H4 = (int)((H - h0 < 256 ? H - h0 : 256) / 4);
         int rc = general ? launch_spmm_vec<true>(p, s) : launch_spmm_vec<false>(p, s);
         if (rc != BG_OK) return rc;
@@ -361,7 +370,22 @@ int bg_spmm_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_
     if (n_rows == 0 || H == 0) return BG_OK;
     if (!x || !rowptr || !out || ldx < H || ldo < H) return BG_ERR_ARG;
     if ((row_mode && !row_scale) || (col_mode && !col_scale) || (eperm && !edge_w)) return BG_ERR_ARG;
-    SpmmArgs a{x, ldx, rowptr, col, edge_w, eperm, row_scale, row_mode, col_scale, col_mode, out, ldo, n_rows, 0};
+    SpmmArgs a{x, ldx, rowptr, col, edge_w, eperm, row_scale, row_mode, col_scale, col_mode, out, ldo, n_rows, 0,
+               nullptr, 0, nullptr, 0};
+    return spmm_dispatch(a, H, (hipStream_t)stream);
+}
+
+int bg_spmm_add_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                    const float* row_scale, int row_mode, const float* col_scale, int col_mode,
+                    const float* add1, int64_t ld1, const float* add2, int64_t ld2,
+                    float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream) {
+    if (n_rows < 0 || H < 0) return BG_ERR_ARG;
+    if (n_rows == 0 || H == 0) return BG_OK;
+    if (!x || !rowptr || !out || ldx < H || ldo < H) return BG_ERR_ARG;
+    if ((row_mode && !row_scale) || (col_mode && !col_scale)) return BG_ERR_ARG;
+    if ((add1 && ld1 < H) || (add2 && ld2 < H)) return BG_ERR_ARG;
+    SpmmArgs a{x, ldx, rowptr, col, nullptr, nullptr, row_scale, row_mode, col_scale, col_mode, out, ldo, n_rows, 0,
+               add1, ld1, add2, ld2};
     return spmm_dispatch(a, H, (hipStream_t)stream);
 }
 
@@ -382,7 +406,8 @@ int bg_segreduce_sum_f32(const float* x, int64_t ldx, const int32_t* rowptr, con
         if (rc != BG_OK) return rc;
     }
     // phase 2: out[r,:] = rs(r) * sum of the row's chunk partials, in chunk order
-    SpmmArgs p{partial, H, chunk_ptr, nullptr, nullptr, nullptr, row_scale, row_mode, nullptr, 0, out, ldo, n_rows, 0};
+    SpmmArgs p{partial, H, chunk_ptr, nullptr, nullptr, nullptr, row_scale, row_mode, nullptr, 0, out, ldo, n_rows, 0,
+               nullptr, 0, nullptr, 0};
     return spmm_dispatch(p, H, s);
 }
 

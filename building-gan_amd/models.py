@@ -26,6 +26,7 @@ from .plan import LinOp, build_plan
 
 NUMBER_OF_CLASS = 6  # /root/reference/Data/GraphConstructor.py:9
 COMPOSE_BLOCKS = True  # collapse messageMLP into updateMLP where legal (VoxelBlock.compose)
+COMPOSE_STACK = True   # run the discriminator's 12 composed layers as one autograd node (ops.AffineStack)
 
 
 def position_encoder(d_model: int, max_len: int = 20) -> torch.Tensor:
@@ -275,6 +276,8 @@ class VoxelGNN_D(nn.Module):
         v = v + ops.spmm_raw(_level_op(plan, self.pe.shape[0]), self.pe)
         v = torch.cat([v, run_mlp(self.label_enc, l)], dim=-1)
         composed = self.block.compose() if (COMPOSE_BLOCKS and plan.vox_all_has) else None
+        if composed is not None and COMPOSE_STACK and self.layer_num > 0:
+            return ops.AffineStack.apply(v, composed[0], composed[1], pdm4, plan.vox_mean, self.layer_num)
         for _ in range(self.layer_num):
             if composed is not None:
                 v = self.block.forward_composed(v, plan, pdm4, composed)

@@ -54,7 +54,8 @@ def _ld(t: torch.Tensor) -> int:
 
 
 # ------------------------------------------------------------------------------- raw launchers
-def spmm_raw(op: LinOp, x: torch.Tensor, edge_w: Optional[torch.Tensor] = None) -> torch.Tensor:
+def spmm_raw(op: LinOp, x: torch.Tensor, edge_w: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     _lib.require_device(x, "spmm")
     squeeze = x.dim() == 1
@@ -63,7 +64,8 @@ def spmm_raw(op: LinOp, x: torch.Tensor, edge_w: Optional[torch.Tensor] = None) 
     if x2.shape[0] != c.n_cols:
         raise _lib.BganError(f"spmm: operand has {x2.shape[0]} rows, plan expects {c.n_cols}")
     H = x2.shape[1]
-    out = torch.empty(c.n_rows, H, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(c.n_rows, H, dtype=torch.float32, device=x.device)
     eperm = None
     if edge_w is not None:
         edge_w = _f32c(edge_w.reshape(-1))
@@ -74,13 +76,32 @@ def spmm_raw(op: LinOp, x: torch.Tensor, edge_w: Optional[torch.Tensor] = None) 
         partial = torch.empty(c.n_chunks_ub, H, dtype=torch.float32, device=x.device)
         check(lib.bg_segreduce_sum_f32(ptr(x2), _ld(x2), ptr(c.rowptr), ptr(c.col), ptr(edge_w), ptr(eperm),
                                        ptr(op.row_scale), op.row_mode, ptr(c.chunk_ptr), c.rows_per_chunk,
-                                       c.n_chunks_ub, ptr(partial), ptr(out), H, c.n_rows, H, stream()),
+                                       c.n_chunks_ub, ptr(partial), ptr(out), _ld(out), c.n_rows, H, stream()),
               "bg_segreduce_sum_f32")
     else:
         check(lib.bg_spmm_f32(ptr(x2), _ld(x2), ptr(c.rowptr), ptr(c.col), ptr(edge_w), ptr(eperm),
                               ptr(op.row_scale), op.row_mode, ptr(op.col_scale), op.col_mode,
-                              ptr(out), H, c.n_rows, H, stream()), "bg_spmm_f32")
+                              ptr(out), _ld(out), c.n_rows, H, stream()), "bg_spmm_f32")
     return out.view(-1) if squeeze else out
+
+
+def spmm_add_raw(op: LinOp, x: torch.Tensor, add1=None, add2=None, out=None) -> torch.Tensor:
+    """out = op(x) + add1 + add2 in one pass (short-row plans only)."""
+    lib = _lib.load()
+    c: Csr = op.csr
+    x2 = _f32c(x)
+    if x2.shape[0] != c.n_cols:
+        raise _lib.BganError("spmm_add: operand rows do not match the plan")
+    H = x2.shape[1]
+    if out is None:
+        out = torch.empty(c.n_rows, H, dtype=torch.float32, device=x.device)
+    a1 = _f32c(add1) if add1 is not None else None
+    a2 = _f32c(add2) if add2 is not None else None
+    check(lib.bg_spmm_add_f32(ptr(x2), _ld(x2), ptr(c.rowptr), ptr(c.col), ptr(op.row_scale), op.row_mode,
+                              ptr(op.col_scale), op.col_mode, ptr(a1), _ld(a1) if a1 is not None else 0,
+                              ptr(a2), _ld(a2) if a2 is not None else 0, ptr(out), _ld(out), c.n_rows, H, stream()),
+          "bg_spmm_add_f32")
+    return out
 
 
 def sddmm_raw(op: LinOp, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -139,7 +160,7 @@ _I64Arr4 = C.c_int64 * 4
 def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: bool,
              bias: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
              act: int = ACT_NONE, slope: float = 0.01, residual: Optional[torch.Tensor] = None,
-             pre_add: Optional[torch.Tensor] = None) -> torch.Tensor:
+             pre_add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C = epilogue(cat(A, -1 (or 0 when transA)) (x) B); see bg_gemm_f32."""
     lib = _lib.load()
     if len(A) < 1 or len(A) > 4:
@@ -156,7 +177,10 @@ def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: b
     N = B2.shape[0] if transB else B2.shape[1]
     if (B2.shape[1] if transB else B2.shape[0]) != Ktot:
         raise _lib.BganError(f"gemm: reduction sizes differ ({Ktot} vs {tuple(B2.shape)}, transB={transB})")
-    out = torch.empty(M, N, dtype=torch.float32, device=B2.device)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=B2.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != torch.float32 or out.stride(-1) != 1:
+        raise _lib.BganError("gemm: `out` must be an fp32 [M, N] matrix with unit inner stride")
     if M == 0 or N == 0:
         return out
     pa = _PtrArr4(*([a.data_ptr() for a in As] + [None] * (4 - len(As))))
@@ -170,7 +194,7 @@ def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: b
         residual = _f32c(residual)
     if pre_add is not None:
         pre_add = _f32c(pre_add)
-    check(lib.bg_gemm_f32(int(transA), int(transB), M, N, len(As), pa, la, ka, ptr(B2), _ld(B2), ptr(out), N,
+    check(lib.bg_gemm_f32(int(transA), int(transB), M, N, len(As), pa, la, ka, ptr(B2), _ld(B2), ptr(out), _ld(out),
                           ptr(bias), ptr(row_scale), act, slope, ptr(residual),
                           _ld(residual) if residual is not None else 0, ptr(pre_add),
                           _ld(pre_add) if pre_add is not None else 0, stream()), "bg_gemm_f32")
@@ -504,3 +528,112 @@ def adam_step(param, grad, m, v, lr, beta1, beta2, eps, step, step_dev=None):
     lib = _lib.load()
     check(lib.bg_adam_f32(ptr(param), ptr(grad), ptr(m), ptr(v), param.numel(), lr, beta1, beta2, eps,
                           int(step) if step_dev is None else 0, ptr(step_dev), stream()), "bg_adam_f32")
+
+
+# ------------------------------------------------------------------------------- fused layer stack
+class AffineStack(torch.autograd.Function):
+    """L residual message-passing layers with ONE shared affine map (the discriminator's composed
+    VoxelBlock, models.VoxelBlock.compose):
+
+        v_{l+1} = v_l + [v_l | A v_l | p] Wc^T + bc ,   l = 0..L-1 ,   A = the plan's gather-mean.
+
+    One autograd node for the whole stack: layer inputs live in one [L, N, H] buffer, so the weight
+    gradient of all L layers is a single split-K GEMM over L*N rows, the bias gradient one column
+    sum, and each layer's input gradient  g + gx[:, :H] + A^T gx[:, H:2H]  one fused gather pass.
+    Differentiable twice: under create_graph the input gradient is produced by AffineStackT, whose
+    own backward is hand-written (third order is not provided).
+    """
+
+    @staticmethod
+    def forward(ctx, v0, Wc, bc, p, op: LinOp, L: int):
+        N, H = v0.shape
+        dev = v0.device
+        Vs = torch.empty(L + 1, N, H, dtype=torch.float32, device=dev)
+        GMs = torch.empty(L, N, H, dtype=torch.float32, device=dev)
+        Vs[0].copy_(v0)
+        for l in range(L):
+            spmm_raw(op, Vs[l], out=GMs[l])
+            gemm_raw([Vs[l], GMs[l], p], Wc, False, True, bias=bc, residual=Vs[l], out=Vs[l + 1])
+        ctx.op, ctx.L = op, L
+        ctx.inputs_only = _INPUT_GRADS_ONLY
+        ctx.save_for_backward(Vs, GMs, Wc, p)
+        return Vs[L]
+
+    @staticmethod
+    def backward(ctx, g):
+        Vs, GMs, Wc, p = ctx.saved_tensors
+        op, L = ctx.op, ctx.L
+        N, H = g.shape
+        need_w = ctx.needs_input_grad[1] and not ctx.inputs_only
+        need_b = ctx.needs_input_grad[2] and not ctx.inputs_only
+        if torch.is_grad_enabled():
+            # create_graph: the input gradient must itself be differentiable
+            gv = AffineStackT.apply(g, Wc, op, L) if ctx.needs_input_grad[0] else None
+            gW = gb = None
+            if need_w or need_b:
+                raise NotImplementedError("AffineStack: differentiable weight gradients are only provided through "
+                                          "ops.input_grads_only() (use COMPOSE_STACK = False for the generic path)")
+            return gv, gW, gb, None, None, None
+        Gs, g0 = _stack_transpose_chain(g, Wc, op, L, keep=need_w or need_b)
+        gW = gb = None
+        if need_w:
+            prep = p.unsqueeze(0).expand(L, N, p.shape[1]).reshape(L * N, p.shape[1])
+            gW = gemm_tn_raw(Gs.view(L * N, H), [Vs[:L].reshape(L * N, H), GMs.view(L * N, H), prep])
+        if need_b:
+            gb = colsum_raw(Gs.view(L * N, H))
+        return (g0 if ctx.needs_input_grad[0] else None), gW, gb, None, None, None
+
+
+def _stack_transpose_chain(g, Wc, op: LinOp, L: int, keep: bool):
+    """G_L = g;  G_l = G_{l+1} + X[:, :H] + A^T X[:, H:2H],  X = G_{l+1} Wc.  Returns (Gs[l] = G_{l+1}, G_0)."""
+    N, H = g.shape
+    g = _f32c(g)
+    Gs = torch.empty(L, N, H, dtype=torch.float32, device=g.device) if keep else None
+    X = torch.empty(N, Wc.shape[1], dtype=torch.float32, device=g.device)
+    cur = g
+    if keep:
+        Gs[L - 1].copy_(g)
+        cur = Gs[L - 1]
+    for l in range(L - 1, -1, -1):
+        gemm_raw([cur], Wc, False, False, out=X)
+        if keep and l > 0:
+            nxt = Gs[l - 1]
+        else:
+            nxt = torch.empty(N, H, dtype=torch.float32, device=g.device)
+        spmm_add_raw(op.T, X[:, H:2 * H], cur, X[:, :H], out=nxt)
+        cur = nxt
+    return Gs, cur
+
+
+class AffineStackT(torch.autograd.Function):
+    """g0 = T^L g with T(G) = G + (G Wc)[:, :H] + A^T (G Wc)[:, H:2H]: the input gradient of AffineStack
+    as a differentiable function of (g, Wc).  Its backward (the WGAN-GP double backward) is
+        U_{l+1} = U_l + [U_l | A U_l] Wc[:, :2H]^T ,   dWc[:, :2H] = sum_l G_{l+1}^T [U_l | A U_l]."""
+
+    @staticmethod
+    def forward(ctx, g, Wc, op: LinOp, L: int):
+        Gs, g0 = _stack_transpose_chain(g, Wc, op, L, keep=True)
+        ctx.op, ctx.L = op, L
+        ctx.save_for_backward(Gs, Wc)
+        return g0
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, u):
+        Gs, Wc = ctx.saved_tensors
+        op, L = ctx.op, ctx.L
+        N, H = u.shape
+        dev = u.device
+        Us = torch.empty(L + 1, N, H, dtype=torch.float32, device=dev)
+        AUs = torch.empty(L, N, H, dtype=torch.float32, device=dev)
+        Us[0].copy_(u)
+        W2 = Wc[:, :2 * H]
+        for l in range(L):
+            spmm_raw(op, Us[l], out=AUs[l])
+            gemm_raw([Us[l], AUs[l]], W2, False, True, residual=Us[l], out=Us[l + 1])
+        gW = None
+        if ctx.needs_input_grad[1]:
+            # G_{l+1} pairs with U_l:  Gs[l] holds G_{l+1}
+            gW2 = gemm_tn_raw(Gs.view(L * N, H), [Us[:L].reshape(L * N, H), AUs.view(L * N, H)])
+            gW = torch.nn.functional.pad(gW2, (0, Wc.shape[1] - 2 * H))
+        return (Us[L] if ctx.needs_input_grad[0] else None), gW, None, None
