@@ -155,7 +155,9 @@ def test_trainer_matches_oracle_iterations(cuda):
         torch.testing.assert_close(sh["d_loss"].cpu(), so["d_loss"], rtol=2.5 * tol, atol=5e-3)
         torch.testing.assert_close(sh["gp"].cpu(), so["gp"], rtol=tol, atol=1e-4)
         if i == 0:
-            torch.testing.assert_close(sh["g_loss"].cpu().view(-1), so["g_loss"].view(-1), rtol=2e-3, atol=1e-3)
+            # g_loss is evaluated AFTER the discriminator's first Adam step (a +-lr move per weight whose
+            # sign is rounding-sensitive where the gradient is ~0), so it only agrees to ~1e-2
+            torch.testing.assert_close(sh["g_loss"].cpu().view(-1), so["g_loss"].view(-1), rtol=1e-2, atol=5e-3)
     # Adam's first steps move every weight by ~lr regardless of gradient scale: compare updates loosely
     for (n, po), (_, ph) in zip(list(Do.named_parameters()) + list(Go.named_parameters()),
                                 list(tr.discriminator.named_parameters()) + list(tr.generator.named_parameters())):
@@ -184,3 +186,70 @@ def test_graph_capture_replays_and_restores_state(cuda):
     # an eager iteration on the same trainer still works after replays
     s2 = tr.train_iteration(batch, 7)
     assert torch.isfinite(s2["d_loss"]).all()
+
+
+def test_isolated_voxel_falls_back_to_two_linear_path(cuda):
+    """A 1x1x1 building has a voxel without in-edges: mean aggregation gives 0 there (not W x_i + b),
+    so the composed-weight shortcut is illegal and the literal two-Linear path must be taken."""
+    import numpy as np
+    from building_gan_amd import models as hm
+    from building_gan_amd.graph import Batch
+    from building_gan_amd.plan import build_plan
+    from building_gan_amd.synthetic import batch_sizes, make_graph
+    from oracle import networks as om
+    rng = np.random.default_rng(5)
+    data = [make_graph(rng, 2, 3, 2, [2, 3], data_id=0), make_graph(rng, 1, 1, 1, [2], data_id=1)]
+    cpu = Batch.from_data_list(data)
+    sz = batch_sizes(cpu)
+    gpu = copy.deepcopy(cpu).to(cuda)
+    assert not build_plan(gpu).vox_all_has
+    torch.manual_seed(3)
+    Go, Do = om.Generator(7, 7, 128, 32, 2, 4), om.DiscriminatorVoxel(7, 6, 128, 4)
+    Gh, Dh = hm.Generator(7, 7, 128, 32, 2, 4, cuda).to(cuda), hm.DiscriminatorVoxel(7, 6, 128, 4).to(cuda)
+    Gh.load_state_dict(Go.state_dict())
+    Dh.load_state_dict(Do.state_dict())
+    noise = [(torch.empty(sz["Nv"], 2).exponential_(), torch.empty(sz["Ec"]).exponential_()) for _ in range(2)]
+    pz, vz = torch.rand(sz["Np"], 32), torch.rand(sz["Nv"], 32)
+    out_o, soft_o, _, _, idx_o = Go(cpu, pz, vz, noise)
+    out_h, soft_h, _, _, idx_h = Gh(gpu, pz.to(cuda), vz.to(cuda), _to(noise, cuda))
+    assert torch.equal(idx_h.cpu(), idx_o)
+    torch.testing.assert_close(soft_h.detach().cpu(), soft_o.detach(), rtol=1e-4, atol=1e-5)
+    lab_o = cpu.voxel_label.clone().requires_grad_(True)
+    lab_h = gpu.voxel_label.clone().requires_grad_(True)
+    bo, so = Do(cpu, lab_o)
+    bh, sh = Dh(gpu, lab_h)
+    torch.testing.assert_close(bh.detach().cpu(), bo.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(sh.detach().cpu(), so.detach(), rtol=1e-4, atol=1e-4)
+    (bo.sum() + so.sum()).backward()
+    (bh.sum() + sh.sum()).backward()
+    torch.testing.assert_close(lab_h.grad.cpu(), lab_o.grad, rtol=1e-3, atol=1e-4)
+
+
+def test_stack_node_equals_per_layer_nodes(cuda):
+    """ops.AffineStack against the same layers run as separate autograd nodes: outputs, first-order
+    gradients and the gradient-penalty double backward."""
+    from building_gan_amd import models as hm
+    from building_gan_amd.graph import detach_batch
+    from building_gan_amd.losses import compute_gradient_penalty
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 31, True, cuda)
+    torch.manual_seed(31)
+    u = torch.rand(sz["Nv"], 1, device=cuda)
+    soft = (torch.rand(sz["Nv"], 6).softmax(-1) * (torch.rand(sz["Nv"], 1) > 0.3).float()).to(cuda)
+    res = {}
+    for flag in (True, False):
+        hm.COMPOSE_STACK = flag
+        try:
+            Dh.zero_grad()
+            b, s = Dh(gpu, gpu.voxel_label)
+            gp, _, _ = compute_gradient_penalty(Dh, detach_batch(gpu), gpu.voxel_label, soft, u)
+            (b.sum() - s.sum() + 10 * gp).backward()
+            res[flag] = (b.detach().clone(), s.detach().clone(), gp.detach().clone(),
+                         [p.grad.clone() for p in Dh.parameters()])
+        finally:
+            hm.COMPOSE_STACK = True
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(res[True][1], res[False][1], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(res[True][2], res[False][2], rtol=1e-4, atol=1e-6)
+    for (n, _), a, c in zip(Dh.named_parameters(), res[True][3], res[False][3]):
+        scale = float(c.abs().max()) + 1e-6
+        assert float((a - c).abs().max()) <= 1e-3 * scale, n
