@@ -104,7 +104,7 @@ class Batch(VolumeDesignGraph):
     @staticmethod
     def from_data_list(data_list: Sequence[VolumeDesignGraph],
                        follow_batch: Iterable[str] = DEFAULT_FOLLOW_BATCH) -> "Batch":
-        follow_batch = tuple(follow_batch)
+        follow_batch = DEFAULT_FOLLOW_BATCH if follow_batch is None else tuple(follow_batch)
         batch = Batch()
         batch.num_graphs = len(data_list)
         keys = [k for k in GRAPH_KEYS if data_list[0][k] is not None]

@@ -1,0 +1,74 @@
+"""Inference-side helpers on the GPU against the oracle."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_check_connectivity_matches_reference_semantics(cuda):
+    from building_gan_amd.synthetic import batch_sizes, make_batch
+    from building_gan_amd.util_eval import check_connectivity as h
+    from oracle.evaluation import check_connectivity as o
+    cpu = make_batch("small", seed=41, ragged=True)
+    sz = batch_sizes(cpu)
+    torch.manual_seed(41)
+    # a plausible generator output: every voxel points at a program node of its own story
+    cev, cep = cpu.cross_edge_voxel_index_select, cpu.cross_edge_program_index_select
+    first = torch.zeros(sz["Nv"], dtype=torch.long).scatter_reduce(0, cev, torch.arange(sz["Ec"]), "amin", include_self=False)
+    count = torch.bincount(cev, minlength=sz["Nv"])
+    pick = first + (torch.rand(sz["Nv"]) * count).long()
+    idx = cep[pick]
+    mask = (torch.rand(sz["Nv"], 1) > 0.3).float()
+    ro = o(cpu, idx, mask)
+    gpu = copy.deepcopy(cpu).to(cuda)
+    rh = h(gpu, idx.to(cuda), mask.to(cuda))
+    for a, b in zip(rh, ro):
+        assert torch.equal(a.cpu(), b)
+    # nothing unmasked -> the reference's else branch
+    rh = h(gpu, idx.to(cuda), torch.zeros(sz["Nv"], 1, device=cuda))
+    assert rh[0].shape[1] == 0 and torch.equal(rh[1].cpu(), cpu.program_edge) and rh[2].shape[1] == 0
+
+
+def test_evaluate_and_variation_sampling_run(cuda):
+    from building_gan_amd import models as hm
+    from building_gan_amd.graph import Batch
+    from building_gan_amd.synthetic import make_batch, make_graph
+    from building_gan_amd.util_eval import evaluate, generate_multiple_outputs_from_data
+    import numpy as np
+    torch.manual_seed(0)
+    G = hm.Generator(7, 7, 128, 32, 4, 12, cuda).to(cuda)
+    loader = [make_batch("small", seed=s, ragged=True) for s in (1, 2)]
+    acc, res = evaluate(loader, G, None, None, None, [cuda], number_of_batches=2)
+    assert 0.0 <= acc <= 1.0 and len(res) == 2
+    assert res[0]["out"].shape[1] == 6 and res[0]["FAR"].shape[0] == loader[0].FAR.shape[0]
+    data = make_graph(np.random.default_rng(3), 3, 4, 3, [3, 2, 4])
+    out, idx, cw, pw, far = generate_multiple_outputs_from_data(data, 25, G, None, None, None, [cuda])
+    nv = data.voxel_feature.shape[0]
+    assert out.shape == (25 * nv, 6) and far.shape == (25, 1)
+    # different noise per copy -> the 25 variations are not all identical
+    copies = out.view(25, nv, 6)
+    assert not all(torch.equal(copies[0], copies[k]) for k in range(1, 25))
+
+
+def test_large_building_needs_a_longer_position_table(cuda):
+    """BASELINE configs[4]: a 32-story building exceeds the reference's 20-row table (models.py:13,192)."""
+    from building_gan_amd import models as hm
+    from building_gan_amd.graph import Batch
+    from building_gan_amd.synthetic import make_graph
+    import numpy as np
+    data = make_graph(np.random.default_rng(9), 32, 16, 16, [4] * 32)
+    batch = Batch.from_data_list([data, data]).to(cuda)
+    torch.manual_seed(1)
+    G20 = hm.Generator(7, 7, 128, 32, 4, 12, cuda).to(cuda)
+    z = (torch.rand(batch.program_class_feature.shape[0], 32, device=cuda), torch.rand(batch.voxel_feature.shape[0], 32, device=cuda))
+    with pytest.raises(IndexError):
+        G20(batch, *z)
+    G32 = hm.Generator(7, 7, 128, 32, 4, 12, cuda, max_len=32).to(cuda)
+    with torch.no_grad():
+        out, soft_out, mask, att, idx = G32(batch, *z)
+    assert out.shape == (batch.voxel_feature.shape[0], 6) and torch.isfinite(soft_out).all()
+    lo, hi = batch.__slices__["program_class_feature"][1], batch.__slices__["program_class_feature"][2]
+    nv = data.voxel_feature.shape[0]
+    assert int(idx[nv:].min()) >= lo and int(idx[nv:].max()) < hi      # second copy points into its own program nodes
