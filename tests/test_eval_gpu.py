@@ -72,3 +72,32 @@ def test_large_building_needs_a_longer_position_table(cuda):
     lo, hi = batch.__slices__["program_class_feature"][1], batch.__slices__["program_class_feature"][2]
     nv = data.voxel_feature.shape[0]
     assert int(idx[nv:].min()) >= lo and int(idx[nv:].max()) < hi      # second copy points into its own program nodes
+
+
+def test_inference_driver_with_released_weights(cuda, tmp_path):
+    """checkpoint file -> generator (strict=False) -> raw JSON designs -> result JSONs + 5 variations."""
+    import json
+    import os
+    import numpy as np
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_util import load_golden
+    from building_gan_amd.inference import run
+    from building_gan_amd.json_io import write_raw_jsons
+    from building_gan_amd.synthetic import make_graph
+    weights, _, _ = load_golden()
+    weights["programGNN.encNorm.weight"] = torch.ones(1)        # an extra key, as in the released file
+    ckpt = str(tmp_path / "70.ckpt")
+    torch.save(weights, ckpt)
+    raw = str(tmp_path / "raw")
+    rng = np.random.default_rng(2)
+    for i, (f, x, y) in enumerate([(3, 4, 3), (2, 3, 3), (4, 2, 2)]):
+        write_raw_jsons(make_graph(rng, f, x, y, [3] * f, data_id=i), x, raw)
+    acc = run(ckpt, raw, str(tmp_path / "out"), [0, 1, 2], cuda, batch_size=2, variation_num=5, variation_ids=[1])
+    assert 0.0 <= acc <= 1.0
+    for i in range(3):
+        v = json.load(open(tmp_path / "out" / "output" / "voxel_data" / ("voxel_%06d.json" % i)))
+        assert all(n["type"] in (-1, 0, 1, 2, 3, 4, 5) for n in v["voxel_node"])
+        g = json.load(open(tmp_path / "out" / "output" / "global_graph_data" / ("graph_global_%06d.json" % i)))
+        assert "new_far" in g and all("new_proportion" in n for n in g["global_node"])
+    assert len(os.listdir(tmp_path / "out" / "var_output1" / "voxel_data")) == 5
