@@ -33,6 +33,9 @@ struct GemmArgs {
     float* partial;       // split-K: [splits, M, N]
     // split-K (TN) only: B may be given as column segments  B = [B_0 | B_1 | ..]  (fused cat of the inputs)
     const float* Bseg[4]; int64_t ldbseg[4]; int64_t Nseg[4]; int n_bseg;
+    // 1-D launch: gx column tiles x gy row tiles x splits; xcd != 0 remaps the linear block id so that
+    // consecutive logical tiles (column tiles of one row panel, tiles of one K split) share an XCD's L2
+    int gx, gy, xcd;
 };
 
 template <int ROWS, bool KC, bool VEC>
@@ -166,12 +169,19 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int64_t m0 = (int64_t)blockIdx.y * BM;
-    int64_t n0 = (int64_t)blockIdx.x * BN;
+    // hardware deals workgroups round-robin over the 8 XCDs: give XCD x a contiguous range of logical tiles
+    uint32_t lid = blockIdx.x;
+    if (g.xcd) {
+        const uint32_t q = gridDim.x >> 3, rem = gridDim.x & 7, x = lid & 7, slot = lid >> 3;
+        lid = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + slot;
+    }
+    const int bx = lid % g.gx, by = (lid / g.gx) % g.gy, bz = lid / (g.gx * g.gy);
+    const int64_t m0 = (int64_t)by * BM;
+    int64_t n0 = (int64_t)bx * BN;
     // TN mode: locate the B segment this column tile belongs to (tiles never straddle segments)
     const float* Bp = g.B; int64_t ldb = g.ldb, n_lim = g.N, col_base = 0;
     if (SPLIT) {
-        int t = blockIdx.x, s = 0;
+        int t = bx, s = 0;
         while (s < g.n_bseg - 1) {
             int nt = (int)((g.Nseg[s] + BN - 1) / BN);
             if (t < nt) break;
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 
     int step_begin = 0, step_end = g.total_steps;
     if (SPLIT) {
-        step_begin = blockIdx.z * g.steps_per_split;
+        step_begin = bz * g.steps_per_split;
         step_end = min(step_begin + g.steps_per_split, g.total_steps);
     }
 
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
                 if (row >= g.M) continue;
                 float v = acc[i][j][q];
                 if (SPLIT) {
-                    g.partial[((int64_t)blockIdx.z * g.M + row) * g.N + col] = v;
+                    g.partial[((int64_t)bz * g.M + row) * g.N + col] = v;
                 } else {
                     v += bv;
                     if (g.row_scale) v *= g.row_scale[row];
@@ -368,9 +378,24 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
     if (lane == 0) out[n] = acc;
 }
 
+// tuning hook: BG_GEMM_XCD=0 keeps the hardware's round-robin tile order
+int xcd_mode() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char* e = getenv("BG_GEMM_XCD");
+        cached = e ? (atoi(e) != 0) : 1;
+    }
+    return cached;
+}
+
 template <int BM, int BN, bool SPLIT>
-int launch_gemm(int transA, int transB, bool vec, const GemmArgs& g, int splits, hipStream_t s, int64_t n_tiles = 0) {
-    dim3 grid((unsigned)(n_tiles > 0 ? n_tiles : (g.N + BN - 1) / BN), (unsigned)((g.M + BM - 1) / BM), (unsigned)splits);
+int launch_gemm(int transA, int transB, bool vec, GemmArgs g, int splits, hipStream_t s, int64_t n_tiles = 0) {
+    g.gx = (int)(n_tiles > 0 ? n_tiles : (g.N + BN - 1) / BN);
+    g.gy = (int)((g.M + BM - 1) / BM);
+    g.xcd = xcd_mode();
+    const int64_t blocks = (int64_t)g.gx * g.gy * splits;
+    if (blocks > 0x7fffffff) return BG_ERR_ARG;
+    dim3 grid((unsigned)blocks);
     const bool akc = !transA, bkc = transB != 0;
 #define BG_GEMM_CASE(AKC, BKC, VEC)                                                     \
     if (akc == AKC && bkc == BKC && vec == VEC) {                                       \

@@ -27,6 +27,7 @@ from .plan import LinOp, build_plan
 NUMBER_OF_CLASS = 6  # /root/reference/Data/GraphConstructor.py:9
 COMPOSE_BLOCKS = True  # collapse messageMLP into updateMLP where legal (VoxelBlock.compose)
 COMPOSE_STACK = True   # run the discriminator's 12 composed layers as one autograd node (ops.AffineStack)
+COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
 
 
 def position_encoder(d_model: int, max_len: int = 20) -> torch.Tensor:
@@ -269,9 +270,70 @@ class VoxelGNN_D(nn.Module):
         self.label_enc = MLP([input_label_dim, hidden_dim])
         self.block = VoxelBlock(2 * hidden_dim, if_agg_story_in_update=False)
 
+    # ---- collapsed evaluation ---------------------------------------------------------------------
+    # Neither messageMLP nor updateMLP of the discriminator's block has an activation (reference
+    # models.py:149-150 with if_agg_story_in_update=False), the encoders are single Linears
+    # (models.py:211-212) and the 12 layers share one block (models.py:213,227-228).  On graphs where
+    # every voxel has an in-edge the whole GNN is therefore the affine map
+    #     v_L = sum_k A^k U T_k ,   U = [feature | onehot(level) | mean dpos | 1 | label]  (N x ~40)
+    # with A the mean-aggregation operator and T_k (~40 x 2H) polynomial coefficients obtained from the
+    # parameters by the recurrence T^{m+1}_k = T^m_k (I + Wa^T) + T^m_{k-1} Wb^T + [k=0] E.
+    # One pass costs L thin gather-means (8 label columns; the label-free columns are shared by every
+    # pass of an iteration) and ONE [N, (L+1)*40] x [.., 2H] GEMM instead of L GEMMs of K = 4H+4.
+    def _static_powers(self, plan, feat, pdm4):
+        """[N, (L+1)*ds]: A^k [feature | onehot(level) | mean dpos | 1 | 0..] for k = 0..L (label-free
+        columns; no gradient).  Kept on the plan until Trainer / the caller starts the next iteration."""
+        key = ("d_static_powers", self.layer_num, self.pe.shape[0])
+        Z = plan.ops.get(key)
+        if Z is None:
+            ML = self.pe.shape[0]
+            onehot = ops.spmm_raw(_level_op(plan, ML), torch.eye(ML, device=feat.device))
+            cols = [feat.detach().float(), onehot, pdm4, torch.ones(feat.shape[0], 1, device=feat.device)]
+            width = sum(c.shape[1] for c in cols)
+            ds = (width + 3) // 4 * 4
+            Z = torch.zeros(feat.shape[0], (self.layer_num + 1) * ds, device=feat.device)
+            Z[:, :width] = torch.cat(cols, dim=1)
+            for k in range(1, self.layer_num + 1):
+                ops.spmm_raw(plan.vox_mean, Z[:, (k - 1) * ds:k * ds], out=Z[:, k * ds:(k + 1) * ds])
+            plan.ops[key] = Z
+        return Z
+
+    def _collapsed_weight(self, composed, n_feat, ds, dl):
+        """W [2H, (L+1)*ds + (L+1)*dl] such that v_L = [Zs | Zl] W^T (columns ordered (k, input column))."""
+        Wc, bc = composed[0], composed[1]
+        H2 = Wc.shape[0]
+        H, ML, L, du = H2 // 2, self.pe.shape[0], self.layer_num, ds + dl
+        fe, le = self.feature_enc[0], self.label_enc[0]
+        z = lambda r, c: Wc.new_zeros(r, c)
+        pad_s = ds - (n_feat + ML + 4 + 1)
+        top = torch.cat([fe.weight, self.pe.t(), z(H, 4), fe.bias.view(-1, 1), z(H, pad_s + dl)], dim=1)
+        bot = torch.cat([z(H, n_feat + ML + 4), le.bias.view(-1, 1), z(H, pad_s), le.weight,
+                         z(H, dl - le.weight.shape[1])], dim=1)
+        T = torch.cat([top, bot], dim=0)                                           # T^0_0 transposed: [2H, du]
+        E = torch.cat([z(H2, n_feat + ML), Wc[:, 2 * H2:2 * H2 + 4], bc.view(-1, 1), z(H2, pad_s + dl)], dim=1)
+        Wpq = torch.cat([Wc[:, :H2] + torch.eye(H2, device=Wc.device), Wc[:, H2:2 * H2]], dim=0)   # [P^T; Q^T]
+        for _ in range(L):
+            X = ops.MatMul.apply(Wpq, T, False, False)                             # [2*2H, w]
+            T = F.pad(X[:H2], (0, du)) + F.pad(X[H2:], (du, 0)) + F.pad(E, (0, T.shape[1]))
+        T3 = T.view(H2, L + 1, du)
+        return torch.cat([T3[:, :, :ds].reshape(H2, -1), T3[:, :, ds:].reshape(H2, -1)], dim=1)
+
+    def forward_collapsed(self, feat, l, plan, pdm4, composed):
+        L = self.layer_num
+        Zs = self._static_powers(plan, feat, pdm4)
+        ds = Zs.shape[1] // (L + 1)
+        dl = (l.shape[1] + 3) // 4 * 4
+        W = self._collapsed_weight(composed, feat.shape[1], ds, dl)
+        zl = [F.pad(l, (0, dl - l.shape[1]))]
+        for _ in range(L):
+            zl.append(SpMM.apply(zl[-1], plan.vox_mean))
+        return linear([Zs, torch.cat(zl, dim=1)], W)
+
     def forward(self, v, l, plan):
         pos, v = extract_pos(v)
         pdm4 = _pos_terms(plan, pos)
+        if COLLAPSE_D and COMPOSE_BLOCKS and plan.vox_all_has and self.layer_num > 0:
+            return self.forward_collapsed(v, l, plan, pdm4, self.block.compose())
         v = run_mlp(self.feature_enc, v)
         v = v + ops.spmm_raw(_level_op(plan, self.pe.shape[0]), self.pe)
         v = torch.cat([v, run_mlp(self.label_enc, l)], dim=-1)

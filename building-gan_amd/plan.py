@@ -143,6 +143,13 @@ class GraphPlan:
             return ops[name]
         raise AttributeError(name)
 
+    def begin_iteration(self):
+        """Drop the data-derived tensors that the networks keep on the plan for the passes of ONE
+        iteration (mean position differences, the discriminator's label-free operator powers), so
+        that every training iteration recomputes them as it would for a fresh batch."""
+        for k in [k for k in self.ops if k == "pdm4" or (isinstance(k, tuple) and k[0] == "d_static_powers")]:
+            del self.ops[k]
+
 
 def _max_plus_one(t: torch.Tensor) -> int:
     return int(t.max().item()) + 1 if t.numel() else 0

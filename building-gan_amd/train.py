@@ -143,6 +143,9 @@ class Trainer:
         dev = self.device
         Bg, Sg, Nvg = counts
         stats = {}
+        plan = batch.__dict__.get("_bg_plan") if hasattr(batch, "__dict__") else None
+        if plan is not None:
+            plan.begin_iteration()
         for p in self.opt_d.params:
             p.requires_grad = True
         self.opt_d.zero_grad()

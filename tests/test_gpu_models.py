@@ -253,3 +253,37 @@ def test_stack_node_equals_per_layer_nodes(cuda):
     for (n, _), a, c in zip(Dh.named_parameters(), res[True][3], res[False][3]):
         scale = float(c.abs().max()) + 1e-6
         assert float((a - c).abs().max()) <= 1e-3 * scale, n
+
+
+def test_collapsed_discriminator_accuracy_against_fp64(cuda):
+    """The polynomial (collapsed) evaluation of the linear discriminator GNN and the layer-by-layer
+    stack are two fp32 roundings of the same function: measure both against the oracle run in
+    float64 on dataset-sized graphs and require the collapsed one to be within the fp32 tolerance."""
+    from building_gan_amd import models as hm
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("dataset", 31, True, cuda)
+    D64 = copy.deepcopy(Do).double()
+    cpu64 = copy.deepcopy(cpu)
+    cpu64.voxel_feature = cpu64.voxel_feature.double()
+    lab64 = cpu.voxel_label.double().requires_grad_(True)
+    b64, s64 = D64(cpu64, lab64)
+    (b64.sum() + 2 * s64.sum()).backward()
+    ref = {n: p.grad for n, p in D64.named_parameters()}
+    errs = {}
+    try:
+        for name, flag in (("collapsed", True), ("stack", False)):
+            hm.COLLAPSE_D = flag
+            gpu.__dict__.pop("_bg_plan", None)
+            Dh.zero_grad()
+            lab = gpu.voxel_label.clone().requires_grad_(True)
+            bh, sh = Dh(gpu, lab)
+            (bh.sum() + 2 * sh.sum()).backward()
+            e_out = max(float((bh.cpu().double() - b64).abs().max() / b64.abs().max()),
+                        float((sh.cpu().double() - s64).abs().max() / s64.abs().max()))
+            e_lab = float((lab.grad.cpu().double() - lab64.grad).abs().max() / lab64.grad.abs().max())
+            e_par = max(float((p.grad.cpu().double() - ref[n]).abs().max() / (ref[n].abs().max() + 1e-12))
+                        for n, p in Dh.named_parameters())
+            errs[name] = (e_out, e_lab, e_par)
+    finally:
+        hm.COLLAPSE_D = True
+    print("relative errors vs float64 (outputs, label gradient, parameter gradients):", errs)
+    assert errs["collapsed"][0] <= 1e-4 and errs["collapsed"][1] <= 1e-3 and errs["collapsed"][2] <= 2e-3
