@@ -299,24 +299,27 @@ class VoxelGNN_D(nn.Module):
         return Z
 
     def _collapsed_weight(self, composed, n_feat, ds, dl):
-        """W [2H, (L+1)*ds + (L+1)*dl] such that v_L = [Zs | Zl] W^T (columns ordered (k, input column))."""
+        """W [(L+1)*ds + (L+1)*dl, 2H] such that v_L = [Zs | Zl] W (rows ordered (k, input column))."""
         Wc, bc = composed[0], composed[1]
         H2 = Wc.shape[0]
         H, ML, L, du = H2 // 2, self.pe.shape[0], self.layer_num, ds + dl
         fe, le = self.feature_enc[0], self.label_enc[0]
         z = lambda r, c: Wc.new_zeros(r, c)
         pad_s = ds - (n_feat + ML + 4 + 1)
-        top = torch.cat([fe.weight, self.pe.t(), z(H, 4), fe.bias.view(-1, 1), z(H, pad_s + dl)], dim=1)
-        bot = torch.cat([z(H, n_feat + ML + 4), le.bias.view(-1, 1), z(H, pad_s), le.weight,
-                         z(H, dl - le.weight.shape[1])], dim=1)
-        T = torch.cat([top, bot], dim=0)                                           # T^0_0 transposed: [2H, du]
-        E = torch.cat([z(H2, n_feat + ML), Wc[:, 2 * H2:2 * H2 + 4], bc.view(-1, 1), z(H2, pad_s + dl)], dim=1)
-        Wpq = torch.cat([Wc[:, :H2] + torch.eye(H2, device=Wc.device), Wc[:, H2:2 * H2]], dim=0)   # [P^T; Q^T]
-        for _ in range(L):
-            X = ops.MatMul.apply(Wpq, T, False, False)                             # [2*2H, w]
-            T = F.pad(X[:H2], (0, du)) + F.pad(X[H2:], (du, 0)) + F.pad(E, (0, T.shape[1]))
-        T3 = T.view(H2, L + 1, du)
-        return torch.cat([T3[:, :, :ds].reshape(H2, -1), T3[:, :, ds:].reshape(H2, -1)], dim=1)
+        n_lab = le.weight.shape[1]
+        # T^0_0 [du, 2H]: how the input columns enter v_0 = [feature_enc(f) + pe[level] | label_enc(l)]
+        X0 = torch.cat([
+            torch.cat([fe.weight.t(), z(n_feat, H)], dim=1),
+            torch.cat([self.pe, z(ML, H)], dim=1),
+            z(4, H2),
+            torch.cat([fe.bias, le.bias]).view(1, -1),
+            z(pad_s, H2),
+            torch.cat([z(n_lab, H), le.weight.t()], dim=1),
+            z(dl - n_lab, H2)], dim=0)
+        # E [du, 2H]: what every layer adds: mean-dpos columns through Wc's position block, the bias
+        E = torch.cat([z(n_feat + ML, H2), Wc[:, 2 * H2:2 * H2 + 4].t(), bc.view(1, -1), z(pad_s + dl, H2)], dim=0)
+        T3 = ops.PolyCoef.apply(Wc, X0, E, L).view(L + 1, du, H2)
+        return torch.cat([T3[:, :ds].reshape(-1, H2), T3[:, ds:].reshape(-1, H2)], dim=0)
 
     def forward_collapsed(self, feat, l, plan, pdm4, composed):
         L = self.layer_num
@@ -327,7 +330,7 @@ class VoxelGNN_D(nn.Module):
         zl = [F.pad(l, (0, dl - l.shape[1]))]
         for _ in range(L):
             zl.append(SpMM.apply(zl[-1], plan.vox_mean))
-        return linear([Zs, torch.cat(zl, dim=1)], W)
+        return linear([Zs, torch.cat(zl, dim=1)], W, w_t=True)
 
     def forward(self, v, l, plan):
         pos, v = extract_pos(v)

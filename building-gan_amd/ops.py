@@ -356,7 +356,11 @@ class LinearCat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, W, b, act, slope, row_scale, residual, pre_add, *xs):
         fuse_res = residual if act != ACT_LEAKY else None
-        y = gemm_raw(list(xs), W, False, True, bias=b, row_scale=row_scale, act=act, slope=slope,
+        w_t = isinstance(act, tuple)            # (act, "t"): W is stored [K, out] instead of [out, K]
+        if w_t:
+            act = act[0]
+        ctx.w_t = w_t
+        y = gemm_raw(list(xs), W, False, not w_t, bias=b, row_scale=row_scale, act=act, slope=slope,
                      residual=fuse_res, pre_add=pre_add)
         ctx.act, ctx.slope = act, slope
         ctx.inputs_only = _INPUT_GRADS_ONLY
@@ -380,11 +384,13 @@ class LinearCat(torch.autograd.Function):
         gW = gb = None
         if ctx.needs_input_grad[0] and not ctx.inputs_only:
             gW = CatTN.apply(g, *xs)
+            if ctx.w_t:
+                gW = gW.t()
         if ctx.needs_input_grad[1] and not ctx.inputs_only:
             gb = ColSum.apply(g)
         gxs: List[Optional[torch.Tensor]] = [None] * len(xs)
         if any(ctx.needs_input_grad[7:]):
-            gx = MatMul.apply(g, W, False, False)
+            gx = MatMul.apply(g, W, False, ctx.w_t)
             off = 0
             for i, wdt in enumerate(ctx.widths):
                 if ctx.needs_input_grad[7 + i]:
@@ -393,10 +399,11 @@ class LinearCat(torch.autograd.Function):
         return (gW, gb, None, None, None, g_res, g_pre, *gxs)
 
 
-def linear(xs, W, b=None, act=ACT_NONE, slope=0.01, row_scale=None, residual=None, pre_add=None):
+def linear(xs, W, b=None, act=ACT_NONE, slope=0.01, row_scale=None, residual=None, pre_add=None, w_t=False):
+    """``w_t``: W is given as [K, out] (y = cat(xs) @ W) instead of the nn.Linear layout [out, K]."""
     if torch.is_tensor(xs):
         xs = [xs]
-    return LinearCat.apply(W, b, act, slope, row_scale, residual, pre_add, *xs)
+    return LinearCat.apply(W, b, (act, "t") if w_t else act, slope, row_scale, residual, pre_add, *xs)
 
 
 class SegMax(torch.autograd.Function):
@@ -637,3 +644,65 @@ class AffineStackT(torch.autograd.Function):
             gW2 = gemm_tn_raw(Gs.view(L * N, H), [Us[:L].reshape(L * N, H), AUs.view(L * N, H)])
             gW = torch.nn.functional.pad(gW2, (0, Wc.shape[1] - 2 * H))
         return (Us[L] if ctx.needs_input_grad[0] else None), gW, None, None
+
+
+class PolyCoef(torch.autograd.Function):
+    """Coefficients of the collapsed discriminator GNN (models.VoxelGNN_D.forward_collapsed).
+
+    State X^m [(L+1)*du, H]: row block k holds T^m_k (du x H), the map from the du input columns to
+    the hidden state through k applications of the aggregation operator.  One layer is
+        X^{m+1} = X^m + [X^m | shift_du(X^m)] Wc[:, :2H]^T + [E; 0; ..]       (shift = one block down)
+    i.e. ONE two-segment GEMM whose second A segment is the first at a row offset (the buffers carry
+    du zero rows above block 0).  Returns X^L.  The backward runs the transposed recurrence and
+    gets dWc[:, :2H] of all L layers from a single split-K GEMM over the stacked slabs.
+    """
+
+    @staticmethod
+    def forward(ctx, Wc, X0, E, L: int):
+        du, H = X0.shape
+        N = (L + 1) * du
+        S = N + du                                    # slab = du zero rows + the state
+        dev = X0.device
+        Xall = torch.zeros(L + 1, S, H, dtype=torch.float32, device=dev)
+        Xall[0, du:2 * du].copy_(X0)
+        Efull = torch.zeros(N, H, dtype=torch.float32, device=dev)
+        Efull[:du].copy_(E)
+        W2 = Wc[:, :2 * H]
+        for m in range(L):
+            rows = min(N, (m + 2) * du)               # blocks above m+1 are still zero
+            cur = Xall[m]
+            gemm_raw([cur[du:du + rows], cur[:rows]], W2, False, True, residual=cur[du:du + rows],
+                     pre_add=Efull[:rows], out=Xall[m + 1, du:du + rows])
+        ctx.L, ctx.du = L, du
+        ctx.save_for_backward(Xall, Wc)
+        return Xall[L, du:]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        Xall, Wc = ctx.saved_tensors
+        L, du = ctx.L, ctx.du
+        H = g.shape[1]
+        N = (L + 1) * du
+        S = N + du
+        dev = g.device
+        # G^m at rows [0, N) of slab m, du zero rows below it (the shift-up view reads them)
+        Gall = torch.zeros(L + 1, S, H, dtype=torch.float32, device=dev)
+        Gall[L, :N].copy_(g)
+        Wab = torch.cat([Wc[:, :H], Wc[:, H:2 * H]], dim=0)          # [2H, H]: G Wa + shiftup(G) Wb
+        for m in range(L - 1, -1, -1):
+            nxt = Gall[m + 1]
+            gemm_raw([nxt[:N], nxt[du:du + N]], Wab, False, False, residual=nxt[:N], out=Gall[m, :N])
+        gW = gX0 = gE = None
+        if ctx.needs_input_grad[0]:
+            # dWc[:, :2H] = sum_m G^{m+1 T} [X^m | shift(X^m)]: slabs share one pitch, so the sum over
+            # layers is one long reduction (pad rows of G are zero, whatever X rows they meet)
+            Gf = Gall[1:L + 1].reshape(L * S, H)
+            Xf = Xall.view((L + 1) * S, H)
+            gW2 = gemm_tn_raw(Gf, [Xf[du:du + L * S], Xf[:L * S]])
+            gW = torch.nn.functional.pad(gW2, (0, Wc.shape[1] - 2 * H))
+        if ctx.needs_input_grad[1]:
+            gX0 = Gall[0, :du].clone()
+        if ctx.needs_input_grad[2]:
+            gE = Gall[1:L + 1, :du].sum(dim=0)
+        return gW, gX0, gE, None
