@@ -125,7 +125,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of hipGraph replay")
-    ap.add_argument("--no-concurrent", action="store_true", help="capture the D passes on one stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,7 +158,7 @@ def main():
     if args.no_graph:
         step_fn = lambda it: trainer.train_iteration(batch, it)
     else:
-        trainer.capture(batch, concurrent=not args.no_concurrent)
+        trainer.capture(batch)
         step_fn = trainer.train_iteration_graphed
     i = 0
     for _ in range(args.warmup):

@@ -16,9 +16,8 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BG_MAX_DEVICES = 64;
 
-constexpr int BK = 32;
-constexpr int KC_PITCH = BK + 4;
 
 struct GemmArgs {
     const float* A[4]; int64_t lda[4]; int64_t Ks[4]; int n_seg;
@@ -28,7 +27,7 @@ struct GemmArgs {
     const float* residual; int64_t ldr;
     const float* pre_add; int64_t ldp;
     int64_t M, N;
-    int total_steps;      // sum over segments of ceil(K_s / 32)
+    int total_steps;      // sum over segments of ceil(K_s / BK)
     int steps_per_split;  // == total_steps when not split
     float* partial;       // split-K: [splits, M, N]
     // split-K (TN) only: B may be given as column segments  B = [B_0 | B_1 | ..]  (fused cat of the inputs)
@@ -38,8 +37,9 @@ struct GemmArgs {
     int gx, gy, xcd;
 };
 
-template <int ROWS, bool KC, bool VEC>
+template <int ROWS, bool KC, bool VEC, int BK>
 struct Stage {
+    static constexpr int KC_PITCH = BK + 4;
     static constexpr int NF4 = ROWS * BK / 4 / 256;   // float4 per thread per tile
     float4 r[NF4];
 
@@ -102,7 +102,7 @@ struct Stage {
 // A segment and advanced by a constant per K step, so the steady-state loop issues bare
 // global_load_dwordx4 (no 64-bit index arithmetic, no exec-masked branches).  Rows / columns past
 // the matrix edge are clamped to a valid row: they only feed accumulators that are never stored.
-template <int ROWS, bool KC>
+template <int ROWS, bool KC, int BK>
 struct FastLoader {
     static constexpr int NF4 = ROWS * BK / 4 / 256;
     const float* p[NF4];
@@ -149,8 +149,9 @@ struct FastLoader {
 };
 
 // fragment of one 32-row tile for the 8-deep k group g: 4 values, value j feeds MFMA step j
-template <int ROWS, bool KC>
+template <int ROWS, bool KC, int BK>
 __device__ __forceinline__ float4 read_frag(const float* lds, int tile_row0, int g, int r, int h) {
+    constexpr int KC_PITCH = BK + 4;
     if (KC) {
         return bg_ld4(lds + (tile_row0 + r) * KC_PITCH + 8 * g + 4 * h);
     } else {
@@ -159,12 +160,13 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int tile_row0, int
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, bool VEC, bool SPLIT>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool VEC, bool SPLIT>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+    constexpr int KC_PITCH = BK + 4;
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_SZ = BM * KC_PITCH, B_SZ = BN * KC_PITCH;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+    extern __shared__ __attribute__((aligned(16))) float smem[];    // 2 * (A_SZ + B_SZ) floats
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -204,10 +206,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    Stage<BM, A_KC, VEC> sa;
-    Stage<BN, B_KC, VEC> sb;
-    FastLoader<BM, A_KC> fa;
-    FastLoader<BN, B_KC> fb;
+    Stage<BM, A_KC, VEC, BK> sa;
+    Stage<BN, B_KC, VEC, BK> sb;
+    FastLoader<BM, A_KC, BK> fa;
+    FastLoader<BN, B_KC, BK> fb;
     int it_seg = 0; int64_t it_k0 = (int64_t)step_begin * BK, it_koff = 0;   // position of the NEXT tile to fetch
     if (VEC && step_begin < step_end) {
         fa.init(g.A[0], g.lda[0], m0, g.M, it_k0);
@@ -263,9 +265,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         for (int kg = 0; kg < BK / 8; ++kg) {
             float4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, A_KC>(As, (wm * TM + i) * 32, kg, r, h);
+            for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, A_KC, BK>(As, (wm * TM + i) * 32, kg, r, h);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32, kg, r, h);
+            for (int j = 0; j < TN; ++j) bf[j] = read_frag<BN, B_KC, BK>(Bs, (wn * TN + j) * 32, kg, r, h);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -388,7 +390,7 @@ int xcd_mode() {
     return cached;
 }
 
-template <int BM, int BN, bool SPLIT>
+template <int BM, int BN, int BK, bool SPLIT>
 int launch_gemm(int transA, int transB, bool vec, GemmArgs g, int splits, hipStream_t s, int64_t n_tiles = 0) {
     g.gx = (int)(n_tiles > 0 ? n_tiles : (g.N + BN - 1) / BN);
     g.gy = (int)((g.M + BM - 1) / BM);
@@ -396,12 +398,25 @@ int launch_gemm(int transA, int transB, bool vec, GemmArgs g, int splits, hipStr
     const int64_t blocks = (int64_t)g.gx * g.gy * splits;
     if (blocks > 0x7fffffff) return BG_ERR_ARG;
     dim3 grid((unsigned)blocks);
+    constexpr size_t lds_bytes = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
     const bool akc = !transA, bkc = transB != 0;
-#define BG_GEMM_CASE(AKC, BKC, VEC)                                                     \
-    if (akc == AKC && bkc == BKC && vec == VEC) {                                       \
-        k_gemm<BM, BN, AKC, BKC, VEC, SPLIT><<<grid, 256, 0, s>>>(g);                   \
-        BG_LAUNCH_CHECK();                                                              \
-        return BG_OK;                                                                   \
+#define BG_GEMM_CASE(AKC, BKC, VEC)                                                                  \
+    if (akc == AKC && bkc == BKC && vec == VEC) {                                                    \
+        auto kern = k_gemm<BM, BN, BK, AKC, BKC, VEC, SPLIT>;                                        \
+        if (lds_bytes > 65536) {   /* above the static limit: opt in once per device */              \
+            static bool raised[BG_MAX_DEVICES] = {};                                                 \
+            int dev = 0;                                                                             \
+            BG_HIP(hipGetDevice(&dev));                                                        \
+            if (dev < 0 || dev >= BG_MAX_DEVICES) return BG_ERR_ARG;                                 \
+            if (!raised[dev]) {                                                                      \
+                BG_HIP(hipFuncSetAttribute((const void*)kern,                                  \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+                raised[dev] = true;                                                                  \
+            }                                                                                        \
+        }                                                                                            \
+        kern<<<grid, 256, lds_bytes, s>>>(g);                                                        \
+        BG_LAUNCH_CHECK();                                                                           \
+        return BG_OK;                                                                                \
     }
     BG_GEMM_CASE(true, true, true)
     BG_GEMM_CASE(true, false, true)
@@ -431,6 +446,17 @@ int tile_override() {
     return cached;
 }
 
+// tuning hook: BG_GEMM_BK = 32 / 64 forces the K depth of a 64x64-tile step (unset: 64)
+int bk_override() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char* e = getenv("BG_GEMM_BK");
+        cached = e ? atoi(e) : 0;
+        if (cached != 32 && cached != 64) cached = 0;
+    }
+    return cached;
+}
+
 }  // namespace
 
 extern "C" {
@@ -446,6 +472,17 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
     GemmArgs g{};
     g.n_seg = n_seg;
     g.pre_add = pre_add; g.ldp = ldp;
+    int tile = tile_override();
+    if (tile == 0) {
+        const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
+        tile = big_tiles >= 512 ? 3 : 0;
+    } else {
+        tile -= 1;
+    }
+    // 64x64 tiles run 1-3 workgroups per CU, so a K step is bounded by the latency of its global
+    // loads: 64-deep steps halve the number of load -> LDS -> barrier round trips
+    int bk = tile == 0 ? 64 : 32;
+    if (tile == 0 && bk_override()) bk = bk_override();
     int64_t Ktot = 0;
     bool vec = true;
     int steps = 0;
@@ -457,7 +494,7 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
         // a segment's rows of B start at koff: keep them 16-byte aligned for the vector path
         if (transB && (Ktot % 4 != 0)) vec = false;
         Ktot += Ks[s];
-        steps += (int)((Ks[s] + BK - 1) / BK);
+        steps += (int)((Ks[s] + bk - 1) / bk);
     }
     if (ldb < (transB ? Ktot : N)) return BG_ERR_ARG;
     vec = vec && operand_vec_ok(B, ldb, transB != 0, 4, N);
@@ -467,18 +504,13 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
     g.residual = residual; g.ldr = ldr; g.M = M; g.N = N;
     g.total_steps = steps; g.steps_per_split = steps; g.partial = nullptr;
     hipStream_t st = (hipStream_t)stream;
-    int tile = tile_override();
-    if (tile == 0) {
-        const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
-        tile = big_tiles >= 512 ? 3 : 0;
-    } else {
-        tile -= 1;
-    }
     switch (tile) {
-        case 3: return launch_gemm<128, 128, false>(transA, transB, vec, g, 1, st);
-        case 2: return launch_gemm<64, 128, false>(transA, transB, vec, g, 1, st);
-        case 1: return launch_gemm<128, 64, false>(transA, transB, vec, g, 1, st);
-        default: return launch_gemm<64, 64, false>(transA, transB, vec, g, 1, st);
+        case 3: return launch_gemm<128, 128, 32, false>(transA, transB, vec, g, 1, st);
+        case 2: return launch_gemm<64, 128, 32, false>(transA, transB, vec, g, 1, st);
+        case 1: return launch_gemm<128, 64, 32, false>(transA, transB, vec, g, 1, st);
+        default:
+            if (bk == 64) return launch_gemm<64, 64, 64, false>(transA, transB, vec, g, 1, st);
+            return launch_gemm<64, 64, 32, false>(transA, transB, vec, g, 1, st);
     }
 }
 
@@ -504,12 +536,13 @@ int bg_gemm_tn_splitk_f32(int64_t M, int64_t R, const float* A, int64_t lda,
         n_tiles += (Ns[s] + 63) / 64;
         if (Ns[s] > 0) vec = vec && operand_vec_ok(B[s], ldb[s], false, R, Ns[s]);
     }
+    constexpr int BK = 32;
     g.total_steps = (int)((R + BK - 1) / BK);
     g.steps_per_split = (g.total_steps + splits - 1) / splits;
     if (g.steps_per_split < 1) g.steps_per_split = 1;
     g.partial = partial;
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_gemm<64, 64, true>(1, 0, vec, g, splits, st, n_tiles);
+    int rc = launch_gemm<64, 64, 32, true>(1, 0, vec, g, splits, st, n_tiles);
     if (rc != BG_OK) return rc;
     if ((M * N) % 4 == 0 && bg_aligned16(partial))
         k_splitk_reduce<<<bg_grid_for((M * N) / 4, 256, 0x7fffffff), 256, 0, st>>>(partial, splits, M, N, C, ldc);

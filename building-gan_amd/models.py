@@ -13,6 +13,7 @@ Attention call) so that runs are reproducible against the CPU oracle.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Optional, Sequence
 
@@ -269,6 +270,8 @@ class VoxelGNN_D(nn.Module):
         self.feature_enc = MLP([input_feature_dim - 3, hidden_dim])
         self.label_enc = MLP([input_label_dim, hidden_dim])
         self.block = VoxelBlock(2 * hidden_dim, if_agg_story_in_update=False)
+        self._share_coef = False      # see DiscriminatorVoxel.shared_coefficients
+        self._coef_cache = None
 
     # ---- collapsed evaluation ---------------------------------------------------------------------
     # Neither messageMLP nor updateMLP of the discriminator's block has an activation (reference
@@ -321,12 +324,18 @@ class VoxelGNN_D(nn.Module):
         T3 = ops.PolyCoef.apply(Wc, X0, E, L).view(L + 1, du, H2)
         return torch.cat([T3[:, :ds].reshape(-1, H2), T3[:, ds:].reshape(-1, H2)], dim=0)
 
-    def forward_collapsed(self, feat, l, plan, pdm4, composed):
+    def forward_collapsed(self, feat, l, plan, pdm4):
         L = self.layer_num
         Zs = self._static_powers(plan, feat, pdm4)
         ds = Zs.shape[1] // (L + 1)
         dl = (l.shape[1] + 3) // 4 * 4
-        W = self._collapsed_weight(composed, feat.shape[1], ds, dl)
+        key = (ds, dl, torch.is_grad_enabled())
+        if self._share_coef and self._coef_cache is not None and self._coef_cache[0] == key:
+            W = self._coef_cache[1]
+        else:
+            W = self._collapsed_weight(self.block.compose(), feat.shape[1], ds, dl)
+            if self._share_coef:
+                self._coef_cache = (key, W)
         zl = [F.pad(l, (0, dl - l.shape[1]))]
         for _ in range(L):
             zl.append(SpMM.apply(zl[-1], plan.vox_mean))
@@ -336,7 +345,7 @@ class VoxelGNN_D(nn.Module):
         pos, v = extract_pos(v)
         pdm4 = _pos_terms(plan, pos)
         if COLLAPSE_D and COMPOSE_BLOCKS and plan.vox_all_has and self.layer_num > 0:
-            return self.forward_collapsed(v, l, plan, pdm4, self.block.compose())
+            return self.forward_collapsed(v, l, plan, pdm4)
         v = run_mlp(self.feature_enc, v)
         v = v + ops.spmm_raw(_level_op(plan, self.pe.shape[0]), self.pe)
         v = torch.cat([v, run_mlp(self.label_enc, l)], dim=-1)
@@ -382,6 +391,19 @@ class DiscriminatorVoxel(nn.Module):
         # activations only through arg-max choices, so a gradient penalty reaches the parameters
         # through the double-backward graph alone (see ops.input_grads_only)
         self.piecewise_linear = not any(k in act for k in ("relu", "tanh", "sigmoid"))
+
+    @contextlib.contextmanager
+    def shared_coefficients(self):
+        """The caller promises not to change the parameters inside this context (the passes of one
+        discriminator update: fake, real, gradient-penalty sample): the collapsed GNN's coefficient
+        table -- a function of the parameters alone -- is then built once and shared by the passes,
+        and its backward runs once on the summed gradient."""
+        gnn = self.voxelGNN_D
+        gnn._share_coef, gnn._coef_cache = True, None
+        try:
+            yield self
+        finally:
+            gnn._share_coef, gnn._coef_cache = False, None
 
     def forward(self, graph, out_label):
         plan = build_plan(graph)

@@ -14,6 +14,7 @@ graph launches, so the same structure runs on 1..8 GPUs.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional, Sequence
 
 import torch
@@ -111,7 +112,6 @@ class Trainer:
         self.g_loss_fn = VolumetricDesignLoss_G(gan_loss=gan_loss)
         self.group = group
         self._graphs = None
-        self._side_streams = None     # set by capture(concurrent=True)
 
     def broadcast_parameters(self, src: int = 0):
         if _world(self.group) > 1:
@@ -156,28 +156,14 @@ class Trainer:
         gen = G(batch, program_z, voxel_z, noise)
         out, soft_out = gen[0], gen[1]
         if do_d:
-            # The three discriminator passes (fake, real, gradient-penalty sample) are independent
-            # chains of medium-sized kernels; on separate HIP streams their ramp-up / tail phases
-            # overlap and the chip stays full (autograd replays each chain's backward on its stream).
-            side = self._side_streams
-            cur = torch.cuda.current_stream() if side is not None else None
-
-            def on(k, fn):
-                if side is None:
-                    return fn()
-                side[k].wait_stream(cur)
-                with torch.cuda.stream(side[k]):
-                    return fn()
-
-            fake_b, fake_s = on(0, lambda: D(detach_batch(batch), out.detach()))
-            gp = None
-            if self.gp_lambda != 0:
-                gp = on(1, lambda: self._gradient_penalty(detach_batch(batch), batch.voxel_label.detach(),
-                                                          soft_out.detach(), u, Nvg))
-            real_b, real_s = D(batch, batch.voxel_label)
-            if side is not None:
-                for s in side:
-                    cur.wait_stream(s)
+            share = D.shared_coefficients() if hasattr(D, "shared_coefficients") else contextlib.nullcontext()
+            with share:
+                fake_b, fake_s = D(detach_batch(batch), out.detach())
+                gp = None
+                if self.gp_lambda != 0:
+                    gp = self._gradient_penalty(detach_batch(batch), batch.voxel_label.detach(), soft_out.detach(),
+                                                u, Nvg)
+                real_b, real_s = D(batch, batch.voxel_label)
             d_loss = -real_b.sum() / Bg - real_s.sum() / Sg + fake_b.sum() / Bg + fake_s.sum() / Sg
             if gp is not None:
                 d_loss = d_loss + self.gp_lambda * gp
@@ -220,7 +206,7 @@ class Trainer:
         return stats
 
     # ------------------------------------------------------------------ hipGraph iteration
-    def capture(self, batch, warmup: int = 2, concurrent: bool = True):
+    def capture(self, batch, warmup: int = 2):
         """Capture the iteration for THIS batch (fixed shapes) into hipGraphs.
 
         Segments: A = phase D (G forward ... d_loss.backward); B = Adam(D) + phase G; C = Adam(G);
@@ -231,7 +217,6 @@ class Trainer:
             raise NotImplementedError("graph capture assumes n_critic_d == 1 (the reference default)")
         saved = (self.opt_g.state(), self.opt_d.state())
         counts = global_counts(batch, self.group)
-        self._side_streams = [torch.cuda.Stream(), torch.cuda.Stream()] if concurrent else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -265,7 +250,6 @@ class Trainer:
         graphs["no_g"] = (gA2, gB2, statsA2)
         self._graphs = graphs
         self._keep = (gen, gen2)
-        self._side_streams = None      # eager iterations stay single-stream
         self.opt_g.restore(saved[0])
         self.opt_d.restore(saved[1])
         torch.cuda.synchronize()
