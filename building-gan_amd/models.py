@@ -341,6 +341,27 @@ class VoxelGNN_D(nn.Module):
             zl.append(SpMM.apply(zl[-1], plan.vox_mean))
         return linear([Zs, torch.cat(zl, dim=1)], W, w_t=True)
 
+    def collapsed_multi(self, feat, labels, plan, pdm4):
+        """v_L of several label sets that share the graph (the passes of one critic update), labels
+        taken as data (no gradient reaches them through this call).  The label-free part S = Zs Ws is
+        evaluated once; each pass adds its own thin product.  Returns ([v_L per pass], Wl, dl) where
+        Wl [(L+1)*dl, 2H] maps label powers to the output (rows ordered (k, label column))."""
+        L, P, N = self.layer_num, len(labels), feat.shape[0]
+        Zs = self._static_powers(plan, feat, pdm4)
+        ds = Zs.shape[1] // (L + 1)
+        n_lab = labels[0].shape[1]
+        dl = (n_lab + 3) // 4 * 4
+        W = self._collapsed_weight(self.block.compose(), feat.shape[1], ds, dl)
+        Ws, Wl = W[:(L + 1) * ds], W[(L + 1) * ds:]
+        Zk = torch.zeros(N, L + 1, P * dl, device=feat.device)
+        for p, l in enumerate(labels):
+            Zk[:, 0, p * dl:p * dl + n_lab] = l.detach()
+        for k in range(L):
+            ops.spmm_raw(plan.vox_mean, Zk[:, k], out=Zk[:, k + 1])
+        Zp = Zk.view(N, L + 1, P, dl).permute(0, 2, 1, 3).contiguous().view(N, P, (L + 1) * dl)
+        S = linear([Zs], Ws, w_t=True)
+        return [linear([Zp[:, p]], Wl, pre_add=S, w_t=True) for p in range(P)], Wl, dl
+
     def forward(self, v, l, plan):
         pos, v = extract_pos(v)
         pdm4 = _pos_terms(plan, pos)
@@ -404,6 +425,50 @@ class DiscriminatorVoxel(nn.Module):
             yield self
         finally:
             gnn._share_coef, gnn._coef_cache = False, None
+
+    def critic_terms(self, graph, label_real, label_fake, label_hat=None):
+        """Every discriminator evaluation of one critic update (reference train.py:88-96) in one
+        pass over the collapsed GNN: D(real), D(fake) and, when ``label_hat`` is given, the gradients
+        of D(hat)'s two outputs with respect to ``label_hat`` (reference losses.py:83-84) -- obtained
+        in closed form, sum_k (A^T)^k G Wl_k^T with G the decoders' gradient scattered to the arg-max
+        voxels, as a differentiable function of the parameters -- instead of two autograd passes
+        over a third forward graph.  Labels are treated as data.
+
+        Returns None when the collapsed form does not apply to this graph (the caller then runs the
+        passes one by one), else (real_b, real_s, fake_b, fake_s, grad_b, grad_s)."""
+        plan = build_plan(graph)
+        gnn = self.voxelGNN_D
+        if not (COLLAPSE_D and COMPOSE_BLOCKS and plan.vox_all_has and gnn.layer_num > 0):
+            return None
+        pos, feat = extract_pos(graph.voxel_feature)
+        pdm4 = _pos_terms(plan, pos)
+        labels = [label_real, label_fake] + ([label_hat] if label_hat is not None else [])
+        vs, Wl, dl = gnn.collapsed_multi(feat, labels, plan, pdm4)
+        B, S, N = plan.B, plan.S, plan.Nv
+        # real and fake share one run of each decoder
+        pooled_s = torch.cat([ops.SegMax.apply(v, plan.story_seg)[0] for v in vs[:2]], dim=0)
+        pooled_b = torch.cat([ops.SegMax.apply(v, plan.graph_seg)[0] for v in vs[:2]], dim=0)
+        val_b, val_s = run_mlp(self.building_dec, pooled_b), run_mlp(self.story_dec, pooled_s)
+        out = [val_b[:B], val_s[:S], val_b[B:], val_s[S:]]
+        if label_hat is None:
+            return (*out, None, None)
+        n_lab, L = label_hat.shape[1], gnn.layer_num
+        with torch.no_grad():
+            hat_s, arg_s = ops.segmax_raw(plan.story_seg, vs[2])
+            hat_b, arg_b = ops.segmax_raw(plan.graph_seg, vs[2])
+        G = []
+        for dec, pooled, arg in ((self.building_dec, hat_b, arg_b), (self.story_dec, hat_s, arg_s)):
+            pooled = pooled.requires_grad_(True)
+            with ops.input_grads_only():
+                val = run_mlp(dec, pooled)
+            gpool = torch.autograd.grad(val, pooled, torch.ones_like(val), create_graph=True)[0]
+            G.append(ops.ScatterArg.apply(gpool, arg, N))
+        X = ops.MatMul.apply(torch.cat(G, dim=0), Wl, False, True)                 # [2N, (L+1)*dl]
+        Y = X.view(2, N, L + 1, dl).permute(1, 2, 0, 3).reshape(N, L + 1, 2 * dl)
+        acc = Y[:, L]
+        for k in range(L - 1, -1, -1):
+            acc = ops.SpMMAdd.apply(acc, Y[:, k], plan.vox_mean.T)
+        return (*out, acc[:, :n_lab], acc[:, dl:dl + n_lab])
 
     def forward(self, graph, out_label):
         plan = build_plan(graph)

@@ -251,6 +251,20 @@ class SpMM(torch.autograd.Function):
         return SpMM.apply(g, ctx.op.T), None
 
 
+class SpMMAdd(torch.autograd.Function):
+    """y = op(x) + a in one pass (short-row plans)."""
+
+    @staticmethod
+    def forward(ctx, x, a, op: LinOp):
+        ctx.op = op
+        return spmm_add_raw(op, x, a)
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = SpMM.apply(g, ctx.op.T) if ctx.needs_input_grad[0] else None
+        return gx, (g if ctx.needs_input_grad[1] else None), None
+
+
 class SpMMW(torch.autograd.Function):
     """y[i] = sum_e w[e] x[col(e)] with differentiable per-edge weights (original edge order)."""
 

@@ -36,17 +36,20 @@ class FlatAdam:
 
     def __init__(self, module: torch.nn.Module, lr=1e-4, betas=(0.5, 0.999), eps=1e-8):
         self.params = [p for p in module.parameters()]
-        n = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
+        # every parameter starts on a 256-byte boundary: the GEMM's 16-byte vector loads need aligned
+        # weights, and the pad (zero gradient, zero moments) stays zero under Adam
+        self.offsets, n = [], 0
         for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 63) // 64 * 64
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.view(-1))
             p.data = self.flat[off:off + k].view_as(p)
             p.grad = self.grad[off:off + k].view_as(p)
-            off += k
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -55,12 +58,9 @@ class FlatAdam:
 
     def zero_grad(self):
         self.grad.zero_()
-        off = 0
-        for p in self.params:                      # autograd may have replaced .grad; re-attach the views
-            k = p.numel()
+        for p, off in zip(self.params, self.offsets):   # autograd may have replaced .grad; re-attach the views
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
-                p.grad = self.grad[off:off + k].view_as(p)
-            off += k
+                p.grad = self.grad[off:off + p.numel()].view_as(p)
 
     def all_reduce(self, group=None):
         if _world(group) > 1:
@@ -119,13 +119,18 @@ class Trainer:
             dist.broadcast(self.opt_d.flat, src, group=self.group)
 
     # ------------------------------------------------------------------ pieces of one iteration
-    def _gradient_penalty(self, batch, label, out, u, Nv_g):
-        """reference losses.py:73-89 with the voxel mean taken over the global voxel count."""
+    @staticmethod
+    def _gp_sample(label, out, u):
+        """The sample at which the penalty is taken (reference losses.py:75-79)."""
         if u is None:
             u = torch.rand(label.shape[0], 1, device=out.device)
         mixed = (label * u + out * (1 - u)).detach().requires_grad_(True)
         nonzero = (mixed.max(dim=-1)[0] != 0).type(torch.float32).view(-1, 1)
-        sample = softmax_to_hard(mixed, -1) * nonzero
+        return softmax_to_hard(mixed, -1) * nonzero
+
+    def _gradient_penalty(self, batch, label, out, u, Nv_g):
+        """reference losses.py:73-89 with the voxel mean taken over the global voxel count."""
+        sample = self._gp_sample(label, out, u)
         if getattr(self.discriminator, "piecewise_linear", False):
             with ops.input_grads_only():
                 val_b, val_s = self.discriminator(batch, sample)
@@ -156,14 +161,23 @@ class Trainer:
         gen = G(batch, program_z, voxel_z, noise)
         out, soft_out = gen[0], gen[1]
         if do_d:
-            share = D.shared_coefficients() if hasattr(D, "shared_coefficients") else contextlib.nullcontext()
-            with share:
-                fake_b, fake_s = D(detach_batch(batch), out.detach())
-                gp = None
-                if self.gp_lambda != 0:
-                    gp = self._gradient_penalty(detach_batch(batch), batch.voxel_label.detach(), soft_out.detach(),
-                                                u, Nvg)
-                real_b, real_s = D(batch, batch.voxel_label)
+            gp = None
+            fused = None
+            if hasattr(D, "critic_terms") and (self.gp_lambda == 0 or getattr(D, "piecewise_linear", False)):
+                sample = self._gp_sample(batch.voxel_label.detach(), soft_out.detach(), u) if self.gp_lambda != 0 else None
+                fused = D.critic_terms(batch, batch.voxel_label, out.detach(), sample)
+            if fused is not None:
+                real_b, real_s, fake_b, fake_s, grad_b, grad_s = fused
+                if grad_b is not None:
+                    gp = (((grad_b.norm(2, 1) - 1) ** 2).sum() + ((grad_s.norm(2, 1) - 1) ** 2).sum()) / Nvg
+            else:
+                share = D.shared_coefficients() if hasattr(D, "shared_coefficients") else contextlib.nullcontext()
+                with share:
+                    fake_b, fake_s = D(detach_batch(batch), out.detach())
+                    if self.gp_lambda != 0:
+                        gp = self._gradient_penalty(detach_batch(batch), batch.voxel_label.detach(),
+                                                    soft_out.detach(), u, Nvg)
+                    real_b, real_s = D(batch, batch.voxel_label)
             d_loss = -real_b.sum() / Bg - real_s.sum() / Sg + fake_b.sum() / Bg + fake_s.sum() / Sg
             if gp is not None:
                 d_loss = d_loss + self.gp_lambda * gp

@@ -287,3 +287,37 @@ def test_collapsed_discriminator_accuracy_against_fp64(cuda):
         hm.COLLAPSE_D = True
     print("relative errors vs float64 (outputs, label gradient, parameter gradients):", errs)
     assert errs["collapsed"][0] <= 1e-4 and errs["collapsed"][1] <= 1e-3 and errs["collapsed"][2] <= 2e-3
+
+
+def test_fused_critic_terms_match_separate_passes_and_oracle_gradients(cuda):
+    """critic_terms (one pass for D(real), D(fake) and the closed-form penalty gradients) against the
+    oracle's three separate passes with torch.autograd.grad (reference losses.py:83-84)."""
+    from building_gan_amd.util import softmax_to_hard
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 21, True, cuda)
+    torch.manual_seed(21)
+    fake = torch.zeros(sz["Nv"], 6).scatter_(1, torch.randint(0, 6, (sz["Nv"], 1)), 1.0) * (torch.rand(sz["Nv"], 1) > 0.3)
+    u = torch.rand(sz["Nv"], 1)
+    mixed = cpu.voxel_label * u + fake * (1 - u)
+    sample = (softmax_to_hard(mixed, -1) * (mixed.max(-1)[0] != 0).float().view(-1, 1)).detach()
+    so = sample.clone().requires_grad_(True)
+    rb, rs = Do(cpu, cpu.voxel_label)
+    fb, fs = Do(cpu, fake)
+    hb, hs = Do(cpu, so)
+    gb = torch.autograd.grad(hb, so, torch.ones_like(hb), retain_graph=True, create_graph=True)[0]
+    gs = torch.autograd.grad(hs, so, torch.ones_like(hs), retain_graph=True, create_graph=True)[0]
+    res = Dh.critic_terms(gpu, gpu.voxel_label, fake.to(cuda), sample.to(cuda))
+    assert res is not None
+    for got, want in zip(res, (rb, rs, fb, fs, gb, gs)):
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=2e-5)
+    # the penalty's parameter gradients (double backward in the oracle, first order here)
+    pen_o = ((gb.norm(2, 1) - 1) ** 2).mean() + ((gs.norm(2, 1) - 1) ** 2).mean()
+    pen_h = ((res[4].norm(2, 1) - 1) ** 2).mean() + ((res[5].norm(2, 1) - 1) ** 2).mean()
+    torch.testing.assert_close(pen_h.cpu(), pen_o, rtol=1e-4, atol=1e-6)
+    pen_o.backward()
+    pen_h.backward()
+    for (n, po), (_, ph) in zip(Do.named_parameters(), Dh.named_parameters()):
+        if po.grad is None:
+            assert ph.grad is None or float(ph.grad.abs().max()) == 0.0, n
+            continue
+        scale = float(po.grad.abs().max()) + 1e-6
+        assert float((ph.grad.cpu() - po.grad).abs().max()) <= 5e-3 * scale, n
