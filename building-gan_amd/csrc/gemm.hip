@@ -160,6 +160,40 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int tile_row0, int
     }
 }
 
+// Epilogue of one 32x32 accumulator tile: lane holds column `col`, rows row0 + (q&3) + 8*(q>>2) (+4h folded
+// into row0).  All addend loads of the 16 rows are issued before the first use (rows past M are clamped for
+// the loads and skipped for the store), so the tile pays one memory round trip per addend, not sixteen.
+__device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc, int64_t row0, int64_t col, float bv) {
+    float rs[16], pa[16], rd[16];
+    int64_t rows[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int64_t row = row0 + (q & 3) + 8 * (q >> 2);
+        rows[q] = row < g.M ? row : g.M - 1;
+    }
+    if (g.row_scale) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rs[q] = g.row_scale[rows[q]];
+    }
+    if (g.pre_add) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pa[q] = g.pre_add[rows[q] * g.ldp + col];
+    }
+    if (g.residual) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rd[q] = g.residual[rows[q] * g.ldr + col];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        float v = acc[q] + bv;
+        if (g.row_scale) v *= rs[q];
+        if (g.pre_add) v += pa[q];
+        if (g.act == BG_ACT_LEAKY) v = v > 0.f ? v : v * g.slope;
+        if (g.residual) v += rd[q];
+        if (row0 + (q & 3) + 8 * (q >> 2) < g.M) g.C[rows[q] * g.ldc + col] = v;
+    }
+}
+
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool VEC, bool SPLIT>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     constexpr int KC_PITCH = BK + 4;
@@ -294,24 +328,146 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
             int64_t col = n0 + (wn * TN + j) * 32 + r;
             if (col >= n_lim) continue;
             col += col_base;
-            const float bv = (!SPLIT && g.bias) ? g.bias[col] : 0.f;
+            if (SPLIT) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int64_t row = m0 + (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (row >= g.M) continue;
-                float v = acc[i][j][q];
-                if (SPLIT) {
-                    g.partial[((int64_t)bz * g.M + row) * g.N + col] = v;
-                } else {
-                    v += bv;
-                    if (g.row_scale) v *= g.row_scale[row];
-                    if (g.pre_add) v += g.pre_add[row * g.ldp + col];
-                    if (g.act == BG_ACT_LEAKY) v = v > 0.f ? v : v * g.slope;
-                    if (g.residual) v += g.residual[row * g.ldr + col];
-                    g.C[row * g.ldc + col] = v;
+                for (int q = 0; q < 16; ++q) {
+                    const int64_t row = m0 + (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    if (row < g.M) g.partial[((int64_t)bz * g.M + row) * g.N + col] = acc[i][j][q];
                 }
+            } else {
+                store_tile(g, acc[i][j], m0 + (wm * TM + i) * 32 + 4 * h, col, g.bias ? g.bias[col] : 0.f);
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 64x64-tile GEMM for K-contiguous A (vector path): operand tiles go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, no staging registers) through a ring of STAGES buffers, so STAGES-1
+// K steps of loads are in flight while one is multiplied.  At the 1-3 workgroups per CU that the
+// train step's shapes give, a step is otherwise bounded by the latency of its own loads.
+//   * LDS images are lane-linear (an LDS-DMA writes base + 16*lane): [row][32] for a K-contiguous
+//     operand with the 16-byte chunk index XOR-ed by (row >> 1) & 7 on the SOURCE address and on
+//     the read (conflict-free ds_read_b128, two rows per 256-byte bank row); [k][64] for B[K,N].
+//   * one s_barrier per step; loads are counted by hand (vmcnt), the compiler never sees them.
+__device__ __attribute__((aligned(16))) float bg_zero_src[4] = {0.f, 0.f, 0.f, 0.f};   // never written
+
+__device__ __forceinline__ void glds16(const float* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int STAGES, bool B_KC>
+__global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs g) {
+    constexpr int BK = 32, TILE_F = 64 * BK, STAGE_F = 2 * TILE_F;
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // STAGES * STAGE_F floats
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    uint32_t lid = blockIdx.x;
+    if (g.xcd) {
+        const uint32_t q = gridDim.x >> 3, rem = gridDim.x & 7, x = lid & 7, slot = lid >> 3;
+        lid = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + slot;
+    }
+    const int bx = lid % g.gx, by = lid / g.gx;
+    const int64_t m0 = (int64_t)by * 64, n0 = (int64_t)bx * 64;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)smem;
+    const int n_steps = g.total_steps;
+
+    // this lane's part of the two A and two B DMA instructions its wave issues per stage
+    int a_row[2], a_k[2], b_k[2];
+    int64_t a_goff[2], b_goff[2];
+    uint32_t a_dst[2], b_dst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = wave * 2 + j;                       // 8 instructions cover a 64-row tile
+        const int row = q * 8 + (lane >> 3), cp = lane & 7;
+        a_row[j] = row;
+        a_k[j] = 4 * (cp ^ ((row >> 1) & 7));             // source chunk of LDS chunk cp
+        int64_t gr = m0 + row;
+        a_goff[j] = gr < g.M ? gr : g.M - 1;              // rows past the edge: any valid row, never stored
+        a_dst[j] = lds0 + 4u * (uint32_t)(q * 256);
+        if (B_KC) {
+            int64_t gn = n0 + row;
+            gn = gn < g.N ? gn : g.N - 1;
+            b_k[j] = a_k[j];
+            b_goff[j] = gn * g.ldb;
+        } else {
+            b_k[j] = q * 4 + (lane >> 4);                 // [k][64]: 4 k rows per instruction
+            int64_t gn = n0 + 4 * (lane & 15);
+            b_goff[j] = gn + 4 <= g.N ? gn : g.N - 4;
+        }
+        b_dst[j] = lds0 + 4u * (uint32_t)(TILE_F + q * 256);
+    }
+
+    int it_seg = 0; int64_t it_k0 = 0, it_koff = 0;       // position of the next step to fetch
+    auto issue = [&](int step) {
+        const uint32_t sofs = 4u * (uint32_t)((step % STAGES) * STAGE_F);
+        if (step < n_steps) {
+            const int64_t K = g.Ks[it_seg];
+            const float* Ab = g.A[it_seg];
+            const int64_t lda = g.lda[it_seg];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool in_a = it_k0 + a_k[j] < K;
+                glds16(in_a ? Ab + a_goff[j] * lda + it_k0 + a_k[j] : bg_zero_src, a_dst[j] + sofs);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool in_b = it_k0 + b_k[j] < K;
+                const float* src = B_KC ? g.B + b_goff[j] + it_koff + it_k0 + b_k[j]
+                                        : g.B + (it_koff + it_k0 + b_k[j]) * g.ldb + b_goff[j];
+                glds16(in_b ? src : bg_zero_src, b_dst[j] + sofs);
+            }
+            it_k0 += BK;
+            if (it_k0 >= K && it_seg + 1 < g.n_seg) { it_koff += K; ++it_seg; it_k0 = 0; }
+        } else {
+            // past the end: keep every wave's outstanding-load count uniform (target: a buffer nobody reads again)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { glds16(bg_zero_src, a_dst[j] + sofs); glds16(bg_zero_src, b_dst[j] + sofs); }
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) issue(s);
+
+    const int arow = wm * 32 + r, brow = wn * 32 + r;
+    const int aswz = (arow >> 1) & 7, bswz = (brow >> 1) & 7;
+    for (int step = 0; step < n_steps; ++step) {
+        // this wave's loads of `step` have landed when at most (STAGES-2) newer stages are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (STAGES - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();                     // .. and everyone's; buffer (step-1) is free
+        asm volatile("" ::: "memory");
+        issue(step + STAGES - 1);
+        const float* As = smem + (step % STAGES) * STAGE_F;
+        const float* Bs = As + TILE_F;
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            const int c = 2 * kg + h;
+            const float4 af = bg_ld4(As + arow * BK + 4 * (c ^ aswz));
+            float4 bf;
+            if (B_KC) {
+                bf = bg_ld4(Bs + brow * BK + 4 * (c ^ bswz));
+            } else {
+                const float* p = Bs + (8 * kg + 4 * h) * 64 + brow;
+                bf = make_float4(p[0], p[64], p[128], p[192]);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+        }
+    }
+    // no LDS-DMA may outlive the workgroup (its LDS is handed to the next one)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const int64_t col = n0 + wn * 32 + r;
+    if (col < g.N) store_tile(g, acc, m0 + wm * 32 + 4 * h, col, g.bias ? g.bias[col] : 0.f);
 }
 
 __global__ void k_splitk_reduce(const float* __restrict__ partial, int splits, int64_t M, int64_t N,
@@ -430,6 +586,32 @@ int launch_gemm(int transA, int transB, bool vec, GemmArgs g, int splits, hipStr
     return BG_ERR_ARG;
 }
 
+// tuning hook: BG_GEMM_DMA=0 keeps the register-staged kernel for every shape; 2..4 force a ring depth
+int dma_mode() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char* e = getenv("BG_GEMM_DMA");
+        cached = e ? atoi(e) : 1;                     // 1 = by shape (see bg_gemm_f32)
+        if (cached < 0 || cached > 4) cached = 1;
+    }
+    return cached;
+}
+
+template <int STAGES>
+int launch_gemm_dma(int transB, GemmArgs g, hipStream_t s) {
+    g.gx = (int)((g.N + 63) / 64);
+    g.gy = (int)((g.M + 63) / 64);
+    g.xcd = xcd_mode();
+    const int64_t blocks = (int64_t)g.gx * g.gy;
+    if (blocks > 0x7fffffff) return BG_ERR_ARG;
+    constexpr size_t lds_bytes = (size_t)STAGES * 2 * 64 * 32 * sizeof(float);
+    static_assert(lds_bytes <= 65536, "ring must fit the default dynamic LDS limit");
+    if (transB) k_gemm_dma<STAGES, true><<<dim3((unsigned)blocks), 256, lds_bytes, s>>>(g);
+    else k_gemm_dma<STAGES, false><<<dim3((unsigned)blocks), 256, lds_bytes, s>>>(g);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
 bool operand_vec_ok(const float* p, int64_t ld, bool kc, int64_t K, int64_t rows) {
     if (!bg_aligned16(p) || ld % 4 != 0) return false;
     return kc ? (K % 4 == 0) : (rows % 4 == 0);
@@ -483,6 +665,17 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
     // loads: 64-deep steps halve the number of load -> LDS -> barrier round trips
     int bk = tile == 0 ? 64 : 32;
     if (tile == 0 && bk_override()) bk = bk_override();
+    // LDS-DMA ring kernel: K-contiguous A on the vector path (decided below), 64x64 tiles
+    int dma = (tile == 0 && !transA && M >= 1 && N >= 4) ? dma_mode() : 0;
+    if (dma == 1) {
+        // measured on the train step's shapes (tools/gemm_shapes.py): with >= 2 workgroups per CU the
+        // register-free ring wins (33 vs 38 us at 720 tiles), below that the 64-deep register-staged
+        // steps do (15 vs 16.5 us at 360 tiles)
+        const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
+        dma = tiles >= 512 ? 2 : 0;
+    }
+    for (int s = 0; s < n_seg; ++s) if (Ks[s] <= 0) dma = 0;      // its step walk assumes non-empty segments
+    if (dma) bk = 32;
     int64_t Ktot = 0;
     bool vec = true;
     int steps = 0;
@@ -504,6 +697,19 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
     g.residual = residual; g.ldr = ldr; g.M = M; g.N = N;
     g.total_steps = steps; g.steps_per_split = steps; g.partial = nullptr;
     hipStream_t st = (hipStream_t)stream;
+    if (dma && vec) {
+        switch (dma) {
+            case 2: return launch_gemm_dma<2>(transB, g, st);
+            case 4: return launch_gemm_dma<4>(transB, g, st);
+            default: return launch_gemm_dma<3>(transB, g, st);
+        }
+    }
+    if (dma) {                     // scalar path keeps its own step depth
+        steps = 0;
+        bk = bk_override() ? bk_override() : 64;
+        for (int s = 0; s < n_seg; ++s) steps += (int)((Ks[s] + bk - 1) / bk);
+        g.total_steps = steps; g.steps_per_split = steps;
+    }
     switch (tile) {
         case 3: return launch_gemm<128, 128, 32, false>(transA, transB, vec, g, 1, st);
         case 2: return launch_gemm<64, 128, 32, false>(transA, transB, vec, g, 1, st);

@@ -95,6 +95,11 @@ def _pos_terms(plan, pos):
     return cached
 
 
+def position_terms(graph):
+    """Compute (and keep on the plan) the per-voxel mean position differences of a batch."""
+    return _pos_terms(build_plan(graph), extract_pos(graph.voxel_feature)[0])
+
+
 def _level_op(plan, max_len: int) -> LinOp:
     key = ("level_op", max_len)
     op = plan.ops.get(key)
@@ -301,6 +306,16 @@ class VoxelGNN_D(nn.Module):
             plan.ops[key] = Z
         return Z
 
+    def coefficients(self, n_feat, ds, dl):
+        """The collapsed weight, shared between calls inside DiscriminatorVoxel.shared_coefficients()."""
+        key = (ds, dl, torch.is_grad_enabled())
+        if self._share_coef and self._coef_cache is not None and self._coef_cache[0] == key:
+            return self._coef_cache[1]
+        W = self._collapsed_weight(self.block.compose(), n_feat, ds, dl)
+        if self._share_coef:
+            self._coef_cache = (key, W)
+        return W
+
     def _collapsed_weight(self, composed, n_feat, ds, dl):
         """W [(L+1)*ds + (L+1)*dl, 2H] such that v_L = [Zs | Zl] W (rows ordered (k, input column))."""
         Wc, bc = composed[0], composed[1]
@@ -329,13 +344,7 @@ class VoxelGNN_D(nn.Module):
         Zs = self._static_powers(plan, feat, pdm4)
         ds = Zs.shape[1] // (L + 1)
         dl = (l.shape[1] + 3) // 4 * 4
-        key = (ds, dl, torch.is_grad_enabled())
-        if self._share_coef and self._coef_cache is not None and self._coef_cache[0] == key:
-            W = self._coef_cache[1]
-        else:
-            W = self._collapsed_weight(self.block.compose(), feat.shape[1], ds, dl)
-            if self._share_coef:
-                self._coef_cache = (key, W)
+        W = self.coefficients(feat.shape[1], ds, dl)
         zl = [F.pad(l, (0, dl - l.shape[1]))]
         for _ in range(L):
             zl.append(SpMM.apply(zl[-1], plan.vox_mean))
@@ -351,7 +360,7 @@ class VoxelGNN_D(nn.Module):
         ds = Zs.shape[1] // (L + 1)
         n_lab = labels[0].shape[1]
         dl = (n_lab + 3) // 4 * 4
-        W = self._collapsed_weight(self.block.compose(), feat.shape[1], ds, dl)
+        W = self.coefficients(feat.shape[1], ds, dl)
         Ws, Wl = W[:(L + 1) * ds], W[(L + 1) * ds:]
         Zk = torch.zeros(N, L + 1, P * dl, device=feat.device)
         for p, l in enumerate(labels):
@@ -469,6 +478,18 @@ class DiscriminatorVoxel(nn.Module):
         for k in range(L - 1, -1, -1):
             acc = ops.SpMMAdd.apply(acc, Y[:, k], plan.vox_mean.T)
         return (*out, acc[:, :n_lab], acc[:, dl:dl + n_lab])
+
+    def prepare(self, graph, n_label: int = NUMBER_OF_CLASS):
+        """Inside shared_coefficients(): build what the collapsed passes share and that depends on
+        the graph and the parameters only (operator powers of the label-free columns, coefficient
+        table), e.g. on a side stream while the generator runs."""
+        plan = build_plan(graph)
+        gnn = self.voxelGNN_D
+        if not (COLLAPSE_D and COMPOSE_BLOCKS and plan.vox_all_has and gnn.layer_num > 0 and gnn._share_coef):
+            return
+        pos, feat = extract_pos(graph.voxel_feature)
+        Zs = gnn._static_powers(plan, feat, _pos_terms(plan, pos))
+        gnn.coefficients(feat.shape[1], Zs.shape[1] // (gnn.layer_num + 1), (n_label + 3) // 4 * 4)
 
     def forward(self, graph, out_label):
         plan = build_plan(graph)

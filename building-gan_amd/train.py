@@ -23,7 +23,7 @@ import torch.distributed as dist
 from . import ops
 from .graph import detach_batch
 from .losses import VolumetricDesignLoss_G
-from .models import DiscriminatorVoxel, Generator
+from .models import DiscriminatorVoxel, Generator, position_terms
 from .util import softmax_to_hard
 
 
@@ -112,6 +112,7 @@ class Trainer:
         self.g_loss_fn = VolumetricDesignLoss_G(gan_loss=gan_loss)
         self.group = group
         self._graphs = None
+        self._overlap_stream = None    # set while capture() records the iteration
 
     def broadcast_parameters(self, src: int = 0):
         if _world(self.group) > 1:
@@ -158,26 +159,40 @@ class Trainer:
             program_z = torch.rand(batch.program_class_feature.shape[0], self.noise_dim, device=dev)
         if voxel_z is None:
             voxel_z = torch.rand(batch.voxel_feature.shape[0], self.noise_dim, device=dev)
-        gen = G(batch, program_z, voxel_z, noise)
-        out, soft_out = gen[0], gen[1]
-        if do_d:
-            gp = None
-            fused = None
-            if hasattr(D, "critic_terms") and (self.gp_lambda == 0 or getattr(D, "piecewise_linear", False)):
-                sample = self._gp_sample(batch.voxel_label.detach(), soft_out.detach(), u) if self.gp_lambda != 0 else None
-                fused = D.critic_terms(batch, batch.voxel_label, out.detach(), sample)
-            if fused is not None:
-                real_b, real_s, fake_b, fake_s, grad_b, grad_s = fused
-                if grad_b is not None:
-                    gp = (((grad_b.norm(2, 1) - 1) ** 2).sum() + ((grad_s.norm(2, 1) - 1) ** 2).sum()) / Nvg
-            else:
-                share = D.shared_coefficients() if hasattr(D, "shared_coefficients") else contextlib.nullcontext()
-                with share:
+        fused_ok = do_d and hasattr(D, "critic_terms") and (self.gp_lambda == 0 or getattr(D, "piecewise_linear", False))
+        share = D.shared_coefficients() if (do_d and hasattr(D, "shared_coefficients")) else contextlib.nullcontext()
+        with share:
+            side = self._overlap_stream if fused_ok else None
+            if side is not None:
+                # what the critic needs from the graph and the parameters alone (operator powers,
+                # coefficient table: chains of small kernels) runs beside the generator forward
+                position_terms(batch)                      # shared with the generator: not on the side stream
+                cur = torch.cuda.current_stream()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    D.prepare(batch)
+            gen = G(batch, program_z, voxel_z, noise)
+            if side is not None:
+                cur.wait_stream(side)
+            out, soft_out = gen[0], gen[1]
+            if do_d:
+                gp = None
+                fused = None
+                if fused_ok:
+                    sample = (self._gp_sample(batch.voxel_label.detach(), soft_out.detach(), u)
+                              if self.gp_lambda != 0 else None)
+                    fused = D.critic_terms(batch, batch.voxel_label, out.detach(), sample)
+                if fused is not None:
+                    real_b, real_s, fake_b, fake_s, grad_b, grad_s = fused
+                    if grad_b is not None:
+                        gp = (((grad_b.norm(2, 1) - 1) ** 2).sum() + ((grad_s.norm(2, 1) - 1) ** 2).sum()) / Nvg
+                else:
                     fake_b, fake_s = D(detach_batch(batch), out.detach())
                     if self.gp_lambda != 0:
                         gp = self._gradient_penalty(detach_batch(batch), batch.voxel_label.detach(),
                                                     soft_out.detach(), u, Nvg)
                     real_b, real_s = D(batch, batch.voxel_label)
+        if do_d:
             d_loss = -real_b.sum() / Bg - real_s.sum() / Sg + fake_b.sum() / Bg + fake_s.sum() / Sg
             if gp is not None:
                 d_loss = d_loss + self.gp_lambda * gp
@@ -220,7 +235,7 @@ class Trainer:
         return stats
 
     # ------------------------------------------------------------------ hipGraph iteration
-    def capture(self, batch, warmup: int = 2):
+    def capture(self, batch, warmup: int = 2, overlap: bool = False):
         """Capture the iteration for THIS batch (fixed shapes) into hipGraphs.
 
         Segments: A = phase D (G forward ... d_loss.backward); B = Adam(D) + phase G; C = Adam(G);
@@ -231,6 +246,7 @@ class Trainer:
             raise NotImplementedError("graph capture assumes n_critic_d == 1 (the reference default)")
         saved = (self.opt_g.state(), self.opt_d.state())
         counts = global_counts(batch, self.group)
+        self._overlap_stream = torch.cuda.Stream() if overlap else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -264,6 +280,7 @@ class Trainer:
         graphs["no_g"] = (gA2, gB2, statsA2)
         self._graphs = graphs
         self._keep = (gen, gen2)
+        self._overlap_stream = None    # eager iterations stay on one stream
         self.opt_g.restore(saved[0])
         self.opt_d.restore(saved[1])
         torch.cuda.synchronize()

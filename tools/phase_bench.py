@@ -16,7 +16,7 @@ torch.manual_seed(0)
 tr = Trainer(dev)
 build_plan(batch)
 if mode == "graph":
-    tr.capture(batch)
+    tr.capture(batch, overlap=os.environ.get('OVERLAP', '0') == '1')
     fn = tr.train_iteration_graphed
 else:
     fn = lambda i: tr.train_iteration(batch, i)
