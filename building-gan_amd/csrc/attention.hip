@@ -141,6 +141,36 @@ __global__ void k_seg_argmax(const float* __restrict__ logit, const int32_t* __r
     arg[v] = ba;
 }
 
+// Two-way Gumbel-softmax of the attention's voxel mask (reference models.py:109-111):
+//   z = logits - log(expn);  soft = softmax(z);  hard = (onehot(argmax soft) - soft) + soft;
+// only column 0 of either is used downstream.  One thread per voxel.
+__global__ void k_mask_gumbel(const float* __restrict__ logits, const float* __restrict__ expn,
+                              float* __restrict__ soft0, float* __restrict__ hard0, int64_t n) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const float2 l = *reinterpret_cast<const float2*>(logits + 2 * v);
+    const float2 e = *reinterpret_cast<const float2*>(expn + 2 * v);
+    const float z0 = l.x - logf(e.x), z1 = l.y - logf(e.y);
+    const float m = fmaxf(z0, z1);
+    const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+    const float sum = e0 + e1;
+    const float s0 = e0 / sum, s1 = e1 / sum;
+    const float one0 = s0 >= s1 ? 1.f : 0.f;            // first maximum wins a tie
+    soft0[v] = s0;
+    hard0[v] = (one0 - s0) + s0;
+}
+
+// d logits of  <g_soft, soft0> + <g_hard, hard0>  (the hard output passes its gradient straight through)
+__global__ void k_mask_gumbel_bwd(const float* __restrict__ soft0, const float* __restrict__ g_soft,
+                                  const float* __restrict__ g_hard, float* __restrict__ d_logits, int64_t n) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const float s = soft0[v];
+    const float g = (g_soft ? g_soft[v] : 0.f) + (g_hard ? g_hard[v] : 0.f);
+    const float d = g * s * (1.f - s);
+    *reinterpret_cast<float2*>(d_logits + 2 * v) = make_float2(d, -d);
+}
+
 }  // namespace
 
 extern "C" {
@@ -210,6 +240,27 @@ int bg_seg_argmax_f32(const float* logit, const int32_t* rowptr, int32_t* arg, i
     if (n_seg == 0) return BG_OK;
     if (!logit || !rowptr || !arg) return BG_ERR_ARG;
     k_seg_argmax<<<bg_grid_for(n_seg, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(logit, rowptr, arg, n_seg);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_mask_gumbel_f32(const float* logits, const float* expn, float* soft0, float* hard0, int64_t n,
+                       bgStream stream) {
+    if (n < 0) return BG_ERR_ARG;
+    if (n == 0) return BG_OK;
+    if (!logits || !expn || !soft0 || !hard0) return BG_ERR_ARG;
+    k_mask_gumbel<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(logits, expn, soft0, hard0, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_mask_gumbel_bwd_f32(const float* soft0, const float* g_soft, const float* g_hard, float* d_logits,
+                           int64_t n, bgStream stream) {
+    if (n < 0) return BG_ERR_ARG;
+    if (n == 0) return BG_OK;
+    if (!soft0 || !d_logits) return BG_ERR_ARG;
+    k_mask_gumbel_bwd<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(soft0, g_soft, g_hard,
+                                                                                         d_logits, n);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

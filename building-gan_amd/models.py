@@ -159,10 +159,8 @@ class Attention(nn.Module):
         logits = run_mlp(self.dec, voxel_feature)
         if exp_mask is None:
             exp_mask = torch.empty_like(logits).exponential_()
-        soft_mask = ((logits - exp_mask.log()) / 1.0).softmax(-1)
-        winner = soft_mask.max(-1, keepdim=True)[1]
-        hard_mask = torch.zeros_like(soft_mask).scatter_(-1, winner, 1.0) - soft_mask.detach() + soft_mask
-        out_mask = {"hard": hard_mask[:, 0].view(-1, 1), "soft": soft_mask[:, 0].view(-1, 1)}
+        soft0, hard0 = ops.MaskGumbel.apply(logits, exp_mask)
+        out_mask = {"hard": hard0, "soft": soft0}
 
         a = linear(voxel_feature, self.NN_v.weight, self.NN_v.bias)
         b = linear(program_graph_feature, self.NN_p.weight, self.NN_p.bias)
@@ -173,7 +171,7 @@ class Attention(nn.Module):
         out_att = {"hard": hard_att.view(-1, 1), "soft": soft_att.view(-1, 1)}
 
         gathered = SpMMW.apply(program_graph_feature, soft_att, plan.cross_v_sum)
-        new_voxel_feature = voxel_feature + out_mask["soft"] * gathered
+        new_voxel_feature = torch.addcmul(voxel_feature, out_mask["soft"], gathered)
         return out_mask, out_att, new_voxel_feature
 
     @staticmethod

@@ -380,18 +380,19 @@ class LinearCat(torch.autograd.Function):
         ctx.inputs_only = _INPUT_GRADS_ONLY
         ctx.has_res, ctx.has_pre = residual is not None, pre_add is not None
         ctx.widths = [x.shape[1] for x in xs]
-        pos = (y > 0) if act == ACT_LEAKY else None      # sign of the pre-activation
+        # leaky(z) has the sign of z: the activation's output doubles as the mask for the backward
+        act_out = y if act == ACT_LEAKY else None
         if act == ACT_LEAKY and residual is not None:
             y = y + residual
-        ctx.save_for_backward(W, row_scale, pos, *xs)
+        ctx.save_for_backward(W, row_scale, act_out, *xs)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        W, row_scale, pos, *xs = ctx.saved_tensors
+        W, row_scale, act_out, *xs = ctx.saved_tensors
         g_res = g if ctx.has_res and ctx.needs_input_grad[5] else None
         if ctx.act == ACT_LEAKY:
-            g = torch.where(pos, g, g * ctx.slope)
+            g = torch.where(act_out > 0, g, g * ctx.slope)
         g_pre = g if ctx.has_pre and ctx.needs_input_grad[6] else None
         if row_scale is not None:
             g = g * row_scale.view(-1, 1)
@@ -533,6 +534,37 @@ class SegGumbelSoftmax(torch.autograd.Function):
         check(lib.bg_seg_softmax_bwd_f32(ptr(soft), ptr(g), ptr(cv.rowptr), ctx.tau, ptr(d_att), cv.n_rows, stream()),
               "bg_seg_softmax_bwd_f32")
         return d_att, None, None, None
+
+
+class MaskGumbel(torch.autograd.Function):
+    """(soft[:, 0], hard[:, 0]) of the two-way Gumbel-softmax over the mask decoder's logits
+    (reference models.py:109-111) in one launch; first-order autograd."""
+
+    @staticmethod
+    def forward(ctx, logits, expn):
+        lib = _lib.load()
+        _lib.require_device(logits, "mask_gumbel")
+        l2, e2 = _f32c(logits).contiguous(), _f32c(expn).contiguous()
+        n = l2.shape[0]
+        if l2.shape[1] != 2 or tuple(e2.shape) != tuple(l2.shape):
+            raise _lib.BganError("mask_gumbel: logits and noise must both be [n, 2]")
+        soft0 = torch.empty(n, 1, dtype=torch.float32, device=logits.device)
+        hard0 = torch.empty(n, 1, dtype=torch.float32, device=logits.device)
+        check(lib.bg_mask_gumbel_f32(ptr(l2), ptr(e2), ptr(soft0), ptr(hard0), n, stream()), "bg_mask_gumbel_f32")
+        ctx.save_for_backward(soft0)
+        return soft0, hard0
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_soft, g_hard):
+        (soft0,) = ctx.saved_tensors
+        lib = _lib.load()
+        n = soft0.shape[0]
+        gs = _f32c(g_soft).contiguous() if g_soft is not None else None
+        gh = _f32c(g_hard).contiguous() if g_hard is not None else None
+        d = torch.empty(n, 2, dtype=torch.float32, device=soft0.device)
+        check(lib.bg_mask_gumbel_bwd_f32(ptr(soft0), ptr(gs), ptr(gh), ptr(d), n, stream()), "bg_mask_gumbel_bwd_f32")
+        return d, None
 
 
 def seg_argmax(logit: torch.Tensor, plan) -> torch.Tensor:

@@ -160,6 +160,18 @@ int bg_seg_softmax_bwd_f32(const float* soft, const float* g, const int32_t* row
 int bg_seg_argmax_f32(const float* logit, const int32_t* rowptr, int32_t* arg, int64_t n_seg,
                       bgStream stream);
 
+/* Two-way Gumbel-softmax of the voxel mask, column 0 of the soft and of the straight-through hard
+ * output: z = logits - log(expn) ([n,2] each, Exp(1) noise), soft = softmax(z),
+ * hard = (onehot(first argmax of soft) - soft) + soft.
+ * replaces: Model/models.py:109-111 (torch.nn.functional.gumbel_softmax + util.py:6-10
+ * softmax_to_hard on the mask decoder's logits).                                              */
+int bg_mask_gumbel_f32(const float* logits, const float* expn, float* soft0, float* hard0, int64_t n,
+                       bgStream stream);
+
+/* d_logits [n,2] of <g_soft, soft0> + <g_hard, hard0>; either gradient may be NULL.            */
+int bg_mask_gumbel_bwd_f32(const float* soft0, const float* g_soft, const float* g_hard, float* d_logits,
+                           int64_t n, bgStream stream);
+
 /* ------------------------------------------------------------------ dense (fp32 MFMA) --- */
 
 #define BG_ACT_NONE 0

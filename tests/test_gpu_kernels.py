@@ -297,3 +297,24 @@ def test_bad_arguments_are_rejected(cuda):
     with pytest.raises(_lib.BganError):
         from building_gan_amd import ops
         ops.gemm_raw([torch.zeros(4, 4)], torch.zeros(4, 4), False, True)            # CPU tensors: no fallback
+
+
+def test_mask_gumbel_two_way(cuda):
+    """Fused mask kernel against the reference expression (models.py:109-111, util.py:6-10), with its gradient."""
+    from building_gan_amd import ops
+    from oracle.pointer import softmax_to_hard
+    torch.manual_seed(3)
+    n = 5000
+    logits = (torch.randn(n, 2) * 3).requires_grad_(True)
+    expn = torch.empty(n, 2).exponential_()
+    soft = (logits - expn.log()).softmax(-1)
+    hard = softmax_to_hard(soft, -1)
+    lg = logits.detach().to(cuda).requires_grad_(True)
+    s0, h0 = ops.MaskGumbel.apply(lg, expn.to(cuda))
+    torch.testing.assert_close(s0.cpu(), soft[:, :1].detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(h0.cpu(), hard[:, :1].detach(), rtol=0, atol=2e-7)
+    assert torch.equal(h0.cpu().round(), hard[:, :1].detach().round())           # same winners
+    w = torch.randn(n, 1)
+    (soft[:, :1] * w + 2 * hard[:, :1] * w).sum().backward()
+    (s0 * w.to(cuda) + 2 * h0 * w.to(cuda)).sum().backward()
+    torch.testing.assert_close(lg.grad.cpu(), logits.grad, rtol=1e-4, atol=1e-6)
