@@ -26,6 +26,7 @@ struct GemmArgs {
     const float* bias; const float* row_scale; int act; float slope;
     const float* residual; int64_t ldr;
     const float* pre_add; int64_t ldp;
+    const int32_t* pre_rows;   // optional: pre_add row of output row i is pre_rows[i] (a fused gather)
     int64_t M, N;
     int total_steps;      // sum over segments of ceil(K_s / BK)
     int steps_per_split;  // == total_steps when not split
@@ -176,8 +177,16 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc,
         for (int q = 0; q < 16; ++q) rs[q] = g.row_scale[rows[q]];
     }
     if (g.pre_add) {
+        if (g.pre_rows) {
+            int32_t pr[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) pa[q] = g.pre_add[rows[q] * g.ldp + col];
+            for (int q = 0; q < 16; ++q) pr[q] = g.pre_rows[rows[q]];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pa[q] = g.pre_add[(int64_t)pr[q] * g.ldp + col];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pa[q] = g.pre_add[rows[q] * g.ldp + col];
+        }
     }
     if (g.residual) {
 #pragma unroll
@@ -647,13 +656,14 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
                 const float* const* A, const int64_t* lda, const int64_t* Ks,
                 const float* B, int64_t ldb, float* C, int64_t ldc,
                 const float* bias, const float* row_scale, int act, float slope,
-                const float* residual, int64_t ldr, const float* pre_add, int64_t ldp, bgStream stream) {
+                const float* residual, int64_t ldr, const float* pre_add, int64_t ldp,
+                const int32_t* pre_add_rows, bgStream stream) {
     if (M < 0 || N < 0 || n_seg < 1 || n_seg > 4 || !A || !lda || !Ks) return BG_ERR_ARG;
     if (M == 0 || N == 0) return BG_OK;
     if (!B || !C || ldc < N || (residual && ldr < N) || (pre_add && ldp < N)) return BG_ERR_ARG;
     GemmArgs g{};
     g.n_seg = n_seg;
-    g.pre_add = pre_add; g.ldp = ldp;
+    g.pre_add = pre_add; g.ldp = ldp; g.pre_rows = pre_add ? pre_add_rows : nullptr;
     int tile = tile_override();
     if (tile == 0) {
         const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);

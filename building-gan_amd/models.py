@@ -198,7 +198,8 @@ class VoxelBlock(nn.Module):
         two Linears collapse into one:  Wu[v; Wm[v; Av; p] + bm; ...] = Wc[v; Av; p] + bc (+ story terms)
         with Wc = [Wu1 + Wu2 Wm1 | Wu2 Wm2 | Wu2 Wm3], bc = Wu2 bm + bu.  Halves (D) / thirds (G) the
         flops of every pass; the small weight products are differentiable GEMMs, so gradients reach
-        messageMLP / updateMLP through the chain rule.  Returns (Wc [H,2H+4], bc, Ws, Wb)."""
+        messageMLP / updateMLP through the chain rule.  Returns (Wc [H,2H+4], bc, Wsb [H,2H]) with
+        Wsb = [Wu3 - Wu4 | Wu4] acting on [story mean | building mean]."""
         Wm, bm = self.messageMLP[0].weight, self.messageMLP[0].bias
         Wu, bu = self.updateMLP[0].weight, self.updateMLP[0].bias
         H = Wm.shape[0]
@@ -207,21 +208,21 @@ class VoxelBlock(nn.Module):
         Wc = P[:, :2 * H + 4] + F.pad(Wu[:, :H], (0, H + 4))
         bc = P[:, 2 * H + 4] + bu
         if self.if_agg_story_in_update:
-            return Wc, bc, Wu[:, 2 * H:3 * H] - Wu[:, 3 * H:], Wu[:, 3 * H:]
-        return Wc, bc, None, None
+            return Wc, bc, torch.cat([Wu[:, 2 * H:3 * H] - Wu[:, 3 * H:], Wu[:, 3 * H:]], dim=1)
+        return Wc, bc, None
 
     def forward_composed(self, voxel_feature, plan, pdm4, composed):
         """v + block(v) with the collapsed weights (valid when plan.vox_all_has)."""
-        Wc, bc, Ws, Wb = composed
+        Wc, bc, Wsb = composed
         gm = SpMM.apply(voxel_feature, plan.vox_mean)
         if not self.if_agg_story_in_update:
             return linear([voxel_feature, gm, pdm4], Wc, bc, residual=voxel_feature)
         story = SpMM.apply(voxel_feature, plan.story_mean)                      # [S, H]
-        building = SpMM.apply(story, plan.graph_of_story_mean)                  # [B, H]
-        # (Wu3 - Wu4) story + Wu4 building, evaluated per story and gathered to the voxels
-        term = linear(story, Ws) + SpMM.apply(linear(building, Wb), plan.story_graph_gather)
-        pre = SpMM.apply(term, plan.story_gather)
-        return voxel_feature + linear([voxel_feature, gm, pdm4], Wc, bc, ACT_LEAKY, 0.01, pre_add=pre)
+        building = SpMM.apply(SpMM.apply(story, plan.graph_of_story_mean), plan.story_graph_gather)   # [S, H]
+        # (Wu3 - Wu4) story + Wu4 building, evaluated per STORY; the product's epilogue gathers it to the voxels
+        term = linear([story, building], Wsb)
+        return voxel_feature + linear([voxel_feature, gm, pdm4], Wc, bc, ACT_LEAKY, 0.01, pre_add=term,
+                                      pre_gather=plan.story_gather)
 
     def forward(self, voxel_feature, plan, pdm4):
         H = voxel_feature.shape[1]

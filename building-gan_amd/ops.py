@@ -160,7 +160,8 @@ _I64Arr4 = C.c_int64 * 4
 def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: bool,
              bias: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
              act: int = ACT_NONE, slope: float = 0.01, residual: Optional[torch.Tensor] = None,
-             pre_add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             pre_add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+             pre_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C = epilogue(cat(A, -1 (or 0 when transA)) (x) B); see bg_gemm_f32."""
     lib = _lib.load()
     if len(A) < 1 or len(A) > 4:
@@ -194,10 +195,12 @@ def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: b
         residual = _f32c(residual)
     if pre_add is not None:
         pre_add = _f32c(pre_add)
+        if pre_rows is not None and (pre_rows.dtype != torch.int32 or pre_rows.numel() != M):
+            raise _lib.BganError("gemm: pre_rows must hold one int32 row index per output row")
     check(lib.bg_gemm_f32(int(transA), int(transB), M, N, len(As), pa, la, ka, ptr(B2), _ld(B2), ptr(out), _ld(out),
                           ptr(bias), ptr(row_scale), act, slope, ptr(residual),
                           _ld(residual) if residual is not None else 0, ptr(pre_add),
-                          _ld(pre_add) if pre_add is not None else 0, stream()), "bg_gemm_f32")
+                          _ld(pre_add) if pre_add is not None else 0, ptr(pre_rows), stream()), "bg_gemm_f32")
     return out
 
 
@@ -374,8 +377,12 @@ class LinearCat(torch.autograd.Function):
         if w_t:
             act = act[0]
         ctx.w_t = w_t
+        pre_op = None
+        if isinstance(slope, tuple):            # (slope, gather LinOp): pre_add has one row per gathered group
+            slope, pre_op = slope
+        ctx.pre_op = pre_op
         y = gemm_raw(list(xs), W, False, not w_t, bias=b, row_scale=row_scale, act=act, slope=slope,
-                     residual=fuse_res, pre_add=pre_add)
+                     residual=fuse_res, pre_add=pre_add, pre_rows=pre_op.csr.col if pre_op is not None else None)
         ctx.act, ctx.slope = act, slope
         ctx.inputs_only = _INPUT_GRADS_ONLY
         ctx.has_res, ctx.has_pre = residual is not None, pre_add is not None
@@ -394,6 +401,8 @@ class LinearCat(torch.autograd.Function):
         if ctx.act == ACT_LEAKY:
             g = torch.where(act_out > 0, g, g * ctx.slope)
         g_pre = g if ctx.has_pre and ctx.needs_input_grad[6] else None
+        if g_pre is not None and ctx.pre_op is not None:
+            g_pre = SpMM.apply(g_pre, ctx.pre_op.T)          # transpose of the fused gather: sum over each group
         if row_scale is not None:
             g = g * row_scale.view(-1, 1)
         gW = gb = None
@@ -414,11 +423,19 @@ class LinearCat(torch.autograd.Function):
         return (gW, gb, None, None, None, g_res, g_pre, *gxs)
 
 
-def linear(xs, W, b=None, act=ACT_NONE, slope=0.01, row_scale=None, residual=None, pre_add=None, w_t=False):
-    """``w_t``: W is given as [K, out] (y = cat(xs) @ W) instead of the nn.Linear layout [out, K]."""
+def linear(xs, W, b=None, act=ACT_NONE, slope=0.01, row_scale=None, residual=None, pre_add=None, w_t=False,
+           pre_gather: Optional[LinOp] = None):
+    """``w_t``: W is given as [K, out] (y = cat(xs) @ W) instead of the nn.Linear layout [out, K].
+    ``pre_gather``: a pure gather LinOp (one source row per output row, no scaling); ``pre_add`` then holds
+    one row per SOURCE and the gather is fused into the product's epilogue."""
     if torch.is_tensor(xs):
         xs = [xs]
-    return LinearCat.apply(W, b, (act, "t") if w_t else act, slope, row_scale, residual, pre_add, *xs)
+    if pre_gather is not None:
+        c = pre_gather.csr
+        if pre_gather.row_mode != SCALE_NONE or pre_gather.col_mode != SCALE_NONE or c.nnz != c.n_rows:
+            raise _lib.BganError("linear: pre_gather must be an unscaled one-entry-per-row gather")
+    return LinearCat.apply(W, b, (act, "t") if w_t else act, (slope, pre_gather) if pre_gather is not None else slope,
+                           row_scale, residual, pre_add, *xs)
 
 
 class SegMax(torch.autograd.Function):

@@ -180,7 +180,9 @@ int bg_mask_gumbel_bwd_f32(const float* soft0, const float* g_soft, const float*
 /* C[M,N] = epilogue( sum_s opA(A_s) * opB(B)[koff_s : koff_s+K_s, :] ),  koff_s = K_0+..+K_{s-1}
  *   transA == 0: A_s is [M, K_s] (pitch lda[s]);  transA == 1: A_s is [K_s, M]
  *   transB == 0: B is [K, N] (pitch ldb);         transB == 1: B is [N, K]  (nn.Linear weight)
- *   epilogue(v)[m,n] = act(row_scale[m] * (v + bias[n]) + pre_add[m,n]) + residual[m,n]; each part optional.
+ *   epilogue(v)[m,n] = act(row_scale[m] * (v + bias[n]) + pre_add[pr(m),n]) + residual[m,n]; each part
+ *   optional; pr(m) = pre_add_rows[m] when given (a gather of per-story rows onto voxels fused into
+ *   the product: the index_select at models.py:168-169), else m.
  * n_seg in 1..4 fuses torch.cat((A_0,..), -1) into the product.  Exact fp32 (v_mfma_f32_32x32x2_f32).
  * Vector path needs 16-byte aligned bases and pitches / K_s % 4 == 0; anything else runs a
  * scalar-load path of the same kernel.
@@ -189,7 +191,8 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
                 const float* const* A, const int64_t* lda, const int64_t* Ks,
                 const float* B, int64_t ldb, float* C, int64_t ldc,
                 const float* bias, const float* row_scale, int act, float slope,
-                const float* residual, int64_t ldr, const float* pre_add, int64_t ldp, bgStream stream);
+                const float* residual, int64_t ldr, const float* pre_add, int64_t ldp,
+                const int32_t* pre_add_rows, bgStream stream);
 
 /* C[M,N] = A^T[M,R] * [B_0 | B_1 | ..][R,N] with the long reduction R split over `splits`
  * workgroups per tile: A is [R, M] (pitch lda), B_s is [R, Ns[s]] (pitch ldb[s]), N = sum Ns
