@@ -7,8 +7,8 @@ A "step" is one G+D training iteration (reference train.py:73-114) over one synt
 "dataset-sized" buildings per GPU (BASELINE.json configs[1]); the index i of the iteration keeps
 running through warm-up and timed steps, so every 5th step carries the generator update.
 value = voxel-graphs/s over the whole job.  Extra objects on the same JSON line:
-  roofline     -- the dominant kernel of the step (fp32 MFMA GEMM of the discriminator's
-                  message layer), timed live with HIP events on the launch stream;
+  roofline     -- the dominant kernel of the step (fp32 MFMA GEMM of the generator block),
+                  timed live with HIP events on the launch stream;
   microbench   -- configs[2]: one message-passing gather-mean layer at 10^6 edges (HBM roofline);
   cpu_baseline -- the CPU oracle (a "port": the reference itself cannot run) timed
                   on this host on a bounded sample of the same workload (rank 0, N=1 only).
@@ -43,23 +43,50 @@ def event_time_ms(fn, iters, warm=3):
     return a.elapsed_time(b) / iters
 
 
-def roofline_dominant_gemm(dev, Nv, hidden=128):
-    """Discriminator message GEMM of one layer: [Nv, 2H'+4] x [2H'+4 -> H'], H' = 2*hidden."""
+def pmc_traffic(key):
+    """HBM bytes per launch from the committed PMC pass (profiles/r01_traffic.json; collected with
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950), or None when that file does not cover the kernel."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            return json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
+
+
+def roofline_dominant_gemm(dev, batch, plan, hidden=128):
+    """The kernel with the largest share of the step (profiles/r01_bench_kernel_stats*): the generator
+    block's collapsed Linear, [v | mean_j v_j | dpos] (K = 2H+4) -> H with bias, the per-story term
+    gathered in the epilogue and LeakyReLU.  Algorithmic flops = 2 M N K."""
     from building_gan_amd import ops
-    H = 2 * hidden
+    H, Nv = hidden, int(batch.voxel_feature.shape[0])
     torch.manual_seed(1)
     xs = [torch.rand(Nv, H, device=dev) * 2 - 1, torch.rand(Nv, H, device=dev) * 2 - 1,
           torch.rand(Nv, 4, device=dev) * 2 - 1]
     W = torch.rand(H, 2 * H + 4, device=dev) * 2 - 1
     b = torch.rand(H, device=dev)
-    rs = torch.ones(Nv, device=dev)
-    ms = event_time_ms(lambda: ops.gemm_raw(xs, W, False, True, bias=b, row_scale=rs), 50)
+    term = torch.rand(plan.S, H, device=dev)
+    rows = plan.story_gather.csr.col
+    run = lambda: ops.gemm_raw(xs, W, False, True, bias=b, act=ops.ACT_LEAKY, slope=0.01, pre_add=term, pre_rows=rows)
+    # launch-bound in eager mode at this size: time the kernel inside a hipGraph of 20 launches
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run()
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        for _ in range(20):
+            run()
+    ms = event_time_ms(g.replay, 10) / 20
     flops = 2.0 * Nv * (2 * H + 4) * H
     ach = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "k_gemm (discriminator message Linear, M=%d N=%d K=%d)" % (Nv, H, 2 * H + 4),
+    return {"kernel": "k_gemm<64,64,64> (generator block Linear, M=%d N=%d K=%d, fused gather + LeakyReLU epilogue)"
+                      % (Nv, H, 2 * H + 4),
             "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_us": round(ms * 1e3, 2),
-            "algorithmic_flops_per_launch": flops}
+            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_generator_block"),
+            "avg_launch_us": round(ms * 1e3, 2), "algorithmic_flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": 4.0 * (Nv * (2 * H + 4) + H * (2 * H + 4) + Nv * H + plan.S * H + Nv)}
 
 
 def microbench_message_passing(dev):
@@ -79,7 +106,7 @@ def microbench_message_passing(dev):
         gbs = nbytes / (ms * 1e-3) / 1e9
         res["H%d" % H] = {"edges_per_s": round(sz["Ev"] / (ms * 1e-3), 1), "avg_launch_us": round(ms * 1e3, 2),
                           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                       "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("spmm_H%d" % H),
                                        "algorithmic_bytes_per_launch": nbytes}}
     return res
 
@@ -147,7 +174,13 @@ def main():
     trainer = Trainer(dev)
     trainer.broadcast_parameters(0)
     torch.manual_seed(1000 + rank)
-    build_plan(batch)
+    build_plan(batch)                     # first build also loads the library and warms the allocator
+    batch.__dict__.pop("_bg_plan", None)
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter()
+    build_plan(batch)                     # per-batch index preprocessing (CSR by target/source, segment tables)
+    torch.cuda.synchronize()
+    plan_ms = round((time.perf_counter() - t_plan) * 1e3, 3)
 
     def sync():
         torch.cuda.synchronize()
@@ -189,7 +222,8 @@ def main():
                        "n_critic_g": 5, "parallelism": "dp%d" % world,
                        "launch": "eager" if args.no_graph else "hipGraph segments + eager RCCL all-reduce"},
         }
-        line["roofline"] = roofline_dominant_gemm(dev, sz["Nv"])
+        line["roofline"] = roofline_dominant_gemm(dev, batch, build_plan(batch))
+        line["plan_build_ms"] = plan_ms
         if world == 1 and not args.no_microbench:
             line["microbench"] = microbench_message_passing(dev)
         if world == 1 and not args.no_cpu_baseline:

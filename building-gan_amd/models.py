@@ -203,7 +203,8 @@ class VoxelBlock(nn.Module):
         Wm, bm = self.messageMLP[0].weight, self.messageMLP[0].bias
         Wu, bu = self.updateMLP[0].weight, self.updateMLP[0].bias
         H = Wm.shape[0]
-        Wm_ext = torch.cat([F.pad(Wm, (0, 1)), bm.view(-1, 1)], dim=1)          # [H, 2H+5]
+        # [H, 2H+8]: [Wm | 0 | bm | 0 0 0] -- the pad keeps the row pitch a multiple of 16 bytes (vector loads)
+        Wm_ext = torch.cat([F.pad(Wm, (0, 1)), bm.view(-1, 1), Wm.new_zeros(H, 3)], dim=1)
         P = ops.MatMul.apply(Wu[:, H:2 * H], Wm_ext, False, False)              # Wu2 @ [Wm | 0 | bm]
         Wc = P[:, :2 * H + 4] + F.pad(Wu[:, :H], (0, H + 4))
         bc = P[:, 2 * H + 4] + bu

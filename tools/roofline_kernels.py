@@ -1,5 +1,6 @@
-"""Launches only the two roofline kernels (for rocprofv3 --kernel-trace / --pmc passes):
-the discriminator message GEMM at the train-step shape and the 10^6-edge gather-mean."""
+"""Launches only the roofline kernels (for rocprofv3 --kernel-trace / --pmc passes): the train step's
+dominant GEMM (the generator block's collapsed Linear: [v | mean_j v_j | dpos] -> H with the per-story
+term gathered in the epilogue and LeakyReLU) and the 10^6-edge gather-mean of the microbench."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,15 +13,16 @@ which = sys.argv[1] if len(sys.argv) > 1 else "both"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 torch.manual_seed(0)
 if which in ("gemm", "both"):
-    M, H = 11520, 256
+    batch = make_batch("dataset", seed=0).to(dev)
+    plan = build_plan(batch)
+    M, H = batch_sizes(batch)["Nv"], 128
     xs = [torch.rand(M, H, device=dev) * 2 - 1, torch.rand(M, H, device=dev) * 2 - 1, torch.rand(M, 4, device=dev) * 2 - 1]
     W = torch.rand(H, 2 * H + 4, device=dev) * 2 - 1
     b = torch.rand(H, device=dev)
-    g = torch.rand(M, H, device=dev) * 2 - 1
+    term = torch.rand(plan.S, H, device=dev)
     for _ in range(iters):
-        ops.gemm_raw(xs, W, False, True, bias=b, residual=xs[0])
-        ops.gemm_raw([g], W, False, False)
-        ops.gemm_tn_raw(g, xs)
+        ops.gemm_raw(xs, W, False, True, bias=b, act=ops.ACT_LEAKY, slope=0.01, pre_add=term,
+                     pre_rows=plan.story_gather.csr.col)
 if which in ("spmm", "both"):
     batch = make_batch("microbench", seed=0).to(dev)
     plan = build_plan(batch)
