@@ -205,11 +205,13 @@ class VoxelBlock(nn.Module):
         H = Wm.shape[0]
         # [H, 2H+8]: [Wm | 0 | bm | 0 0 0] -- the pad keeps the row pitch a multiple of 16 bytes (vector loads)
         Wm_ext = torch.cat([F.pad(Wm, (0, 1)), bm.view(-1, 1), Wm.new_zeros(H, 3)], dim=1)
-        P = ops.MatMul.apply(Wu[:, H:2 * H], Wm_ext, False, False)              # Wu2 @ [Wm | 0 | bm]
-        Wc = P[:, :2 * H + 4] + F.pad(Wu[:, :H], (0, H + 4))
-        bc = P[:, 2 * H + 4] + bu
+        # split / one cat per result: each is ONE autograd node (a slice would cost a zero-fill + add in backward)
+        parts = Wu.split(H, dim=1)
+        P, pb, _ = ops.MatMul.apply(parts[1], Wm_ext, False, False).split([2 * H + 4, 1, 3], dim=1)   # Wu2 @ [Wm | 0 | bm]
+        Wc = P + F.pad(parts[0], (0, H + 4))
+        bc = pb.view(-1) + bu
         if self.if_agg_story_in_update:
-            return Wc, bc, torch.cat([Wu[:, 2 * H:3 * H] - Wu[:, 3 * H:], Wu[:, 3 * H:]], dim=1)
+            return Wc, bc, torch.cat([parts[2] - parts[3], parts[3]], dim=1)
         return Wc, bc, None
 
     def forward_composed(self, voxel_feature, plan, pdm4, composed):
@@ -336,8 +338,8 @@ class VoxelGNN_D(nn.Module):
             z(dl - n_lab, H2)], dim=0)
         # E [du, 2H]: what every layer adds: mean-dpos columns through Wc's position block, the bias
         E = torch.cat([z(n_feat + ML, H2), Wc[:, 2 * H2:2 * H2 + 4].t(), bc.view(1, -1), z(pad_s + dl, H2)], dim=0)
-        T3 = ops.PolyCoef.apply(Wc, X0, E, L).view(L + 1, du, H2)
-        return torch.cat([T3[:, :ds].reshape(-1, H2), T3[:, ds:].reshape(-1, H2)], dim=0)
+        Ts, Tl = ops.PolyCoef.apply(Wc, X0, E, L).view(L + 1, du, H2).split([ds, dl], dim=1)
+        return torch.cat([Ts.reshape(-1, H2), Tl.reshape(-1, H2)], dim=0)
 
     def forward_collapsed(self, feat, l, plan, pdm4):
         L = self.layer_num
@@ -361,7 +363,7 @@ class VoxelGNN_D(nn.Module):
         n_lab = labels[0].shape[1]
         dl = (n_lab + 3) // 4 * 4
         W = self.coefficients(feat.shape[1], ds, dl)
-        Ws, Wl = W[:(L + 1) * ds], W[(L + 1) * ds:]
+        Ws, Wl = W.split([(L + 1) * ds, (L + 1) * dl], dim=0)
         Zk = torch.zeros(N, L + 1, P * dl, device=feat.device)
         for p, l in enumerate(labels):
             Zk[:, 0, p * dl:p * dl + n_lab] = l.detach()
@@ -410,6 +412,18 @@ class Generator(nn.Module):
         return out, soft_out, mask, att, idx
 
 
+def pool_story_and_graph(v, plan):
+    """global_max_pool of the voxel features per story and per graph (reference models.py:262-263).
+    With no empty story the graph maximum is taken over the [S, H] story maxima (exactly the same
+    values; one pass over the voxels instead of two)."""
+    story, _ = ops.SegMax.apply(v, plan.story_seg)
+    if plan.stories_all_nonempty:
+        building, _ = ops.SegMax.apply(story, plan.story_graph_seg)
+    else:
+        building, _ = ops.SegMax.apply(v, plan.graph_seg)
+    return story, building
+
+
 class DiscriminatorVoxel(nn.Module):
     def __init__(self, voxel_input_feature_dim, voxel_input_label_dim, hidden_dim, voxel_layer, act="",
                  max_len: int = 20):
@@ -455,16 +469,20 @@ class DiscriminatorVoxel(nn.Module):
         vs, Wl, dl = gnn.collapsed_multi(feat, labels, plan, pdm4)
         B, S, N = plan.B, plan.S, plan.Nv
         # real and fake share one run of each decoder
-        pooled_s = torch.cat([ops.SegMax.apply(v, plan.story_seg)[0] for v in vs[:2]], dim=0)
-        pooled_b = torch.cat([ops.SegMax.apply(v, plan.graph_seg)[0] for v in vs[:2]], dim=0)
-        val_b, val_s = run_mlp(self.building_dec, pooled_b), run_mlp(self.story_dec, pooled_s)
-        out = [val_b[:B], val_s[:S], val_b[B:], val_s[S:]]
+        pools = [pool_story_and_graph(v, plan) for v in vs[:2]]
+        val_s = run_mlp(self.story_dec, torch.cat([pools[0][0], pools[1][0]], dim=0)).split(S, dim=0)
+        val_b = run_mlp(self.building_dec, torch.cat([pools[0][1], pools[1][1]], dim=0)).split(B, dim=0)
+        out = [val_b[0], val_s[0], val_b[1], val_s[1]]
         if label_hat is None:
             return (*out, None, None)
         n_lab, L = label_hat.shape[1], gnn.layer_num
         with torch.no_grad():
             hat_s, arg_s = ops.segmax_raw(plan.story_seg, vs[2])
-            hat_b, arg_b = ops.segmax_raw(plan.graph_seg, vs[2])
+            if plan.stories_all_nonempty:
+                hat_b, arg_sb = ops.segmax_raw(plan.story_graph_seg, hat_s)       # arg-max story of each graph ..
+                arg_b = ops.gather_arg_raw(arg_s.float(), arg_sb).to(torch.int32)  # .. and that story's arg-max voxel
+            else:
+                hat_b, arg_b = ops.segmax_raw(plan.graph_seg, vs[2])
         G = []
         for dec, pooled, arg in ((self.building_dec, hat_b, arg_b), (self.story_dec, hat_s, arg_s)):
             pooled = pooled.requires_grad_(True)
@@ -473,11 +491,13 @@ class DiscriminatorVoxel(nn.Module):
             gpool = torch.autograd.grad(val, pooled, torch.ones_like(val), create_graph=True)[0]
             G.append(ops.ScatterArg.apply(gpool, arg, N))
         X = ops.MatMul.apply(torch.cat(G, dim=0), Wl, False, True)                 # [2N, (L+1)*dl]
-        Y = X.view(2, N, L + 1, dl).permute(1, 2, 0, 3).reshape(N, L + 1, 2 * dl)
-        acc = Y[:, L]
+        # unbind: ONE backward node (a stack) for the L+1 slices instead of a zero-fill + add per slice
+        Ys = X.view(2, N, L + 1, dl).permute(1, 2, 0, 3).reshape(N, L + 1, 2 * dl).unbind(dim=1)
+        acc = Ys[L]
         for k in range(L - 1, -1, -1):
-            acc = ops.SpMMAdd.apply(acc, Y[:, k], plan.vox_mean.T)
-        return (*out, acc[:, :n_lab], acc[:, dl:dl + n_lab])
+            acc = ops.SpMMAdd.apply(acc, Ys[k], plan.vox_mean.T)
+        grad_b, _, grad_s, _ = acc.split([n_lab, dl - n_lab, n_lab, dl - n_lab], dim=1)
+        return (*out, grad_b, grad_s)
 
     def prepare(self, graph, n_label: int = NUMBER_OF_CLASS):
         """Inside shared_coefficients(): build what the collapsed passes share and that depends on
@@ -494,6 +514,5 @@ class DiscriminatorVoxel(nn.Module):
     def forward(self, graph, out_label):
         plan = build_plan(graph)
         v = self.voxelGNN_D(graph.voxel_feature, out_label, plan)
-        story, _ = ops.SegMax.apply(v, plan.story_seg)
-        building, _ = ops.SegMax.apply(v, plan.graph_seg)
+        story, building = pool_story_and_graph(v, plan)
         return run_mlp(self.building_dec, building), run_mlp(self.story_dec, story)

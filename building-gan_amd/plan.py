@@ -215,6 +215,8 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     story_graph.scatter_(0, vfc, vbi)
     ar_st = torch.arange(S, dtype=torch.int64, device=dev)
     sgr = b.csr("story_by_graph", story_graph, ar_st, B, S, counts=True)
+    b.maybe_chunks(sgr, force=True)
+    o["story_graph_seg"] = sgr                      # pooling stories -> graphs (two-level global max)
     sgr_gather = b.gather_csr(story_graph.to(torch.int32), B)
     o["graph_of_story_mean"] = LinOp.pair(sgr, sgr_gather, sgr.count, SCALE_DIV)
     o["story_graph_gather"] = LinOp.pair(sgr_gather, sgr)
@@ -241,10 +243,11 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
 
     def _min_len(c):
         return (c.rowptr[1:] - c.rowptr[:-1]).min() if c.n_rows > 0 else torch.ones((), dtype=torch.int32, device=dev)
-    extra = torch.stack([lvl_max.to(torch.int32), _min_len(vfw), _min_len(pf), _min_len(cv)])
-    flags, (max_level, min_vdeg, min_pdeg, min_cross) = b.finish(extra)
+    extra = torch.stack([lvl_max.to(torch.int32), _min_len(vfw), _min_len(pf), _min_len(cv), _min_len(st)])
+    flags, (max_level, min_vdeg, min_pdeg, min_cross, min_story) = b.finish(extra)
     o["max_level"] = int(max_level)
     o["vox_all_has"], o["prog_all_has"] = min_vdeg > 0, min_pdeg > 0
+    o["stories_all_nonempty"] = min_story > 0       # then max over a graph = max over its stories' maxima
     for name, fl in flags.items():
         bad = fl[0]
         if bad:
