@@ -413,13 +413,22 @@ class LinearCat(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not ctx.inputs_only:
             gb = ColSum.apply(g)
         gxs: List[Optional[torch.Tensor]] = [None] * len(xs)
-        if any(ctx.needs_input_grad[7:]):
-            gx = MatMul.apply(g, W, False, ctx.w_t)
-            off = 0
-            for i, wdt in enumerate(ctx.widths):
-                if ctx.needs_input_grad[7 + i]:
-                    gxs[i] = gx[:, off:off + wdt]
-                off += wdt
+        need = [i for i in range(len(xs)) if ctx.needs_input_grad[7 + i]]
+        if need:
+            # only the column range that covers the segments wanting a gradient (data segments such as
+            # the position terms sit at the end: one column tile less)
+            offs = [0]
+            for wdt in ctx.widths:
+                offs.append(offs[-1] + wdt)
+            lo, hi = offs[need[0]], offs[need[-1] + 1]
+            Wsub = W if (lo == 0 and hi == offs[-1]) else (W[lo:hi] if ctx.w_t else W[:, lo:hi])
+            gx = MatMul.apply(g, Wsub, False, ctx.w_t)
+            if len(need) == 1:
+                gxs[need[0]] = gx
+            else:
+                parts = gx.split([offs[i + 1] - offs[i] for i in range(need[0], need[-1] + 1)], dim=1)
+                for i in need:
+                    gxs[i] = parts[i - need[0]]
         return (gW, gb, None, None, None, g_res, g_pre, *gxs)
 
 
