@@ -479,6 +479,92 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs g) {
     if (col < g.N) store_tile(g, acc, m0 + wm * 32 + 4 * h, col, g.bias ? g.bias[col] : 0.f);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Skinny products (a few dozen output tiles, K of a few hundred: the coefficient recurrence of the
+// collapsed discriminator, the program GNN, per-story terms).  With so few tiles a workgroup per 64x64
+// tile leaves most CUs idle and walks its K steps one memory round trip at a time.  Here a workgroup
+// owns a 32x32 tile, its four waves split K between them in groups of 8, fragments go global ->
+// registers in the MFMA layout (no LDS staging, no barrier in the K loop, up to GB groups = 2*GB
+// 16-byte loads per lane in flight), and the four partial tiles are summed through LDS.
+template <bool B_KC, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gemm_skinny(GemmArgs g) {
+    constexpr int GB = 8;
+    __shared__ float red[NW][32 * 33];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bx = blockIdx.x % g.gx, by = blockIdx.x / g.gx;
+    const int64_t m0 = (int64_t)by * 32, n0 = (int64_t)bx * 32;
+    const int64_t arow = m0 + r < g.M ? m0 + r : g.M - 1;       // edge rows / columns: any valid one, never stored
+    const int64_t bcol = n0 + r < g.N ? n0 + r : g.N - 1;
+
+    int n_groups = 0;
+    for (int s = 0; s < g.n_seg; ++s) n_groups += (int)((g.Ks[s] + 7) >> 3);
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+
+    for (int g0 = wave; g0 < n_groups; g0 += NW * GB) {
+        float4 af[GB], bf[GB];
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+            int gi = g0 + NW * j, seg = 0;
+            int64_t koff = 0;
+            af[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bf[j] = af[j];
+            if (gi < n_groups) {
+                while (seg < g.n_seg - 1) {                       // wave-uniform walk over <= 4 segments
+                    const int ng = (int)((g.Ks[seg] + 7) >> 3);
+                    if (gi < ng) break;
+                    gi -= ng; koff += g.Ks[seg]; ++seg;
+                }
+                const int64_t k = 8 * (int64_t)gi + 4 * h;
+                if (k < g.Ks[seg]) {                              // K_s % 4 == 0: a 4-chunk is all in or all out
+                    af[j] = bg_ld4(g.A[seg] + arow * g.lda[seg] + k);
+                    if (B_KC) {
+                        bf[j] = bg_ld4(g.B + bcol * g.ldb + koff + k);
+                    } else {
+                        const float* bp = g.B + (koff + k) * g.ldb + bcol;
+                        bf[j] = make_float4(bp[0], bp[g.ldb], bp[2 * g.ldb], bp[3 * g.ldb]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].z, bf[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].w, bf[j].w, acc, 0, 0, 0);
+        }
+    }
+    // lane holds column r, rows (q&3) + 8*(q>>2) + 4*h
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[wave][((q & 3) + 8 * (q >> 2) + 4 * h) * 33 + r] = acc[q];
+    __syncthreads();
+    const int col_l = threadIdx.x & 31;
+    const int64_t col = n0 + col_l;
+    if (col >= g.N) return;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16 / NW; ++j) {
+        const int row_l = (threadIdx.x >> 5) + 2 * NW * j;
+        const int64_t row = m0 + row_l;
+        if (row >= g.M) continue;
+        const int o = row_l * 33 + col_l;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][o];
+        v += bv;
+        if (g.row_scale) v *= g.row_scale[row];
+        if (g.pre_add) v += g.pre_add[(g.pre_rows ? (int64_t)g.pre_rows[row] : row) * g.ldp + col];
+        if (g.act == BG_ACT_LEAKY) v = v > 0.f ? v : v * g.slope;
+        if (g.residual) v += g.residual[row * g.ldr + col];
+        g.C[row * g.ldc + col] = v;
+    }
+}
+
 __global__ void k_splitk_reduce(const float* __restrict__ partial, int splits, int64_t M, int64_t N,
                                 float* __restrict__ C, int64_t ldc) {
     // one float4 of C per thread (M*N % 4 == 0 checked by the launcher), splits added in order
@@ -621,6 +707,36 @@ int launch_gemm_dma(int transB, GemmArgs g, hipStream_t s) {
     return BG_OK;
 }
 
+// tuning hook: BG_GEMM_SKINNY=0 disables the 32x32-tile split-wave kernel
+int skinny_mode() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char* e = getenv("BG_GEMM_SKINNY");
+        cached = e ? (atoi(e) != 0) : 1;
+    }
+    return cached;
+}
+
+int launch_gemm_skinny(int transB, GemmArgs g, hipStream_t s) {
+    g.gx = (int)((g.N + 31) / 32);
+    g.gy = (int)((g.M + 31) / 32);
+    const unsigned blocks = (unsigned)(g.gx * g.gy);
+    int groups = 0;
+    for (int i = 0; i < g.n_seg; ++i) groups += (int)((g.Ks[i] + 7) >> 3);
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("BG_GEMM_SKINNY_WAVES"); force = e ? atoi(e) : 0; }
+    const bool wide = force ? force == 8 : groups > 32;      // K > 256: eight waves share it, one load round each
+    if (wide) {
+        if (transB) k_gemm_skinny<true, 8><<<blocks, 512, 0, s>>>(g);
+        else k_gemm_skinny<false, 8><<<blocks, 512, 0, s>>>(g);
+    } else {
+        if (transB) k_gemm_skinny<true, 4><<<blocks, 256, 0, s>>>(g);
+        else k_gemm_skinny<false, 4><<<blocks, 256, 0, s>>>(g);
+    }
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
 bool operand_vec_ok(const float* p, int64_t ld, bool kc, int64_t K, int64_t rows) {
     if (!bg_aligned16(p) || ld % 4 != 0) return false;
     return kc ? (K % 4 == 0) : (rows % 4 == 0);
@@ -707,6 +823,14 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
     g.residual = residual; g.ldr = ldr; g.M = M; g.N = N;
     g.total_steps = steps; g.steps_per_split = steps; g.partial = nullptr;
     hipStream_t st = (hipStream_t)stream;
+    // few tiles and a moderate K: one 32x32 tile per workgroup, K split over its waves (needs the
+    // 16-byte path on A; B is read by 16-byte chunks when K-contiguous, by dwords otherwise)
+    if (tile_override() == 0 && !transA && vec && skinny_mode() && Ktot <= 4096 &&
+        ((M + 31) / 32) * ((N + 31) / 32) <= 256) {
+        bool nonempty = true;
+        for (int s = 0; s < n_seg; ++s) nonempty = nonempty && Ks[s] > 0;
+        if (nonempty) return launch_gemm_skinny(transB, g, st);
+    }
     if (dma && vec) {
         switch (dma) {
             case 2: return launch_gemm_dma<2>(transB, g, st);
