@@ -717,6 +717,16 @@ int skinny_mode() {
     return cached;
 }
 
+// tuning hook: BG_GEMM_SKINNY_TILES = largest 32x32-tile count that still takes the skinny kernel
+int skinny_max_tiles() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char* e = getenv("BG_GEMM_SKINNY_TILES");
+        cached = e ? atoi(e) : 256;
+    }
+    return cached;
+}
+
 int launch_gemm_skinny(int transB, GemmArgs g, hipStream_t s) {
     g.gx = (int)((g.N + 31) / 32);
     g.gy = (int)((g.M + 31) / 32);
@@ -826,7 +836,7 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
     // few tiles and a moderate K: one 32x32 tile per workgroup, K split over its waves (needs the
     // 16-byte path on A; B is read by 16-byte chunks when K-contiguous, by dwords otherwise)
     if (tile_override() == 0 && !transA && vec && skinny_mode() && Ktot <= 4096 &&
-        ((M + 31) / 32) * ((N + 31) / 32) <= 256) {
+        ((M + 31) / 32) * ((N + 31) / 32) <= skinny_max_tiles()) {
         bool nonempty = true;
         for (int s = 0; s < n_seg; ++s) nonempty = nonempty && Ks[s] > 0;
         if (nonempty) return launch_gemm_skinny(transB, g, st);
