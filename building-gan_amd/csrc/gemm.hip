@@ -584,6 +584,34 @@ __global__ void k_splitk_reduce(const float* __restrict__ partial, int splits, i
     for (int j = 0; j < 4; ++j) C[((t + j) / N) * ldc + ((t + j) % N)] = v[j];
 }
 
+// Few outputs, many splits (weight gradients of the narrow layers): the serial walk over the splits is the
+// whole cost, so 16 waves share it -- wave w adds splits w, w+16, .. for 64 consecutive outputs, the 16
+// partial sums are combined through LDS in wave order (deterministic).
+__global__ __launch_bounds__(1024) void k_splitk_reduce_small(const float* __restrict__ partial, int splits,
+                                                              int64_t M, int64_t N, float* __restrict__ C, int64_t ldc) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t MN = M * N, t = (int64_t)blockIdx.x * 64 + lane;
+    float acc = 0.f;
+    if (t < MN) {
+        int z = wave;
+        for (; z + 48 < splits; z += 64) {
+            const float a = partial[(int64_t)z * MN + t], b = partial[(int64_t)(z + 16) * MN + t];
+            const float c = partial[(int64_t)(z + 32) * MN + t], d = partial[(int64_t)(z + 48) * MN + t];
+            acc += a; acc += b; acc += c; acc += d;
+        }
+        for (; z < splits; z += 16) acc += partial[(int64_t)z * MN + t];
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && t < MN) {
+        float v = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) v += red[w][lane];
+        C[(t / N) * ldc + (t % N)] = v;
+    }
+}
+
 __global__ void k_splitk_reduce_scalar(const float* __restrict__ partial, int splits, int64_t M, int64_t N,
                                        float* __restrict__ C, int64_t ldc) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -894,7 +922,9 @@ int bg_gemm_tn_splitk_f32(int64_t M, int64_t R, const float* A, int64_t lda,
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_gemm<64, 64, 32, true>(1, 0, vec, g, splits, st, n_tiles);
     if (rc != BG_OK) return rc;
-    if ((M * N) % 4 == 0 && bg_aligned16(partial))
+    if (M * N <= 65536 && splits >= 32)
+        k_splitk_reduce_small<<<bg_grid_for(M * N, 64, 0x7fffffff), 1024, 0, st>>>(partial, splits, M, N, C, ldc);
+    else if ((M * N) % 4 == 0 && bg_aligned16(partial))
         k_splitk_reduce<<<bg_grid_for((M * N) / 4, 256, 0x7fffffff), 256, 0, st>>>(partial, splits, M, N, C, ldc);
     else
         k_splitk_reduce_scalar<<<bg_grid_for(M * N, 256, 0x7fffffff), 256, 0, st>>>(partial, splits, M, N, C, ldc);

@@ -399,7 +399,10 @@ class LinearCat(torch.autograd.Function):
         W, row_scale, act_out, *xs = ctx.saved_tensors
         g_res = g if ctx.has_res and ctx.needs_input_grad[5] else None
         if ctx.act == ACT_LEAKY:
-            g = torch.where(act_out > 0, g, g * ctx.slope)
+            if torch.is_grad_enabled():
+                g = torch.where(act_out > 0, g, g * ctx.slope)                        # differentiable form
+            else:
+                g = torch.ops.aten.leaky_relu_backward(g, act_out, ctx.slope, True)   # one launch; input = the result
         g_pre = g if ctx.has_pre and ctx.needs_input_grad[6] else None
         if g_pre is not None and ctx.pre_op is not None:
             g_pre = SpMM.apply(g_pre, ctx.pre_op.T)          # transpose of the fused gather: sum over each group
