@@ -224,8 +224,8 @@ class VoxelBlock(nn.Module):
         building = SpMM.apply(SpMM.apply(story, plan.graph_of_story_mean), plan.story_graph_gather)   # [S, H]
         # (Wu3 - Wu4) story + Wu4 building, evaluated per STORY; the product's epilogue gathers it to the voxels
         term = linear([story, building], Wsb)
-        return voxel_feature + linear([voxel_feature, gm, pdm4], Wc, bc, ACT_LEAKY, 0.01, pre_add=term,
-                                      pre_gather=plan.story_gather)
+        return linear([voxel_feature, gm, pdm4], Wc, bc, ACT_LEAKY, 0.01, pre_add=term, pre_gather=plan.story_gather,
+                      residual=voxel_feature)
 
     def forward(self, voxel_feature, plan, pdm4):
         H = voxel_feature.shape[1]

@@ -372,7 +372,9 @@ class LinearCat(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, W, b, act, slope, row_scale, residual, pre_add, *xs):
-        fuse_res = residual if act != ACT_LEAKY else None
+        # the residual can ride in the epilogue unless a backward will need the activation's own sign
+        no_backward = not any(ctx.needs_input_grad)
+        fuse_res = residual if (act != ACT_LEAKY or no_backward) else None
         w_t = isinstance(act, tuple)            # (act, "t"): W is stored [K, out] instead of [out, K]
         if w_t:
             act = act[0]
@@ -389,7 +391,7 @@ class LinearCat(torch.autograd.Function):
         ctx.widths = [x.shape[1] for x in xs]
         # leaky(z) has the sign of z: the activation's output doubles as the mask for the backward
         act_out = y if act == ACT_LEAKY else None
-        if act == ACT_LEAKY and residual is not None:
+        if residual is not None and fuse_res is None:
             y = y + residual
         ctx.save_for_backward(W, row_scale, act_out, *xs)
         return y

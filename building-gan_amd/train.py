@@ -143,7 +143,7 @@ class Trainer:
         gp_s = ((grad_s.norm(2, 1) - 1) ** 2).sum() / Nv_g
         return gp_b + gp_s
 
-    def _phase_d(self, batch, counts, do_d, program_z=None, voxel_z=None, noise=None, u=None):
+    def _phase_d(self, batch, counts, do_d, program_z=None, voxel_z=None, noise=None, u=None, g_update=True):
         """train.py:80-99: generator forward, discriminator losses, d_loss.backward()."""
         G, D = self.generator, self.discriminator
         dev = self.device
@@ -171,7 +171,9 @@ class Trainer:
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     D.prepare(batch)
-            gen = G(batch, program_z, voxel_z, noise)
+            # the generator's autograd graph is only needed when its own update follows (train.py:106-113)
+            with contextlib.nullcontext() if g_update else torch.no_grad():
+                gen = G(batch, program_z, voxel_z, noise)
             if side is not None:
                 cur.wait_stream(side)
             out, soft_out = gen[0], gen[1]
@@ -221,7 +223,7 @@ class Trainer:
         """Iteration ``i`` of an epoch (reference train.py:74-114).  Returns a dict of detached losses."""
         counts = global_counts(batch, self.group)
         do_d = i % self.n_critic_d == 0
-        gen, stats = self._phase_d(batch, counts, do_d, program_z, voxel_z, noise, u)
+        gen, stats = self._phase_d(batch, counts, do_d, program_z, voxel_z, noise, u, g_update=i % self.n_critic_g == 0)
         if do_d:
             self.opt_d.all_reduce(self.group)
             self.opt_d.step()
@@ -275,7 +277,7 @@ class Trainer:
         gC, _ = cap(lambda: self.opt_g.step())
         graphs["with_g"] = (gA, gB, gC, {**statsA, **statsB})
         # iteration WITHOUT generator update
-        gA2, (gen2, statsA2) = cap(lambda: self._phase_d(batch, counts, True))
+        gA2, (gen2, statsA2) = cap(lambda: self._phase_d(batch, counts, True, g_update=False))
         gB2, _ = cap(lambda: self.opt_d.step())
         graphs["no_g"] = (gA2, gB2, statsA2)
         self._graphs = graphs
