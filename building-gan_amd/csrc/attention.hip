@@ -144,11 +144,11 @@ __global__ void k_seg_argmax(const float* __restrict__ logit, const int32_t* __r
 // Two-way Gumbel-softmax of the attention's voxel mask (reference models.py:109-111):
 //   z = logits - log(expn);  soft = softmax(z);  hard = (onehot(argmax soft) - soft) + soft;
 // only column 0 of either is used downstream.  One thread per voxel.
-__global__ void k_mask_gumbel(const float* __restrict__ logits, const float* __restrict__ expn,
+__global__ void k_mask_gumbel(const float* __restrict__ logits, int64_t ldl, const float* __restrict__ expn,
                               float* __restrict__ soft0, float* __restrict__ hard0, int64_t n) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
-    const float2 l = *reinterpret_cast<const float2*>(logits + 2 * v);
+    const float2 l = make_float2(logits[v * ldl], logits[v * ldl + 1]);
     const float2 e = *reinterpret_cast<const float2*>(expn + 2 * v);
     const float z0 = l.x - logf(e.x), z1 = l.y - logf(e.y);
     const float m = fmaxf(z0, z1);
@@ -244,12 +244,12 @@ int bg_seg_argmax_f32(const float* logit, const int32_t* rowptr, int32_t* arg, i
     return BG_OK;
 }
 
-int bg_mask_gumbel_f32(const float* logits, const float* expn, float* soft0, float* hard0, int64_t n,
+int bg_mask_gumbel_f32(const float* logits, int64_t ldl, const float* expn, float* soft0, float* hard0, int64_t n,
                        bgStream stream) {
     if (n < 0) return BG_ERR_ARG;
     if (n == 0) return BG_OK;
-    if (!logits || !expn || !soft0 || !hard0) return BG_ERR_ARG;
-    k_mask_gumbel<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(logits, expn, soft0, hard0, n);
+    if (!logits || !expn || !soft0 || !hard0 || ldl < 2) return BG_ERR_ARG;
+    k_mask_gumbel<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(logits, ldl, expn, soft0, hard0, n);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

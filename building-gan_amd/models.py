@@ -154,16 +154,38 @@ class Attention(nn.Module):
         a = math.sqrt(6.0 / (1 + hidden_dim))          # torch_geometric inits.glorot
         nn.init.uniform_(self.theta, -a, a)
 
-    def forward(self, program_graph_feature, voxel_feature, plan, noise=None):
+    def shared_terms(self, program_graph_feature):
+        """What the calls of one generator forward have in common (the module and the program features are
+        the same in all of them, reference models.py:194,201):
+          * NN_p(program features), evaluated once instead of once per call;
+          * ONE weight for everything that reads the voxel features: the mask decoder has no activation
+            (models.py:98), so its two Linears are the [2, H] map W2 W1 with bias W2 b1 + b2, stacked under
+            NN_v's [H, H] (rows padded to a multiple of 4).  A call then runs one GEMM instead of three."""
+        b = linear(program_graph_feature, self.NN_p.weight, self.NN_p.bias)
+        mods = [m for m in self.dec if isinstance(m, nn.Linear)]
+        if len(mods) != len(self.dec) or len(mods) != 2:
+            return b, None, None
+        W1, b1, W2, b2 = mods[0].weight, mods[0].bias, mods[1].weight, mods[1].bias
+        Wd = ops.MatMul.apply(W2, W1, False, False)                                    # [2, H]
+        bd = torch.addmv(b2, W2, b1)
+        H = self.NN_v.weight.shape[0]
+        Wcat = torch.cat([self.NN_v.weight, Wd, Wd.new_zeros(2, W1.shape[1])], dim=0)  # [H + 4, H]
+        bcat = torch.cat([self.NN_v.bias, bd, bd.new_zeros(2)])
+        return b, Wcat, bcat
+
+    def forward(self, program_graph_feature, voxel_feature, plan, noise=None, shared=None):
         exp_mask, exp_att = (None, None) if noise is None else noise
-        logits = run_mlp(self.dec, voxel_feature)
+        b, Wcat, bcat = shared if shared is not None else self.shared_terms(program_graph_feature)
+        if Wcat is not None:
+            H = self.NN_v.weight.shape[0]
+            a, logits, _ = linear(voxel_feature, Wcat, bcat).split([H, 2, 2], dim=1)
+        else:
+            logits = run_mlp(self.dec, voxel_feature)
+            a = linear(voxel_feature, self.NN_v.weight, self.NN_v.bias)
         if exp_mask is None:
-            exp_mask = torch.empty_like(logits).exponential_()
+            exp_mask = torch.empty(logits.shape, dtype=logits.dtype, device=logits.device).exponential_()
         soft0, hard0 = ops.MaskGumbel.apply(logits, exp_mask)
         out_mask = {"hard": hard0, "soft": soft0}
-
-        a = linear(voxel_feature, self.NN_v.weight, self.NN_v.bias)
-        b = linear(program_graph_feature, self.NN_p.weight, self.NN_p.bias)
         att = ops.CrossLogits.apply(a, b, self.theta, plan)
         if exp_att is None:
             exp_att = torch.empty_like(att).exponential_()
@@ -256,7 +278,8 @@ class VoxelGNN_G(nn.Module):
         pdm4 = _pos_terms(plan, pos)
         v = run_mlp(self.enc, torch.cat((v, z), dim=-1) if self.noise_dim != 0 else v)
         v = v + ops.spmm_raw(_level_op(plan, self.pe.shape[0]), self.pe)
-        _, _, v = self.attention(x, v, plan, None if draws is None else next(draws))
+        shared = self.attention.shared_terms(x)
+        _, _, v = self.attention(x, v, plan, None if draws is None else next(draws), shared)
         out_mask = out_att = None
         composed = self.block.compose() if (COMPOSE_BLOCKS and plan.vox_all_has) else None
         for i in range(self.layer_num):
@@ -265,7 +288,7 @@ class VoxelGNN_G(nn.Module):
             else:
                 v = v + self.block(v, plan, pdm4)
             if i % 2 == 0 and i != 0:
-                out_mask, out_att, v = self.attention(x, v, plan, None if draws is None else next(draws))
+                out_mask, out_att, v = self.attention(x, v, plan, None if draws is None else next(draws), shared)
         return out_mask, out_att, v
 
 

@@ -575,13 +575,14 @@ class MaskGumbel(torch.autograd.Function):
     def forward(ctx, logits, expn):
         lib = _lib.load()
         _lib.require_device(logits, "mask_gumbel")
-        l2, e2 = _f32c(logits).contiguous(), _f32c(expn).contiguous()
+        l2, e2 = _f32c(logits), _f32c(expn).contiguous()          # logits may be a column slice (row pitch)
         n = l2.shape[0]
         if l2.shape[1] != 2 or tuple(e2.shape) != tuple(l2.shape):
             raise _lib.BganError("mask_gumbel: logits and noise must both be [n, 2]")
         soft0 = torch.empty(n, 1, dtype=torch.float32, device=logits.device)
         hard0 = torch.empty(n, 1, dtype=torch.float32, device=logits.device)
-        check(lib.bg_mask_gumbel_f32(ptr(l2), ptr(e2), ptr(soft0), ptr(hard0), n, stream()), "bg_mask_gumbel_f32")
+        check(lib.bg_mask_gumbel_f32(ptr(l2), _ld(l2), ptr(e2), ptr(soft0), ptr(hard0), n, stream()),
+              "bg_mask_gumbel_f32")
         ctx.save_for_backward(soft0)
         return soft0, hard0
 

@@ -161,11 +161,11 @@ int bg_seg_argmax_f32(const float* logit, const int32_t* rowptr, int32_t* arg, i
                       bgStream stream);
 
 /* Two-way Gumbel-softmax of the voxel mask, column 0 of the soft and of the straight-through hard
- * output: z = logits - log(expn) ([n,2] each, Exp(1) noise), soft = softmax(z),
+ * output: z = logits - log(expn) (logits [n,2] with row pitch ldl, Exp(1) noise [n,2]), soft = softmax(z),
  * hard = (onehot(first argmax of soft) - soft) + soft.
  * replaces: Model/models.py:109-111 (torch.nn.functional.gumbel_softmax + util.py:6-10
  * softmax_to_hard on the mask decoder's logits).                                              */
-int bg_mask_gumbel_f32(const float* logits, const float* expn, float* soft0, float* hard0, int64_t n,
+int bg_mask_gumbel_f32(const float* logits, int64_t ldl, const float* expn, float* soft0, float* hard0, int64_t n,
                        bgStream stream);
 
 /* d_logits [n,2] of <g_soft, soft0> + <g_hard, hard0>; either gradient may be NULL.            */
