@@ -138,6 +138,8 @@ struct ChunkArgs {
     const float* edge_w; const int32_t* eperm;
     const int32_t* chunk_ptr; int32_t R; int64_t n_rows;
     float* partial; int32_t* partial_arg; int H;
+    // direct mode (chunk_ptr == nullptr): one workgroup per ROW, final result written here
+    float* out; int64_t ldo; int32_t* arg; const float* row_scale; int row_mode;
 };
 
 // binary search: the row r with chunk_ptr[r] <= c < chunk_ptr[r+1]
@@ -159,10 +161,11 @@ __global__ __launch_bounds__(256) void k_chunk_reduce(ChunkArgs a, int lpr, int 
     __shared__ float4 sval[256];
     __shared__ int4 sarg[IS_MAX ? 256 : 1];
     const int32_t c = blockIdx.x;
-    if (c >= a.chunk_ptr[a.n_rows]) return;
-    const int64_t row = row_of_chunk(a.chunk_ptr, a.n_rows, c);
-    const int32_t k0 = a.rowptr[row] + (c - a.chunk_ptr[row]) * a.R;
-    const int32_t k1 = min(k0 + a.R, a.rowptr[row + 1]);
+    const bool direct = a.chunk_ptr == nullptr;
+    if (!direct && c >= a.chunk_ptr[a.n_rows]) return;
+    const int64_t row = direct ? (int64_t)c : row_of_chunk(a.chunk_ptr, a.n_rows, c);
+    const int32_t k0 = direct ? a.rowptr[row] : a.rowptr[row] + (c - a.chunk_ptr[row]) * a.R;
+    const int32_t k1 = direct ? a.rowptr[row + 1] : min(k0 + a.R, a.rowptr[row + 1]);
     const int spb = 256 / lpr;
     const int sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
     const int H4 = (a.H - hoff) / 4 < 64 ? (a.H - hoff) / 4 : 64;
@@ -221,15 +224,27 @@ __global__ __launch_bounds__(256) void k_chunk_reduce(ChunkArgs a, int lpr, int 
                 acc = bg_add4(acc, v);
             }
         }
-        float* po = a.partial + (int64_t)c * a.H + hoff + 4 * sub;
-        bg_st4(po, acc);
+        int4 r = make_int4(-1, -1, -1, -1);
         if (IS_MAX) {
-            int4 r;
             r.x = ak.x == 0x7fffffff ? -1 : (a.col ? a.col[ak.x] : ak.x);
             r.y = ak.y == 0x7fffffff ? -1 : (a.col ? a.col[ak.y] : ak.y);
             r.z = ak.z == 0x7fffffff ? -1 : (a.col ? a.col[ak.z] : ak.z);
             r.w = ak.w == 0x7fffffff ? -1 : (a.col ? a.col[ak.w] : ak.w);
-            *reinterpret_cast<int4*>(a.partial_arg + (int64_t)c * a.H + hoff + 4 * sub) = r;
+        }
+        if (direct) {
+            if (IS_MAX) {                       // an empty segment gives 0 and arg -1
+                acc.x = r.x >= 0 ? acc.x : 0.f; acc.y = r.y >= 0 ? acc.y : 0.f;
+                acc.z = r.z >= 0 ? acc.z : 0.f; acc.w = r.w >= 0 ? acc.w : 0.f;
+                *reinterpret_cast<int4*>(a.arg + row * a.H + hoff + 4 * sub) = r;
+            } else if (a.row_mode) {
+                const float sc = a.row_scale[row];
+                acc.x = apply_scale(acc.x, sc, a.row_mode); acc.y = apply_scale(acc.y, sc, a.row_mode);
+                acc.z = apply_scale(acc.z, sc, a.row_mode); acc.w = apply_scale(acc.w, sc, a.row_mode);
+            }
+            bg_st4(a.out + row * a.ldo + hoff + 4 * sub, acc);
+        } else {
+            bg_st4(a.partial + (int64_t)c * a.H + hoff + 4 * sub, acc);
+            if (IS_MAX) *reinterpret_cast<int4*>(a.partial_arg + (int64_t)c * a.H + hoff + 4 * sub) = r;
         }
     }
 }
@@ -262,8 +277,10 @@ __global__ __launch_bounds__(256) void k_chunk_reduce_scalar(ChunkArgs a) {
 
 template <bool IS_MAX>
 int launch_chunk_reduce(const ChunkArgs& a, int64_t n_chunks_ub, hipStream_t s) {
-    bool vec = (a.H % 4 == 0) && (a.ldx % 4 == 0) && bg_aligned16(a.x) && bg_aligned16(a.partial) &&
-               (!IS_MAX || bg_aligned16(a.partial_arg));
+    bool vec = (a.H % 4 == 0) && (a.ldx % 4 == 0) && bg_aligned16(a.x);
+    if (a.chunk_ptr) vec = vec && bg_aligned16(a.partial) && (!IS_MAX || bg_aligned16(a.partial_arg));
+    else vec = vec && bg_aligned16(a.out) && (a.ldo % 4 == 0) && (!IS_MAX || bg_aligned16(a.arg));
+    if (!vec && !a.chunk_ptr) return BG_ERR_ALIGN;      // the one-launch form has no scalar fallback
     if (!vec) {
         k_chunk_reduce_scalar<IS_MAX><<<(int)n_chunks_ub, 256, 0, s>>>(a);
         BG_LAUNCH_CHECK();
@@ -397,11 +414,18 @@ int bg_segreduce_sum_f32(const float* x, int64_t ldx, const int32_t* rowptr, con
                          bgStream stream) {
     if (n_rows < 0 || H < 0 || n_chunks_ub < 0) return BG_ERR_ARG;
     if (n_rows == 0 || H == 0) return BG_OK;
-    if (!x || !rowptr || !chunk_ptr || !out || rows_per_chunk <= 0 || ldx < H || ldo < H) return BG_ERR_ARG;
-    if ((row_mode && !row_scale) || (eperm && !edge_w) || (n_chunks_ub > 0 && !partial)) return BG_ERR_ARG;
+    if (!x || !rowptr || !out || ldx < H || ldo < H) return BG_ERR_ARG;
+    if ((row_mode && !row_scale) || (eperm && !edge_w)) return BG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (!chunk_ptr) {      // one launch: a workgroup per row writes the scaled sum (rows of moderate length)
+        ChunkArgs a{x, ldx, rowptr, col, edge_w, eperm, nullptr, 0, n_rows, nullptr, nullptr, (int)H,
+                    out, ldo, nullptr, row_scale, row_mode};
+        return launch_chunk_reduce<false>(a, n_rows, s);
+    }
+    if (rows_per_chunk <= 0 || (n_chunks_ub > 0 && !partial)) return BG_ERR_ARG;
     if (n_chunks_ub > 0) {
-        ChunkArgs a{x, ldx, rowptr, col, edge_w, eperm, chunk_ptr, rows_per_chunk, n_rows, partial, nullptr, (int)H};
+        ChunkArgs a{x, ldx, rowptr, col, edge_w, eperm, chunk_ptr, rows_per_chunk, n_rows, partial, nullptr, (int)H,
+                    nullptr, 0, nullptr, nullptr, 0};
         int rc = launch_chunk_reduce<false>(a, n_chunks_ub, s);
         if (rc != BG_OK) return rc;
     }
@@ -417,11 +441,17 @@ int bg_segmax_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int3
                   float* out, int64_t ldo, int32_t* arg, int64_t n_rows, int64_t H, bgStream stream) {
     if (n_rows < 0 || H < 0 || n_chunks_ub < 0) return BG_ERR_ARG;
     if (n_rows == 0 || H == 0) return BG_OK;
-    if (!x || !rowptr || !chunk_ptr || !out || !arg || rows_per_chunk <= 0 || ldx < H || ldo < H) return BG_ERR_ARG;
-    if (n_chunks_ub > 0 && (!partial_val || !partial_arg)) return BG_ERR_ARG;
+    if (!x || !rowptr || !out || !arg || ldx < H || ldo < H) return BG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (!chunk_ptr) {
+        ChunkArgs a{x, ldx, rowptr, col, nullptr, nullptr, nullptr, 0, n_rows, nullptr, nullptr, (int)H,
+                    out, ldo, arg, nullptr, 0};
+        return launch_chunk_reduce<true>(a, n_rows, s);
+    }
+    if (rows_per_chunk <= 0 || (n_chunks_ub > 0 && (!partial_val || !partial_arg))) return BG_ERR_ARG;
     if (n_chunks_ub > 0) {
-        ChunkArgs a{x, ldx, rowptr, col, nullptr, nullptr, chunk_ptr, rows_per_chunk, n_rows, partial_val, partial_arg, (int)H};
+        ChunkArgs a{x, ldx, rowptr, col, nullptr, nullptr, chunk_ptr, rows_per_chunk, n_rows, partial_val, partial_arg, (int)H,
+                    nullptr, 0, nullptr, nullptr, 0};
         int rc = launch_chunk_reduce<true>(a, n_chunks_ub, s);
         if (rc != BG_OK) return rc;
     }

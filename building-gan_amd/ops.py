@@ -54,6 +54,11 @@ def _ld(t: torch.Tensor) -> int:
 
 
 # ------------------------------------------------------------------------------- raw launchers
+def _vec_ok(*ts) -> bool:
+    """16-byte path: width % 4 == 0, aligned base, pitch % 4 == 0."""
+    return all(t.shape[-1] % 4 == 0 and t.data_ptr() % 16 == 0 and _ld(t) % 4 == 0 for t in ts)
+
+
 def spmm_raw(op: LinOp, x: torch.Tensor, edge_w: Optional[torch.Tensor] = None,
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
@@ -72,7 +77,11 @@ def spmm_raw(op: LinOp, x: torch.Tensor, edge_w: Optional[torch.Tensor] = None,
         if edge_w.numel() != c.nnz:
             raise _lib.BganError("spmm: edge weight count does not match the plan")
         eperm = c.perm
-    if c.long_rows and op.col_mode == SCALE_NONE:
+    if c.row_per_workgroup and op.col_mode == SCALE_NONE and _vec_ok(x2, out):
+        check(lib.bg_segreduce_sum_f32(ptr(x2), _ld(x2), ptr(c.rowptr), ptr(c.col), ptr(edge_w), ptr(eperm),
+                                       ptr(op.row_scale), op.row_mode, None, 0, 0, None, ptr(out), _ld(out),
+                                       c.n_rows, H, stream()), "bg_segreduce_sum_f32")
+    elif c.long_rows and op.col_mode == SCALE_NONE:
         partial = torch.empty(c.n_chunks_ub, H, dtype=torch.float32, device=x.device)
         check(lib.bg_segreduce_sum_f32(ptr(x2), _ld(x2), ptr(c.rowptr), ptr(c.col), ptr(edge_w), ptr(eperm),
                                        ptr(op.row_scale), op.row_mode, ptr(c.chunk_ptr), c.rows_per_chunk,
@@ -126,6 +135,10 @@ def segmax_raw(c: Csr, x: torch.Tensor):
     dev = x.device
     out = torch.empty(c.n_rows, H, dtype=torch.float32, device=dev)
     arg = torch.empty(c.n_rows, H, dtype=torch.int32, device=dev)
+    if c.row_per_workgroup and _vec_ok(x2):
+        check(lib.bg_segmax_f32(ptr(x2), _ld(x2), ptr(c.rowptr), ptr(c.col), None, 0, 0, None, None, ptr(out), H,
+                                ptr(arg), c.n_rows, H, stream()), "bg_segmax_f32")
+        return out, arg
     pv = torch.empty(c.n_chunks_ub, H, dtype=torch.float32, device=dev)
     pa = torch.empty(c.n_chunks_ub, H, dtype=torch.int32, device=dev)
     check(lib.bg_segmax_f32(ptr(x2), _ld(x2), ptr(c.rowptr), ptr(c.col), ptr(c.chunk_ptr), c.rows_per_chunk,

@@ -8,6 +8,7 @@ torch_geometric call (index_select + scatter pairs, ``torch.unique`` in avg_pool
 """
 from __future__ import annotations
 
+import dataclasses
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -33,10 +34,17 @@ class Csr:
     chunk_ptr: Optional[torch.Tensor] = None   # int32 [n_rows + 1]
     rows_per_chunk: int = 0
     n_chunks_ub: int = 0
+    max_len: int = 0                           # longest segment (known for chunked CSRs after the plan's sync)
 
     @property
     def long_rows(self) -> bool:
         return self.chunk_ptr is not None
+
+    @property
+    def row_per_workgroup(self) -> bool:
+        """Many segments of moderate length (stories, program nodes): one launch with a workgroup per
+        segment instead of the two-phase chunk reduction."""
+        return self.chunk_ptr is not None and self.n_rows >= 32 and 0 < self.max_len <= 4096
 
 
 class LinOp:
@@ -67,6 +75,7 @@ class _Builder:
         self.lib = _lib.load()
         self.flags = torch.zeros(max_builds, 4, dtype=torch.int32, device=device)
         self.names = []
+        self.chunked = []          # CSRs with chunk tables: their longest segment is read back in finish()
 
     def _slot(self, name):
         i = len(self.names)
@@ -115,6 +124,7 @@ class _Builder:
         c.rows_per_chunk = R
         c.n_chunks_ub = c.nnz // R + c.n_rows
         check(self.lib.bg_plan_chunks(ptr(c.rowptr), c.n_rows, R, ptr(c.chunk_ptr), stream()), "bg_plan_chunks")
+        self.chunked.append(c)
 
     def finish(self, extra: torch.Tensor):
         """The one host synchronisation of a plan build: read the validity flags (and a few
@@ -215,8 +225,11 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     story_graph.scatter_(0, vfc, vbi)
     ar_st = torch.arange(S, dtype=torch.int64, device=dev)
     sgr = b.csr("story_by_graph", story_graph, ar_st, B, S, counts=True)
-    b.maybe_chunks(sgr, force=True)
-    o["story_graph_seg"] = sgr                      # pooling stories -> graphs (two-level global max)
+    # pooling stories -> graphs (two-level global max): a copy with chunk tables (segment max needs them);
+    # the mean over a graph's few stories keeps the one-launch short-row path
+    sgr_seg = dataclasses.replace(sgr)
+    b.maybe_chunks(sgr_seg, force=True)
+    o["story_graph_seg"] = sgr_seg
     sgr_gather = b.gather_csr(story_graph.to(torch.int32), B)
     o["graph_of_story_mean"] = LinOp.pair(sgr, sgr_gather, sgr.count, SCALE_DIV)
     o["story_graph_gather"] = LinOp.pair(sgr_gather, sgr)
@@ -243,8 +256,12 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
 
     def _min_len(c):
         return (c.rowptr[1:] - c.rowptr[:-1]).min() if c.n_rows > 0 else torch.ones((), dtype=torch.int32, device=dev)
-    extra = torch.stack([lvl_max.to(torch.int32), _min_len(vfw), _min_len(pf), _min_len(cv), _min_len(st)])
-    flags, (max_level, min_vdeg, min_pdeg, min_cross, min_story) = b.finish(extra)
+    extra = torch.stack([lvl_max.to(torch.int32), _min_len(vfw), _min_len(pf), _min_len(cv), _min_len(st)] +
+                        [(c.rowptr[1:] - c.rowptr[:-1]).max() for c in b.chunked])
+    flags, (max_level, min_vdeg, min_pdeg, min_cross, min_story, *max_lens) = b.finish(extra)
+    for c, ml in zip(b.chunked, max_lens):
+        c.max_len = int(ml)
+    edge_by_program.max_len = cp.max_len
     o["max_level"] = int(max_level)
     o["vox_all_has"], o["prog_all_has"] = min_vdeg > 0, min_pdeg > 0
     o["stories_all_nonempty"] = min_story > 0       # then max over a graph = max over its stories' maxima

@@ -93,6 +93,9 @@ int bg_spmm_add_f32(const float* x, int64_t ldx, const int32_t* rowptr, const in
 /* Same contraction for LONG rows, two phases: phase 1 reduces chunks of at most rows_per_chunk
  * slots (chunk_ptr from bg_plan_chunks, n_chunks_ub >= chunk_ptr[n_rows]) into
  * partial[n_chunks_ub, H]; phase 2 adds a row's partials in chunk order.  Deterministic.
+ * chunk_ptr == NULL selects the one-launch form: a workgroup per row walks the whole row and writes
+ * the scaled sum (for many rows of moderate length, e.g. stories; partial is not used; needs the
+ * 16-byte path: H % 4 == 0, aligned x / out, pitches % 4 == 0).
  * replaces: avg_pool_x over stories / graphs, Model/models.py:166-167 (K5); the program-node
  * side of the cross-edge scatters in util_graph.py:32 and the backward of models.py:113,122. */
 int bg_segreduce_sum_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
@@ -104,7 +107,7 @@ int bg_segreduce_sum_f32(const float* x, int64_t ldx, const int32_t* rowptr, con
 
 /* Segment max with arg: out[s,h] = max_{k in seg s} x[c_k,h], arg[s,h] = c_k of the FIRST maximum
  * (slot order); an empty segment gives 0 and arg = -1.  Two phases as above;
- * partial_val / partial_arg: [n_chunks_ub, H].
+ * partial_val / partial_arg: [n_chunks_ub, H]; chunk_ptr == NULL: one launch, a workgroup per row.
  * replaces: tg.nn.global_max_pool, Model/models.py:262-263 (K13) incl. its scatter_max arg. */
 int bg_segmax_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
                   const int32_t* chunk_ptr, int32_t rows_per_chunk, int64_t n_chunks_ub,

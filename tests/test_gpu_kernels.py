@@ -318,3 +318,32 @@ def test_mask_gumbel_two_way(cuda):
     (soft[:, :1] * w + 2 * hard[:, :1] * w).sum().backward()
     (s0 * w.to(cuda) + 2 * h0 * w.to(cuda)).sum().backward()
     torch.testing.assert_close(lg.grad.cpu(), logits.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_one_launch_segment_sum_and_max(cuda):
+    """chunk_ptr == NULL form (a workgroup per segment) against the oracle: many segments of moderate,
+    ragged length, two of them empty, ties inside a segment."""
+    from building_gan_amd import ops
+    from building_gan_amd.plan import LinOp, SCALE_DIV, _Builder
+    from oracle.scatter import scatter_max, scatter_mean
+    torch.manual_seed(7)
+    n_seg, n = 50, 4000
+    seg = torch.randint(0, n_seg, (n,))
+    seg[seg == 11] = 12
+    seg[seg == 30] = 29                                   # segments 11 and 30 are empty
+    H = 128
+    x = torch.rand(n, H) * 2 - 1
+    first = int((seg == 5).nonzero()[0])
+    later = int((seg == 5).nonzero()[-1])
+    x[later] = x[first] = 3.0                             # a tie at the maximum: the first slot must win
+    b = _Builder(cuda)
+    c = b.csr("s", seg.to(cuda), torch.arange(n).to(cuda), n_seg, n, counts=True)
+    b.maybe_chunks(c, force=True)
+    c.max_len = int(torch.bincount(seg, minlength=n_seg).max())
+    assert c.row_per_workgroup
+    val, arg = ops.segmax_raw(c, x.to(cuda))
+    rv, ra = scatter_max(x, seg, n_seg)
+    assert torch.equal(val.cpu(), rv)
+    assert torch.equal(arg.cpu().long(), torch.where(ra == n, torch.full_like(ra, -1), ra))
+    mean = ops.spmm_raw(LinOp(c, c.count, SCALE_DIV), x.to(cuda))
+    torch.testing.assert_close(mean.cpu(), scatter_mean(x, seg, n_seg), rtol=1e-5, atol=1e-6)
