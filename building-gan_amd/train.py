@@ -64,6 +64,8 @@ class FlatAdam:
 
     def all_reduce(self, group=None):
         if _world(group) > 1:
+            if self.grad.is_cuda and dist.get_backend(group) == "gloo":
+                torch.cuda.current_stream().synchronize()      # gloo reads the buffer from the host side
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
 
     def step(self):
