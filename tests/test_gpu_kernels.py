@@ -347,3 +347,46 @@ def test_one_launch_segment_sum_and_max(cuda):
     assert torch.equal(arg.cpu().long(), torch.where(ra == n, torch.full_like(ra, -1), ra))
     mean = ops.spmm_raw(LinOp(c, c.count, SCALE_DIV), x.to(cuda))
     torch.testing.assert_close(mean.cpu(), scatter_mean(x, seg, n_seg), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,Ks,transB", [(200, 96, [64, 36], True),        # skinny kernel, 4 waves
+                                            (500, 256, [256, 256], True),     # skinny kernel, 8 waves
+                                            (500, 256, [512], False),         # skinny kernel, B stored [K, N]
+                                            (11520, 128, [128, 128, 4], True),  # 64x64 register-staged kernel
+                                            (9000, 260, [128], False),        # same, B stored [K, N]
+                                            (40000, 128, [128, 128, 4], True),  # LDS-DMA ring kernel (>= 512 tiles)
+                                            (33000, 104, [256], False)])      # LDS-DMA ring kernel, B stored [K, N]
+def test_gemm_epilogue_all_kernels(cuda, M, N, Ks, transB):
+    """Every GEMM kernel variant with the full epilogue: bias, row mask, gathered pre-activation addend
+    (pre_add_rows), LeakyReLU, residual -- against float64."""
+    from building_gan_amd import ops
+    torch.manual_seed(M + N)
+    K = sum(Ks)
+    xs = [torch.rand(M, k) * 2 - 1 for k in Ks]
+    W = torch.rand(N, K) * 2 - 1 if transB else torch.rand(K, N) * 2 - 1
+    b = torch.rand(N) * 2 - 1
+    rs = (torch.rand(M) > 0.2).float()
+    G = 37
+    term = torch.rand(G, N) * 2 - 1
+    rows = torch.randint(0, G, (M,), dtype=torch.int32)
+    res = torch.rand(M, N) * 2 - 1
+    Wd = W.double().t() if transB else W.double()
+    ref = (torch.cat(xs, 1).double() @ Wd + b.double()) * rs.double().view(-1, 1) + term.double()[rows.long()]
+    ref = torch.nn.functional.leaky_relu(ref, 0.01) + res.double()
+    out = ops.gemm_raw([x.to(cuda) for x in xs], W.to(cuda), False, transB, bias=b.to(cuda), row_scale=rs.to(cuda),
+                       act=ops.ACT_LEAKY, slope=0.01, residual=res.to(cuda), pre_add=term.to(cuda),
+                       pre_rows=rows.to(cuda))
+    scale = torch.cat(xs, 1).abs().double() @ Wd.abs()
+    err = (out.cpu().double() - ref).abs()
+    assert float((err / (scale + 1.0)).max()) < 2e-6
+
+
+def test_splitk_small_output_reduce(cuda):
+    """Weight gradient of a narrow layer: few outputs, hundreds of splits (k_splitk_reduce_small)."""
+    from building_gan_amd import ops
+    torch.manual_seed(9)
+    R, M, N = 11520, 2, 64
+    g, x = torch.rand(R, M) * 2 - 1, torch.rand(R, N) * 2 - 1
+    out = ops.gemm_tn_raw(g.to(cuda), x.to(cuda))
+    ref = g.double().t() @ x.double()
+    assert float((out.cpu().double() - ref).abs().max()) < 1e-3
