@@ -19,6 +19,7 @@ from typing import Optional, Sequence
 
 import torch
 import torch.distributed as dist
+import torch.nn.functional as F
 
 from . import ops
 from .graph import detach_batch
@@ -99,18 +100,22 @@ class Trainer:
     def __init__(self, device, hidden_dim=128, noise_dim=32, program_layer=4, voxel_layer=12,
                  g_lr=1e-4, d_lr=1e-4, b1=0.5, b2=0.999, gp_lambda=10.0, n_critic_d=1, n_critic_g=5,
                  gan_loss="WGANGP", max_len=20, group=None, generator=None, discriminator=None):
-        if gan_loss != "WGANGP":
-            raise NotImplementedError("the data-parallel step implements the default WGANGP objective")
+        if gan_loss not in ("WGANGP", "NSGAN", "LSGAN", "hinge"):
+            raise TypeError("gan_loss is not valid")          # as reference losses.py:35
+        self.gan_loss = gan_loss
         self.device = device
         self.noise_dim = noise_dim
         # networks can be injected (same call signature) -- the multi-process CPU tests do that
         self.generator = generator if generator is not None else \
             Generator(7, 7, hidden_dim, noise_dim, program_layer, voxel_layer, device, max_len).to(device)
         self.discriminator = discriminator if discriminator is not None else \
-            DiscriminatorVoxel(7, 6, hidden_dim, voxel_layer, act="", max_len=max_len).to(device)
+            DiscriminatorVoxel(7, 6, hidden_dim, voxel_layer, act="sigmoid" if gan_loss == "NSGAN" else "",
+                               max_len=max_len).to(device)           # reference train.py:65
         self.opt_g = FlatAdam(self.generator, g_lr, (b1, b2))
         self.opt_d = FlatAdam(self.discriminator, d_lr, (b1, b2))
-        self.gp_lambda, self.n_critic_d, self.n_critic_g = gp_lambda, n_critic_d, n_critic_g
+        # the penalty belongs to WGAN-GP only (reference train.py:92-95)
+        self.gp_lambda = gp_lambda if gan_loss == "WGANGP" else 0.0
+        self.n_critic_d, self.n_critic_g = n_critic_d, n_critic_g
         self.g_loss_fn = VolumetricDesignLoss_G(gan_loss=gan_loss)
         self.group = group
         self._graphs = None
@@ -120,6 +125,31 @@ class Trainer:
         if _world(self.group) > 1:
             dist.broadcast(self.opt_g.flat, src, group=self.group)
             dist.broadcast(self.opt_d.flat, src, group=self.group)
+
+    # ------------------------------------------------------------------ objectives
+    # reference losses.py:14-35 / 52-61 with every mean written as (local sum) / (global count), so that the
+    # SUM all-reduce of the ranks' gradients is the gradient of the union batch.
+    def _d_adversarial(self, real_b, real_s, fake_b, fake_s, Bg, Sg):
+        gl = self.gan_loss
+        if gl == "WGANGP":
+            return -real_b.sum() / Bg - real_s.sum() / Sg + fake_b.sum() / Bg + fake_s.sum() / Sg
+        if gl == "NSGAN":
+            bce = lambda x, t: F.binary_cross_entropy(x, torch.full_like(x, t), reduction="sum")
+            return bce(real_b, 1.0) / Bg + bce(real_s, 1.0) / Sg + bce(fake_b, 0.0) / Bg + bce(fake_s, 0.0) / Sg
+        if gl == "LSGAN":
+            sq = lambda x, t: ((x - t) ** 2).sum()
+            return 0.5 * (sq(real_b, 1.0) / Bg + sq(real_s, 1.0) / Sg + sq(fake_b, 0.0) / Bg + sq(fake_s, 0.0) / Sg)
+        return (F.relu(1.0 - real_b).sum() / Bg + F.relu(1.0 - real_s).sum() / Sg
+                + F.relu(fake_b + 1.0).sum() / Bg + F.relu(fake_s + 1.0).sum() / Sg)          # hinge
+
+    def _g_adversarial(self, val_b, val_s, Bg, Sg):
+        gl = self.gan_loss
+        if gl in ("WGANGP", "hinge"):
+            return -val_b.sum() / Bg - val_s.sum() / Sg
+        if gl == "NSGAN":
+            bce = lambda x: F.binary_cross_entropy(x, torch.ones_like(x), reduction="sum")
+            return bce(val_b) / Bg + bce(val_s) / Sg
+        return ((val_b - 1.0) ** 2).sum() / Bg + ((val_s - 1.0) ** 2).sum() / Sg               # LSGAN
 
     # ------------------------------------------------------------------ pieces of one iteration
     @staticmethod
@@ -197,7 +227,7 @@ class Trainer:
                                                     soft_out.detach(), u, Nvg)
                     real_b, real_s = D(batch, batch.voxel_label)
         if do_d:
-            d_loss = -real_b.sum() / Bg - real_s.sum() / Sg + fake_b.sum() / Bg + fake_s.sum() / Sg
+            d_loss = self._d_adversarial(real_b, real_s, fake_b, fake_s, Bg, Sg)
             if gp is not None:
                 d_loss = d_loss + self.gp_lambda * gp
                 stats["gp"] = gp.detach()
@@ -215,7 +245,7 @@ class Trainer:
         val_b, val_s = self.discriminator(batch, out)
         # get_program_ratio runs in every G step although its losses have zero weight (losses.py:65)
         self.g_loss_fn((val_b, val_s), batch, att["hard"], mask["hard"], 6)
-        g_loss = -val_b.sum() / Bg - val_s.sum() / Sg
+        g_loss = self._g_adversarial(val_b, val_s, Bg, Sg)
         g_loss.backward()
         return {"g_loss": g_loss.detach()}
 

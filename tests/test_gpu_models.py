@@ -321,3 +321,31 @@ def test_fused_critic_terms_match_separate_passes_and_oracle_gradients(cuda):
             continue
         scale = float(po.grad.abs().max()) + 1e-6
         assert float((ph.grad.cpu() - po.grad).abs().max()) <= 5e-3 * scale, n
+
+
+@pytest.mark.parametrize("gan_loss", ["NSGAN", "LSGAN", "hinge"])
+def test_trainer_other_objectives_match_oracle(cuda, gan_loss):
+    """The non-default objectives of reference losses.py:14-35,52-61 in the trainer (NSGAN puts a sigmoid
+    on the decoders, reference train.py:65; no gradient penalty): first iteration against the oracle."""
+    from building_gan_amd import models as hm
+    from building_gan_amd.graph import detach_batch
+    from building_gan_amd.train import Trainer
+    from oracle import networks as om
+    from oracle.objectives import train_iteration
+    cpu, gpu, sz, Go, _, _, _, noise, pz, vz = _setup("small", 23, True, cuda)
+    act = "sigmoid" if gan_loss == "NSGAN" else ""
+    torch.manual_seed(23)
+    Do = om.DiscriminatorVoxel(7, 6, 128, 12, act)
+    tr = Trainer(cuda, gan_loss=gan_loss)
+    tr.generator.load_state_dict(Go.state_dict())
+    tr.discriminator.load_state_dict(Do.state_dict())
+    og = torch.optim.Adam(Go.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    od = torch.optim.Adam(Do.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    so = train_iteration(Go, Do, og, od, cpu, detach_batch, 0, pz, vz, noise, None, gan_loss=gan_loss)
+    sh = tr.train_iteration(gpu, 0, pz.to(cuda), vz.to(cuda), _to(noise, cuda), None)
+    assert "gp" not in sh
+    torch.testing.assert_close(sh["d_loss"].cpu(), so["d_loss"], rtol=5e-3, atol=5e-3)
+    torch.testing.assert_close(sh["g_loss"].cpu().view(-1), so["g_loss"].view(-1), rtol=1e-2, atol=5e-3)
+    for (n, po), (_, ph) in zip(list(Do.named_parameters()) + list(Go.named_parameters()),
+                                list(tr.discriminator.named_parameters()) + list(tr.generator.named_parameters())):
+        assert float((ph.detach().cpu() - po.detach()).abs().max()) <= 2.5e-4, n     # one Adam step: <= 2 lr
