@@ -169,8 +169,8 @@ class Attention(nn.Module):
         Wd = ops.MatMul.apply(W2, W1, False, False)                                    # [2, H]
         bd = torch.addmv(b2, W2, b1)
         H = self.NN_v.weight.shape[0]
-        Wcat = torch.cat([self.NN_v.weight, Wd, Wd.new_zeros(2, W1.shape[1])], dim=0)  # [H + 4, H]
-        bcat = torch.cat([self.NN_v.bias, bd, bd.new_zeros(2)])
+        Wcat = torch.cat([self.NN_v.weight, Wd, ops.zeros_view(2, W1.shape[1], device=Wd.device)], dim=0)  # [H + 4, H]
+        bcat = torch.cat([self.NN_v.bias, bd, ops.zeros_view(2, device=bd.device)])
         return b, Wcat, bcat
 
     def forward(self, program_graph_feature, voxel_feature, plan, noise=None, shared=None):
@@ -226,7 +226,8 @@ class VoxelBlock(nn.Module):
         Wu, bu = self.updateMLP[0].weight, self.updateMLP[0].bias
         H = Wm.shape[0]
         # [H, 2H+8]: [Wm | 0 | bm | 0 0 0] -- the pad keeps the row pitch a multiple of 16 bytes (vector loads)
-        Wm_ext = torch.cat([F.pad(Wm, (0, 1)), bm.view(-1, 1), Wm.new_zeros(H, 3)], dim=1)
+        Wm_ext = torch.cat([Wm, ops.zeros_view(H, 1, device=Wm.device), bm.view(-1, 1),
+                            ops.zeros_view(H, 3, device=Wm.device)], dim=1)
         # split / one cat per result: each is ONE autograd node (a slice would cost a zero-fill + add in backward)
         parts = Wu.split(H, dim=1)
         P, pb, _ = ops.MatMul.apply(parts[1], Wm_ext, False, False).split([2 * H + 4, 1, 3], dim=1)   # Wu2 @ [Wm | 0 | bm]
@@ -347,7 +348,7 @@ class VoxelGNN_D(nn.Module):
         H2 = Wc.shape[0]
         H, ML, L, du = H2 // 2, self.pe.shape[0], self.layer_num, ds + dl
         fe, le = self.feature_enc[0], self.label_enc[0]
-        z = lambda r, c: Wc.new_zeros(r, c)
+        z = lambda r, c: ops.zeros_view(r, c, device=Wc.device)     # cached zeros: no fill launches
         pad_s = ds - (n_feat + ML + 4 + 1)
         n_lab = le.weight.shape[1]
         # T^0_0 [du, 2H]: how the input columns enter v_0 = [feature_enc(f) + pe[level] | label_enc(l)]
@@ -472,7 +473,7 @@ class DiscriminatorVoxel(nn.Module):
         finally:
             gnn._share_coef, gnn._coef_cache = False, None
 
-    def critic_terms(self, graph, label_real, label_fake, label_hat=None):
+    def critic_terms(self, graph, label_real, label_fake, label_hat=None, stacked: bool = False):
         """Every discriminator evaluation of one critic update (reference train.py:88-96) in one
         pass over the collapsed GNN: D(real), D(fake) and, when ``label_hat`` is given, the gradients
         of D(hat)'s two outputs with respect to ``label_hat`` (reference losses.py:83-84) -- obtained
@@ -481,7 +482,9 @@ class DiscriminatorVoxel(nn.Module):
         over a third forward graph.  Labels are treated as data.
 
         Returns None when the collapsed form does not apply to this graph (the caller then runs the
-        passes one by one), else (real_b, real_s, fake_b, fake_s, grad_b, grad_s)."""
+        passes one by one), else (real_b, real_s, fake_b, fake_s, grad_b, grad_s); with ``stacked`` the
+        same numbers un-split: (val_b [2B,1] real rows first, val_s [2S,1], grads [N, 2, dl] or None) where
+        grads[:, 0] / grads[:, 1] are grad_b / grad_s zero-padded to dl columns."""
         plan = build_plan(graph)
         gnn = self.voxelGNN_D
         if not (COLLAPSE_D and COMPOSE_BLOCKS and plan.vox_all_has and gnn.layer_num > 0):
@@ -493,11 +496,15 @@ class DiscriminatorVoxel(nn.Module):
         B, S, N = plan.B, plan.S, plan.Nv
         # real and fake share one run of each decoder
         pools = [pool_story_and_graph(v, plan) for v in vs[:2]]
-        val_s = run_mlp(self.story_dec, torch.cat([pools[0][0], pools[1][0]], dim=0)).split(S, dim=0)
-        val_b = run_mlp(self.building_dec, torch.cat([pools[0][1], pools[1][1]], dim=0)).split(B, dim=0)
-        out = [val_b[0], val_s[0], val_b[1], val_s[1]]
+        val_s_all = run_mlp(self.story_dec, torch.cat([pools[0][0], pools[1][0]], dim=0))
+        val_b_all = run_mlp(self.building_dec, torch.cat([pools[0][1], pools[1][1]], dim=0))
+        if stacked:
+            out = None
+        else:
+            val_s, val_b = val_s_all.split(S, dim=0), val_b_all.split(B, dim=0)
+            out = [val_b[0], val_s[0], val_b[1], val_s[1]]
         if label_hat is None:
-            return (*out, None, None)
+            return (val_b_all, val_s_all, None) if stacked else (*out, None, None)
         n_lab, L = label_hat.shape[1], gnn.layer_num
         with torch.no_grad():
             hat_s, arg_s = ops.segmax_raw(plan.story_seg, vs[2])
@@ -506,19 +513,21 @@ class DiscriminatorVoxel(nn.Module):
                 arg_b = ops.gather_arg_raw(arg_s.float(), arg_sb).to(torch.int32)  # .. and that story's arg-max voxel
             else:
                 hat_b, arg_b = ops.segmax_raw(plan.graph_seg, vs[2])
-        G = []
-        for dec, pooled, arg in ((self.building_dec, hat_b, arg_b), (self.story_dec, hat_s, arg_s)):
+        gpools = []
+        for dec, pooled in ((self.building_dec, hat_b), (self.story_dec, hat_s)):
             pooled = pooled.requires_grad_(True)
             with ops.input_grads_only():
                 val = run_mlp(dec, pooled)
-            gpool = torch.autograd.grad(val, pooled, torch.ones_like(val), create_graph=True)[0]
-            G.append(ops.ScatterArg.apply(gpool, arg, N))
-        X = ops.MatMul.apply(torch.cat(G, dim=0), Wl, False, True)                 # [2N, (L+1)*dl]
+            gpools.append(torch.autograd.grad(val, pooled, torch.ones_like(val), create_graph=True)[0])
+        G2 = ops.ScatterArgPair.apply(gpools[0], arg_b, gpools[1], arg_s, N)       # [2N, 2H]: building rows first
+        X = ops.MatMul.apply(G2, Wl, False, True)                                  # [2N, (L+1)*dl]
         # unbind: ONE backward node (a stack) for the L+1 slices instead of a zero-fill + add per slice
         Ys = X.view(2, N, L + 1, dl).permute(1, 2, 0, 3).reshape(N, L + 1, 2 * dl).unbind(dim=1)
         acc = Ys[L]
         for k in range(L - 1, -1, -1):
             acc = ops.SpMMAdd.apply(acc, Ys[k], plan.vox_mean.T)
+        if stacked:
+            return val_b_all, val_s_all, acc.view(N, 2, dl)      # the pad columns are exactly zero
         grad_b, _, grad_s, _ = acc.split([n_lab, dl - n_lab, n_lab, dl - n_lab], dim=1)
         return (*out, grad_b, grad_s)
 

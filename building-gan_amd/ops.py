@@ -54,6 +54,22 @@ def _ld(t: torch.Tensor) -> int:
 
 
 # ------------------------------------------------------------------------------- raw launchers
+_ZEROS = {}
+
+
+def zeros_view(*shape, device) -> torch.Tensor:
+    """A read-only all-zero fp32 tensor of the given shape: a view of one cached buffer per device (no
+    fill launch).  For padding blocks inside torch.cat; never write to it."""
+    n = 1
+    for d in shape:
+        n *= d
+    buf = _ZEROS.get(device)
+    if buf is None or buf.numel() < n:
+        buf = torch.zeros(max(n, 1 << 16), dtype=torch.float32, device=device)
+        _ZEROS[device] = buf
+    return buf[:n].view(*shape)
+
+
 def _vec_ok(*ts) -> bool:
     """16-byte path: width % 4 == 0, aligned base, pitch % 4 == 0."""
     return all(t.shape[-1] % 4 == 0 and t.data_ptr() % 16 == 0 and _ld(t) % 4 == 0 for t in ts)
@@ -156,11 +172,12 @@ def gather_arg_raw(x: torch.Tensor, arg: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def scatter_arg_raw(g: torch.Tensor, arg: torch.Tensor, n_rows: int) -> torch.Tensor:
+def scatter_arg_raw(g: torch.Tensor, arg: torch.Tensor, n_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     g2 = _f32c(g)
     S, H = arg.shape
-    out = torch.empty(n_rows, H, dtype=torch.float32, device=g.device)
+    if out is None:
+        out = torch.empty(n_rows, H, dtype=torch.float32, device=g.device)
     check(lib.bg_scatter_arg_f32(ptr(g2), _ld(g2), ptr(arg), ptr(out), H, S, n_rows, H, stream()),
           "bg_scatter_arg_f32")
     return out
@@ -492,6 +509,25 @@ class ScatterArg(torch.autograd.Function):
     def backward(ctx, gg):
         (arg,) = ctx.saved_tensors
         return GatherArg.apply(gg, arg), None, None
+
+
+class ScatterArgPair(torch.autograd.Function):
+    """[scatter(g1, arg1); scatter(g2, arg2)] stacked into one [2 * n_rows, H] matrix (no concatenation)."""
+
+    @staticmethod
+    def forward(ctx, g1, arg1, g2, arg2, n_rows):
+        ctx.n_rows = n_rows
+        ctx.save_for_backward(arg1, arg2)
+        out = torch.empty(2 * n_rows, arg1.shape[1], dtype=torch.float32, device=g1.device)
+        scatter_arg_raw(g1, arg1, n_rows, out=out[:n_rows])
+        scatter_arg_raw(g2, arg2, n_rows, out=out[n_rows:])
+        return out
+
+    @staticmethod
+    def backward(ctx, gg):
+        arg1, arg2 = ctx.saved_tensors
+        n = ctx.n_rows
+        return GatherArg.apply(gg[:n], arg1), None, GatherArg.apply(gg[n:], arg2), None, None
 
 
 class GatherArg(torch.autograd.Function):

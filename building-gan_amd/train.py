@@ -119,6 +119,7 @@ class Trainer:
         self.g_loss_fn = VolumetricDesignLoss_G(gan_loss=gan_loss)
         self.group = group
         self._graphs = None
+        self._cw_cache = None
         self._overlap_stream = None    # set while capture() records the iteration
 
     def broadcast_parameters(self, src: int = 0):
@@ -141,6 +142,14 @@ class Trainer:
             return 0.5 * (sq(real_b, 1.0) / Bg + sq(real_s, 1.0) / Sg + sq(fake_b, 0.0) / Bg + sq(fake_s, 0.0) / Sg)
         return (F.relu(1.0 - real_b).sum() / Bg + F.relu(1.0 - real_s).sum() / Sg
                 + F.relu(fake_b + 1.0).sum() / Bg + F.relu(fake_s + 1.0).sum() / Sg)          # hinge
+
+    def _critic_weights(self, B, S, Bg, Sg, dev):
+        key = (B, S, Bg, Sg)
+        if self._cw_cache is None or self._cw_cache[0] != key:
+            wb = torch.cat([torch.full((B,), -1.0 / Bg), torch.full((B,), 1.0 / Bg)]).to(dev)
+            ws = torch.cat([torch.full((S,), -1.0 / Sg), torch.full((S,), 1.0 / Sg)]).to(dev)
+            self._cw_cache = (key, wb, ws)
+        return self._cw_cache[1], self._cw_cache[2]
 
     def _g_adversarial(self, val_b, val_s, Bg, Sg):
         gl = self.gan_loss
@@ -215,11 +224,11 @@ class Trainer:
                 if fused_ok:
                     sample = (self._gp_sample(batch.voxel_label.detach(), soft_out.detach(), u)
                               if self.gp_lambda != 0 else None)
-                    fused = D.critic_terms(batch, batch.voxel_label, out.detach(), sample)
+                    fused = D.critic_terms(batch, batch.voxel_label, out.detach(), sample, stacked=True)
                 if fused is not None:
-                    real_b, real_s, fake_b, fake_s, grad_b, grad_s = fused
-                    if grad_b is not None:
-                        gp = (((grad_b.norm(2, 1) - 1) ** 2).sum() + ((grad_s.norm(2, 1) - 1) ** 2).sum()) / Nvg
+                    val_b_all, val_s_all, grads = fused
+                    if grads is not None:          # both penalties at once: grads[:, 0] and grads[:, 1]
+                        gp = ((grads.norm(2, 2) - 1) ** 2).sum() / Nvg
                 else:
                     fake_b, fake_s = D(detach_batch(batch), out.detach())
                     if self.gp_lambda != 0:
@@ -227,7 +236,14 @@ class Trainer:
                                                     soft_out.detach(), u, Nvg)
                     real_b, real_s = D(batch, batch.voxel_label)
         if do_d:
-            d_loss = self._d_adversarial(real_b, real_s, fake_b, fake_s, Bg, Sg)
+            if fused is not None and self.gan_loss == "WGANGP":
+                # -E[real] + E[fake] over graphs and over stories as two dot products with +-1/count weights
+                wb, ws = self._critic_weights(val_b_all.shape[0] // 2, val_s_all.shape[0] // 2, Bg, Sg, dev)
+                d_loss = torch.dot(val_b_all.view(-1), wb) + torch.dot(val_s_all.view(-1), ws)
+            else:
+                if fused is not None:
+                    (real_b, fake_b), (real_s, fake_s) = val_b_all.chunk(2, dim=0), val_s_all.chunk(2, dim=0)
+                d_loss = self._d_adversarial(real_b, real_s, fake_b, fake_s, Bg, Sg)
             if gp is not None:
                 d_loss = d_loss + self.gp_lambda * gp
                 stats["gp"] = gp.detach()
