@@ -274,13 +274,20 @@ class VoxelGNN_G(nn.Module):
         self.attention = Attention(hidden_dim)
 
     def forward(self, x, v, z, plan, noise: Optional[Sequence] = None):
-        draws = iter(noise) if noise is not None else None
+        n_calls = 1 + sum(1 for i in range(self.layer_num) if i % 2 == 0 and i != 0)
+        if noise is None:
+            # all Exp(1) draws of this forward (mask [Nv, 2] + attention [Ec] per call) in ONE launch
+            per = 2 * plan.Nv + (plan.Ec + 3) // 4 * 4           # every piece starts 16-byte aligned
+            flat = torch.empty(n_calls * per, dtype=torch.float32, device=v.device).exponential_()
+            noise = [(flat[c * per:c * per + 2 * plan.Nv].view(plan.Nv, 2),
+                      flat[c * per + 2 * plan.Nv:c * per + 2 * plan.Nv + plan.Ec]) for c in range(n_calls)]
+        draws = iter(noise)
         pos, v = extract_pos(v)
         pdm4 = _pos_terms(plan, pos)
         v = run_mlp(self.enc, torch.cat((v, z), dim=-1) if self.noise_dim != 0 else v)
         v = v + ops.spmm_raw(_level_op(plan, self.pe.shape[0]), self.pe)
         shared = self.attention.shared_terms(x)
-        _, _, v = self.attention(x, v, plan, None if draws is None else next(draws), shared)
+        _, _, v = self.attention(x, v, plan, next(draws), shared)
         out_mask = out_att = None
         composed = self.block.compose() if (COMPOSE_BLOCKS and plan.vox_all_has) else None
         for i in range(self.layer_num):
@@ -289,7 +296,7 @@ class VoxelGNN_G(nn.Module):
             else:
                 v = v + self.block(v, plan, pdm4)
             if i % 2 == 0 and i != 0:
-                out_mask, out_att, v = self.attention(x, v, plan, None if draws is None else next(draws), shared)
+                out_mask, out_att, v = self.attention(x, v, plan, next(draws), shared)
         return out_mask, out_att, v
 
 
