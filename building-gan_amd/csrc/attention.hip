@@ -171,6 +171,88 @@ __global__ void k_mask_gumbel_bwd(const float* __restrict__ soft0, const float* 
     *reinterpret_cast<float2*>(d_logits + 2 * v) = make_float2(d, -d);
 }
 
+// Forward-only fusion of one Attention call (reference models.py:104-126) for passes that build no
+// autograd graph (inference, the generator forward of critic-only iterations).  One wave per voxel does
+// what k_mask_gumbel, k_cross_logits, k_seg_gumbel_softmax, the weighted program gather and the
+// final v + soft_mask * gathered do as five launches: lane j keeps the logit of the voxel's j-th cross
+// edge (degree <= 64, checked by the launcher's caller), max / sum / arg-max run over lanes in slot
+// order, so every output equals the unfused kernels' (same operation order).
+template <int CPL>
+__global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__ A, int64_t lda,        // NN_v(v) [Nv, H]
+                                                       const float* __restrict__ logits, int64_t ldl,  // mask logits [Nv, 2]
+                                                       const float* __restrict__ B, int64_t ldb,        // NN_p(x) [Np, H]
+                                                       const float* __restrict__ X, int64_t ldx,        // program features [Np, H]
+                                                       const float* __restrict__ V, int64_t ldv,        // voxel features [Nv, H]
+                                                       const float* __restrict__ theta,
+                                                       const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                       const float* __restrict__ exp_mask,              // [Nv, 2]
+                                                       const float* __restrict__ exp_att,               // [Ec]
+                                                       float tau,
+                                                       float* __restrict__ soft0, float* __restrict__ hard0,   // [Nv]
+                                                       float* __restrict__ soft, float* __restrict__ hard,     // [Ec]
+                                                       float* __restrict__ out, int64_t ldo, int64_t n_vox) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    float th[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) th[j] = theta[lane + 64 * j];
+    for (int64_t v = wave_id; v < n_vox; v += n_waves) {
+        // ---- two-way mask (k_mask_gumbel)
+        const float z0 = logits[v * ldl] - logf(exp_mask[2 * v]), z1 = logits[v * ldl + 1] - logf(exp_mask[2 * v + 1]);
+        const float zm = fmaxf(z0, z1);
+        const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
+        const float esum = e0 + e1;
+        const float s0 = e0 / esum, s1 = e1 / esum;
+        const float one0 = s0 >= s1 ? 1.f : 0.f;
+        if (lane == 0) { soft0[v] = s0; hard0[v] = (one0 - s0) + s0; }
+        // ---- logits of the voxel's cross edges (k_cross_logits); lane j keeps edge j's y = (att + gumbel) / tau
+        float av[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) av[j] = A[v * lda + lane + 64 * j];
+        const int32_t b = rowptr[v], e = rowptr[v + 1];
+        const int deg = e - b;
+        float y = -3.402823466e+38f;
+        for (int32_t k = b; k < e; ++k) {
+            const float* bp = B + (int64_t)col[k] * ldb;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) acc = fmaf(th[j], tanhf(av[j] + bp[lane + 64 * j]), acc);
+            acc = bg_wave_sum(acc);
+            if (lane == k - b) y = (acc + (-logf(exp_att[k]))) / tau;
+        }
+        // ---- segment Gumbel-softmax (k_seg_gumbel_softmax): max, then exp / sum in slot order
+        float m = y;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        const float ex = lane < deg ? expf(y - m) : 0.f;
+        float sum = 0.f;
+        for (int j = 0; j < deg; ++j) sum += __shfl(ex, j, 64);
+        const float o = ex / (sum + 1e-16f);
+        float best = -3.402823466e+38f; int ba = 0;
+        for (int j = 0; j < deg; ++j) {
+            const float oj = __shfl(o, j, 64);
+            if (oj > best) { best = oj; ba = j; }
+        }
+        if (lane < deg) {
+            soft[b + lane] = o;
+            hard[b + lane] = ((lane == ba ? 1.f : 0.f) - o) + o;
+        }
+        // ---- v + soft_mask * sum_k soft_k x[col_k]   (weighted gather in slot order, then addcmul)
+        float g[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) g[j] = 0.f;
+        for (int jk = 0; jk < deg; ++jk) {
+            const float w = __shfl(o, jk, 64);
+            const float* xp = X + (int64_t)col[b + jk] * ldx;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) g[j] += w * xp[lane + 64 * j];
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) out[v * ldo + lane + 64 * j] = V[v * ldv + lane + 64 * j] + s0 * g[j];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -261,6 +343,35 @@ int bg_mask_gumbel_bwd_f32(const float* soft0, const float* g_soft, const float*
     if (!soft0 || !d_logits) return BG_ERR_ARG;
     k_mask_gumbel_bwd<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(soft0, g_soft, g_hard,
                                                                                          d_logits, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_attention_fwd_f32(const float* a, int64_t lda, const float* logits, int64_t ldl,
+                         const float* b, int64_t ldb, const float* x, int64_t ldx,
+                         const float* v, int64_t ldv, const float* theta,
+                         const int32_t* rowptr, const int32_t* col,
+                         const float* exp_mask, const float* exp_att, float tau,
+                         float* soft0, float* hard0, float* soft, float* hard,
+                         float* out, int64_t ldo, int64_t n_vox, int64_t H, bgStream stream) {
+    if (n_vox < 0 || H <= 0 || tau == 0.f) return BG_ERR_ARG;
+    if (n_vox == 0) return BG_OK;
+    if (!a || !logits || !b || !x || !v || !theta || !rowptr || !col || !exp_mask || !exp_att || !soft0 || !hard0 ||
+        !soft || !hard || !out || lda < H || ldb < H || ldx < H || ldv < H || ldo < H || ldl < 2)
+        return BG_ERR_ARG;
+    if (H % 64 != 0 || H > 64 * kMaxCPL) return BG_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = bg_grid_for(n_vox, 4, 256 * 16);
+#define BG_ATT_CASE(C)                                                                                          \
+    case C:                                                                                                     \
+        k_attention_fwd<C><<<grid, 256, 0, s>>>(a, lda, logits, ldl, b, ldb, x, ldx, v, ldv, theta, rowptr, col, \
+                                                exp_mask, exp_att, tau, soft0, hard0, soft, hard, out, ldo, n_vox); \
+        break;
+    switch ((int)(H / 64)) {
+        BG_ATT_CASE(1) BG_ATT_CASE(2) BG_ATT_CASE(3) BG_ATT_CASE(4)
+        BG_ATT_CASE(5) BG_ATT_CASE(6) BG_ATT_CASE(7) BG_ATT_CASE(8)
+    }
+#undef BG_ATT_CASE
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -28,6 +28,7 @@ from .plan import LinOp, build_plan
 NUMBER_OF_CLASS = 6  # /root/reference/Data/GraphConstructor.py:9
 COMPOSE_BLOCKS = True  # collapse messageMLP into updateMLP where legal (VoxelBlock.compose)
 COMPOSE_STACK = True   # run the discriminator's 12 composed layers as one autograd node (ops.AffineStack)
+FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is being built
 COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
 
 
@@ -184,6 +185,14 @@ class Attention(nn.Module):
             a = linear(voxel_feature, self.NN_v.weight, self.NN_v.bias)
         if exp_mask is None:
             exp_mask = torch.empty(logits.shape, dtype=logits.dtype, device=logits.device).exponential_()
+        if FUSE_ATTENTION and not torch.is_grad_enabled() and 0 < plan.cross_v.max_len <= 64:
+            # nothing will be differentiated: the rest of the call is one launch
+            if exp_att is None:
+                exp_att = torch.empty(plan.Ec, dtype=logits.dtype, device=logits.device).exponential_()
+            soft0, hard0, soft_att, hard_att, new_voxel_feature = ops.attention_forward_raw(
+                a, logits, b, program_graph_feature, voxel_feature, self.theta, plan, exp_mask, exp_att, -1.0)
+            return ({"hard": hard0, "soft": soft0}, {"hard": hard_att.view(-1, 1), "soft": soft_att.view(-1, 1)},
+                    new_voxel_feature)
         soft0, hard0 = ops.MaskGumbel.apply(logits, exp_mask)
         out_mask = {"hard": hard0, "soft": soft0}
         att = ops.CrossLogits.apply(a, b, self.theta, plan)

@@ -648,6 +648,27 @@ class MaskGumbel(torch.autograd.Function):
         return d, None
 
 
+def attention_forward_raw(a, logits, b, x, v, theta, plan, exp_mask, exp_att, tau: float):
+    """One Attention call without an autograd graph (see bg_attention_fwd_f32).
+    Returns (soft0 [Nv,1], hard0 [Nv,1], soft [Ec], hard [Ec], new voxel features [Nv,H])."""
+    lib = _lib.load()
+    _lib.require_device(v, "attention_forward")
+    cv = plan.cross_v
+    a2, l2, b2, x2, v2 = _f32c(a), _f32c(logits), _f32c(b), _f32c(x), _f32c(v)
+    th, em, ea = _f32c(theta.reshape(-1)), _f32c(exp_mask).contiguous(), _f32c(exp_att.reshape(-1))
+    n, H = v2.shape
+    dev = v.device
+    soft0 = torch.empty(n, 1, dtype=torch.float32, device=dev)
+    hard0 = torch.empty(n, 1, dtype=torch.float32, device=dev)
+    soft = torch.empty(cv.nnz, dtype=torch.float32, device=dev)
+    hard = torch.empty(cv.nnz, dtype=torch.float32, device=dev)
+    out = torch.empty(n, H, dtype=torch.float32, device=dev)
+    check(lib.bg_attention_fwd_f32(ptr(a2), _ld(a2), ptr(l2), _ld(l2), ptr(b2), _ld(b2), ptr(x2), _ld(x2), ptr(v2), _ld(v2),
+                                   ptr(th), ptr(cv.rowptr), ptr(cv.col), ptr(em), ptr(ea), tau, ptr(soft0), ptr(hard0),
+                                   ptr(soft), ptr(hard), ptr(out), _ld(out), n, H, stream()), "bg_attention_fwd_f32")
+    return soft0, hard0, soft, hard, out
+
+
 def seg_argmax(logit: torch.Tensor, plan) -> torch.Tensor:
     lib = _lib.load()
     cv = plan.cross_v

@@ -256,10 +256,12 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
 
     def _min_len(c):
         return (c.rowptr[1:] - c.rowptr[:-1]).min() if c.n_rows > 0 else torch.ones((), dtype=torch.int32, device=dev)
+    measured = b.chunked + [cv]                       # CSRs whose longest segment the networks want to know
     extra = torch.stack([lvl_max.to(torch.int32), _min_len(vfw), _min_len(pf), _min_len(cv), _min_len(st)] +
-                        [(c.rowptr[1:] - c.rowptr[:-1]).max() for c in b.chunked])
+                        [(c.rowptr[1:] - c.rowptr[:-1]).max() if c.n_rows > 0 else lvl_max.new_zeros(()).to(torch.int32)
+                         for c in measured])
     flags, (max_level, min_vdeg, min_pdeg, min_cross, min_story, *max_lens) = b.finish(extra)
-    for c, ml in zip(b.chunked, max_lens):
+    for c, ml in zip(measured, max_lens):
         c.max_len = int(ml)
     edge_by_program.max_len = cp.max_len
     o["max_level"] = int(max_level)

@@ -175,6 +175,19 @@ int bg_mask_gumbel_f32(const float* logits, int64_t ldl, const float* expn, floa
 int bg_mask_gumbel_bwd_f32(const float* soft0, const float* g_soft, const float* g_hard, float* d_logits,
                            int64_t n, bgStream stream);
 
+/* One whole Attention call, forward only (no autograd graph: inference, critic-only iterations): the
+ * two-way mask, the tanh cross logits, the segment Gumbel-softmax pointer, the soft-weighted gather of
+ * program features and  out = v + soft_mask * gathered  in one launch (one wave per voxel; every voxel
+ * must have between 1 and 64 cross edges).  a = NN_v(v), b = NN_p(x) as for bg_cross_logits_f32.
+ * replaces: Model/models.py:109-126 (Attention.forward) when nothing is differentiated.      */
+int bg_attention_fwd_f32(const float* a, int64_t lda, const float* logits, int64_t ldl,
+                         const float* b, int64_t ldb, const float* x, int64_t ldx,
+                         const float* v, int64_t ldv, const float* theta,
+                         const int32_t* rowptr, const int32_t* col,
+                         const float* exp_mask, const float* exp_att, float tau,
+                         float* soft0, float* hard0, float* soft, float* hard,
+                         float* out, int64_t ldo, int64_t n_vox, int64_t H, bgStream stream);
+
 /* ------------------------------------------------------------------ dense (fp32 MFMA) --- */
 
 #define BG_ACT_NONE 0

@@ -349,3 +349,19 @@ def test_trainer_other_objectives_match_oracle(cuda, gan_loss):
     for (n, po), (_, ph) in zip(list(Do.named_parameters()) + list(Go.named_parameters()),
                                 list(tr.discriminator.named_parameters()) + list(tr.generator.named_parameters())):
         assert float((ph.detach().cpu() - po.detach()).abs().max()) <= 2.5e-4, n     # one Adam step: <= 2 lr
+
+
+def test_fused_attention_forward_equals_unfused(cuda):
+    """The one-launch Attention call of graph-free passes (bg_attention_fwd_f32) against the five-kernel
+    autograd path on identical weights, inputs and noise: same pointers, activations to rounding."""
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 41, True, cuda)
+    nz = _to(noise, cuda)
+    ref = Gh(gpu, pz.to(cuda), vz.to(cuda), nz)                    # builds a graph -> unfused kernels
+    with torch.no_grad():
+        got = Gh(gpu, pz.to(cuda), vz.to(cuda), nz)                # fused kernel
+    out_r, soft_r, mask_r, att_r, idx_r = ref
+    out_g, soft_g, mask_g, att_g, idx_g = got
+    assert torch.equal(idx_g, idx_r)
+    assert torch.equal(att_g["hard"].round(), att_r["hard"].round()) and torch.equal(mask_g["hard"].round(), mask_r["hard"].round())
+    for a, b in ((out_g, out_r), (soft_g, soft_r), (mask_g["soft"], mask_r["soft"]), (att_g["soft"], att_r["soft"])):
+        torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
