@@ -375,6 +375,58 @@ __global__ void k_sddmm_scalar(const float* __restrict__ A, int64_t lda, const f
     }
 }
 
+// Forward-only fusion for the generator block's story term (reference models.py:166-170): one workgroup
+// per story averages the story's voxel rows (H <= 256 channels) and multiplies the mean by a [2H', H]
+// weight held as W[o, 0:H] (first H' outputs) and W[o, H:2H] (second H' outputs) of a row-major
+// [H', 2H] matrix -- i.e. out[s] = [ mean W[:, :H]^T | mean W[:, H:]^T ]: the story's own term and its
+// contribution to the building term, without the [S, H] mean ever going back to memory.
+__global__ __launch_bounds__(256) void k_story_project(const float* __restrict__ x, int64_t ldx,
+                                                       const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                       const float* __restrict__ count,
+                                                       const float* __restrict__ W, int64_t ldw, int Hout,
+                                                       float* __restrict__ out, int64_t ldo, int H) {
+    __shared__ float4 part[256];
+    __shared__ float mean[256];
+    const int64_t row = blockIdx.x;
+    const int H4 = H / 4;                       // <= 64 lanes per slot row
+    int lpr = 1;
+    while (lpr < H4) lpr <<= 1;
+    const int spb = 256 / lpr, sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
+    const int32_t k0 = rowptr[row], k1 = rowptr[row + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sub < H4) {
+        const float* xb = x + 4 * sub;
+        int32_t k = k0 + grp;
+        for (; k + 3 * spb < k1; k += 4 * spb) {
+            const int32_t ca = col ? col[k] : k, cb = col ? col[k + spb] : k + spb;
+            const int32_t cc = col ? col[k + 2 * spb] : k + 2 * spb, cd = col ? col[k + 3 * spb] : k + 3 * spb;
+            const float4 va = bg_ld4(xb + (int64_t)ca * ldx), vb = bg_ld4(xb + (int64_t)cb * ldx);
+            const float4 vc = bg_ld4(xb + (int64_t)cc * ldx), vd = bg_ld4(xb + (int64_t)cd * ldx);
+            acc = bg_add4(acc, va); acc = bg_add4(acc, vb); acc = bg_add4(acc, vc); acc = bg_add4(acc, vd);
+        }
+        for (; k < k1; k += spb) acc = bg_add4(acc, bg_ld4(xb + (int64_t)(col ? col[k] : k) * ldx));
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (grp == 0 && sub < H4) {
+        for (int g = 1; g < spb; ++g) acc = bg_add4(acc, part[g * lpr + sub]);
+        const float c = count[row];
+        mean[4 * sub + 0] = acc.x / c; mean[4 * sub + 1] = acc.y / c;
+        mean[4 * sub + 2] = acc.z / c; mean[4 * sub + 3] = acc.w / c;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * Hout; o += 256) {
+        const float* w = W + (int64_t)(o < Hout ? o : o - Hout) * ldw + (o < Hout ? 0 : H);
+        float d = 0.f;
+        for (int h = 0; h < H; h += 4) {
+            const float4 wv = bg_ld4(w + h);
+            d = fmaf(wv.x, mean[h], d); d = fmaf(wv.y, mean[h + 1], d);
+            d = fmaf(wv.z, mean[h + 2], d); d = fmaf(wv.w, mean[h + 3], d);
+        }
+        out[row * ldo + o] = d;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -506,6 +558,20 @@ int bg_sddmm_f32(const float* a, int64_t lda, const float* b, int64_t ldb,
     if (H4 >= 32) k_sddmm<32><<<grid, 256, 0, s>>>(a, lda, b, ldb, rowptr, col, eperm, out, n_rows, H4);
     else if (H4 >= 8) k_sddmm<8><<<grid, 256, 0, s>>>(a, lda, b, ldb, rowptr, col, eperm, out, n_rows, H4);
     else k_sddmm<1><<<grid, 256, 0, s>>>(a, lda, b, ldb, rowptr, col, eperm, out, n_rows, H4);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_story_project_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                         const float* count, const float* W, int64_t ldw, int64_t Hout,
+                         float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream) {
+    if (n_rows < 0 || H <= 0 || Hout <= 0) return BG_ERR_ARG;
+    if (n_rows == 0) return BG_OK;
+    if (!x || !rowptr || !count || !W || !out || ldx < H || ldw < 2 * H || ldo < 2 * Hout) return BG_ERR_ARG;
+    if (H % 4 != 0 || H > 256) return BG_ERR_SHAPE;
+    if (!bg_aligned16(x) || !bg_aligned16(W) || ldx % 4 != 0 || ldw % 4 != 0) return BG_ERR_ALIGN;
+    k_story_project<<<(unsigned)n_rows, 256, 0, (hipStream_t)stream>>>(x, ldx, rowptr, col, count, W, ldw, (int)Hout,
+                                                                      out, ldo, (int)H);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -648,6 +648,19 @@ class MaskGumbel(torch.autograd.Function):
         return d, None
 
 
+def story_project_raw(c: Csr, x: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    """[mean_s(x) W[:, :H]^T | mean_s(x) W[:, H:]^T] per segment of ``c`` (see bg_story_project_f32)."""
+    lib = _lib.load()
+    x2, W2 = _f32c(x), _f32c(W)
+    H, Hout = x2.shape[1], W2.shape[0]
+    if W2.shape[1] != 2 * H or c.count is None or x2.shape[0] != c.n_cols:
+        raise _lib.BganError("story_project: W must be [Hout, 2H] and the plan must carry segment counts")
+    out = torch.empty(c.n_rows, 2 * Hout, dtype=torch.float32, device=x.device)
+    check(lib.bg_story_project_f32(ptr(x2), _ld(x2), ptr(c.rowptr), ptr(c.col), ptr(c.count), ptr(W2), _ld(W2), Hout,
+                                   ptr(out), _ld(out), c.n_rows, H, stream()), "bg_story_project_f32")
+    return out
+
+
 def attention_forward_raw(a, logits, b, x, v, theta, plan, exp_mask, exp_att, tau: float):
     """One Attention call without an autograd graph (see bg_attention_fwd_f32).
     Returns (soft0 [Nv,1], hard0 [Nv,1], soft [Ec], hard [Ec], new voxel features [Nv,H])."""

@@ -256,11 +256,24 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
 
     def _min_len(c):
         return (c.rowptr[1:] - c.rowptr[:-1]).min() if c.n_rows > 0 else torch.ones((), dtype=torch.int32, device=dev)
+    n_per_graph = (sgr.rowptr[1:] - sgr.rowptr[:-1]).to(torch.int64)            # stories of every graph
     measured = b.chunked + [cv]                       # CSRs whose longest segment the networks want to know
     extra = torch.stack([lvl_max.to(torch.int32), _min_len(vfw), _min_len(pf), _min_len(cv), _min_len(st)] +
                         [(c.rowptr[1:] - c.rowptr[:-1]).max() if c.n_rows > 0 else lvl_max.new_zeros(()).to(torch.int32)
-                         for c in measured])
-    flags, (max_level, min_vdeg, min_pdeg, min_cross, min_story, *max_lens) = b.finish(extra)
+                         for c in measured] + [(n_per_graph * n_per_graph).sum().to(torch.int32)])
+    flags, (max_level, min_vdeg, min_pdeg, min_cross, min_story, *max_lens, nnz_ss) = b.finish(extra)
+    # stories x stories: row s lists the stories of s's graph, scaled by 1 / their number -- the building
+    # mean gathered back to the stories as ONE operator (its size is known only now, after the sync)
+    nnz_ss = int(nnz_ss)
+    if S > 0 and nnz_ss > 0:
+        deg = n_per_graph[story_graph]                                            # [S]
+        rp = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+        rp[1:] = torch.cumsum(deg, 0)
+        row_of = torch.repeat_interleave(ar_st, deg, output_size=nnz_ss)
+        within = torch.arange(nnz_ss, dtype=torch.int64, device=dev) - rp[row_of]
+        col_ss = sgr.col.to(torch.int64)[sgr.rowptr.to(torch.int64)[story_graph[row_of]] + within]
+        ss = Csr(rp.to(torch.int32), col_ss.to(torch.int32), None, S, S, nnz_ss, count=deg.to(torch.float32))
+        o["story_building_mean"] = LinOp(ss, ss.count, SCALE_DIV)
     for c, ml in zip(measured, max_lens):
         c.max_len = int(ml)
     edge_by_program.max_len = cp.max_len

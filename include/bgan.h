@@ -105,6 +105,16 @@ int bg_segreduce_sum_f32(const float* x, int64_t ldx, const int32_t* rowptr, con
                          float* partial, float* out, int64_t ldo, int64_t n_rows, int64_t H,
                          bgStream stream);
 
+/* Forward-only fusion of the generator block's per-story term: for every segment (story) s,
+ * m = mean of its rows of x (count[s] = max(len, 1)), out[s, 0:Hout] = m W[:, 0:H]^T and
+ * out[s, Hout:2Hout] = m W[:, H:2H]^T for a row-major W [Hout, 2H] (pitch ldw).  One workgroup per
+ * segment; H % 4 == 0, H <= 256.
+ * replaces: the avg_pool_x over a story and the story / building columns of updateMLP's Linear,
+ * Model/models.py:166,170, when nothing is differentiated.                                    */
+int bg_story_project_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                         const float* count, const float* W, int64_t ldw, int64_t Hout,
+                         float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream);
+
 /* Segment max with arg: out[s,h] = max_{k in seg s} x[c_k,h], arg[s,h] = c_k of the FIRST maximum
  * (slot order); an empty segment gives 0 and arg = -1.  Two phases as above;
  * partial_val / partial_arg: [n_chunks_ub, H]; chunk_ptr == NULL: one launch, a workgroup per row.
