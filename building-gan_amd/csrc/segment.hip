@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_spmm_vec(SpmmArgs a) {
             if (a.edge_w) w = a.edge_w[a.eperm ? a.eperm[k] : k];
             if (a.col_mode) w = apply_scale(w, a.col_scale[c], a.col_mode);
             float4 v = bg_ld4(xb + (int64_t)c * a.ldx);
-            acc = bg_add4(acc, bg_scale4(w, v));
+            acc = bg_fma4(w, v, acc);          // explicit fma: k_spmm_chain repeats exactly this arithmetic
         }
     }
     if (a.row_mode) {
@@ -427,6 +427,218 @@ __global__ __launch_bounds__(256) void k_story_project(const float* __restrict__
     }
 }
 
+
+// ---------------------------------------------------------------- operator chains
+// n_steps successive applications of ONE block-diagonal sparse operator to a narrow matrix in a single
+// launch:  y_k = rs * P (cs * y_{k-1}) + add_k,  k = 1..n_steps,  y_0 = x0.  A workgroup owns one diagonal
+// block (the voxels of one graph: no edge leaves a graph) and one chunk of four columns; the block's
+// rows ping-pong between two LDS images, the block's CSR (local column ids) and scales sit in LDS too,
+// and a workgroup barrier separates the steps.  Same slot order and scale arithmetic as k_spmm_vec, so
+// every step equals the corresponding separate launch.
+struct ChainArgs {
+    const float* x0; int64_t ldx;
+    const int32_t* rowptr; const int32_t* col;
+    const float* row_scale; int row_mode;
+    const float* col_scale; int col_mode;
+    const int32_t* blk_ptr; int max_rows; int max_nnz;
+    const float* add; int64_t ld_add; int64_t add_step;
+    float* out; int64_t ldo; int64_t out_step;
+    int n_steps;
+};
+
+template <bool IDX_LDS>
+__global__ __launch_bounds__(1024) void k_spmm_chain(ChainArgs a) {
+    extern __shared__ float4 chain_smem[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int32_t r0 = a.blk_ptr[blockIdx.x];
+    const int32_t nr = a.blk_ptr[blockIdx.x + 1] - r0;
+    const int cc = 4 * blockIdx.y;
+    if (nr <= 0 || nr > a.max_rows) return;                 // uniform per workgroup (host checks the plan)
+    float4* buf0 = chain_smem;
+    float4* buf1 = chain_smem + a.max_rows;
+    float* s_rs = reinterpret_cast<float*>(chain_smem + 2 * (size_t)a.max_rows);
+    float* s_cs = s_rs + a.max_rows;
+    int32_t* s_rp = reinterpret_cast<int32_t*>(s_cs + a.max_rows);
+    int32_t* s_col = s_rp + a.max_rows + 1;
+    const int32_t e0 = a.rowptr[r0];
+    const int32_t ne = a.rowptr[r0 + nr] - e0;
+    if (IDX_LDS && ne > a.max_nnz) return;
+    for (int r = tid; r < nr; r += nt) {
+        buf0[r] = bg_ld4(a.x0 + (int64_t)(r0 + r) * a.ldx + cc);
+        if (a.row_mode) s_rs[r] = a.row_scale[r0 + r];
+        if (a.col_mode) s_cs[r] = a.col_scale[r0 + r];
+    }
+    if (IDX_LDS) {
+        for (int r = tid; r <= nr; r += nt) s_rp[r] = a.rowptr[r0 + r] - e0;
+        for (int k = tid; k < ne; k += nt) s_col[k] = a.col[e0 + k] - r0;
+    }
+    __syncthreads();
+    for (int step = 1; step <= a.n_steps; ++step) {
+        const float4* src = (step & 1) ? buf0 : buf1;
+        float4* dst = (step & 1) ? buf1 : buf0;
+        const float* addk = a.add ? a.add + (int64_t)(step - 1) * a.add_step : nullptr;
+        float* outk = (a.out_step != 0 || step == a.n_steps) ? a.out + (int64_t)(step - 1) * a.out_step : nullptr;
+        for (int r = tid; r < nr; r += nt) {
+            const int64_t grow = (int64_t)r0 + r;
+            float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (addk) ad = bg_ld4(addk + grow * a.ld_add + cc);
+            int32_t kb, ke;
+            if (IDX_LDS) { kb = s_rp[r]; ke = s_rp[r + 1]; }
+            else { kb = a.rowptr[grow]; ke = a.rowptr[grow + 1]; }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int32_t k = kb; k < ke; ++k) {
+                const int32_t c = IDX_LDS ? s_col[k] : a.col[k] - r0;
+                if ((uint32_t)c >= (uint32_t)nr) continue;      // never taken on a checked plan
+                const float4 v = src[c];
+                if (a.col_mode) {
+                    float w = 1.f;
+                    w = apply_scale(w, s_cs[c], a.col_mode);
+                    acc = bg_fma4(w, v, acc);
+                } else {
+                    acc = bg_add4(acc, v);
+                }
+            }
+            if (a.row_mode) {
+                const float s = s_rs[r];
+                acc.x = apply_scale(acc.x, s, a.row_mode); acc.y = apply_scale(acc.y, s, a.row_mode);
+                acc.z = apply_scale(acc.z, s, a.row_mode); acc.w = apply_scale(acc.w, s, a.row_mode);
+            }
+            if (addk) acc = bg_add4(acc, ad);
+            dst[r] = acc;
+            if (outk) bg_st4(outk + grow * a.ldo + cc, acc);
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int BG_SEG_MAX_DEVICES = 64;
+constexpr size_t BG_CHAIN_LDS_LIMIT = 160 * 1024;
+
+size_t chain_lds_bytes(int64_t max_rows, int64_t max_nnz, bool idx) {
+    size_t b = (size_t)max_rows * (2 * 16 + 4 + 4) + (size_t)(max_rows + 1) * 4;
+    if (idx) b += (size_t)max_nnz * 4;
+    return (b + 15) & ~(size_t)15;
+}
+
+template <bool IDX_LDS>
+int launch_chain(const ChainArgs& a, int64_t n_blk, int64_t W, size_t lds, hipStream_t s) {
+    auto kern = k_spmm_chain<IDX_LDS>;
+    if (lds > 65536) {          // above the static limit: opt in once per device
+        static bool raised[BG_SEG_MAX_DEVICES] = {};
+        int dev = 0;
+        BG_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= BG_SEG_MAX_DEVICES) return BG_ERR_ARG;
+        if (!raised[dev]) {
+            BG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)BG_CHAIN_LDS_LIMIT));
+            raised[dev] = true;
+        }
+    }
+    const int nt = a.max_rows > 512 ? 1024 : (a.max_rows > 256 ? 512 : 256);
+    dim3 grid((unsigned)n_blk, (unsigned)(W / 4));
+    kern<<<grid, nt, lds, s>>>(a);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+// Fast form for short rows (every row of the operator has at most CHAIN_DEG slots, as on voxel grids: six
+// neighbours): each thread keeps the local column ids (and column weights) of its RPT rows in registers,
+// so a step is RPT x deg independent LDS reads per thread and one barrier; no index tables in LDS.
+constexpr int CHAIN_DEG = 8;
+
+template <int RPT>
+__global__ __launch_bounds__(1024) void k_spmm_chain_short(ChainArgs a) {
+    extern __shared__ float4 chain_smem[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int32_t r0 = a.blk_ptr[blockIdx.x];
+    const int32_t nr = a.blk_ptr[blockIdx.x + 1] - r0;
+    const int cc = 4 * blockIdx.y;
+    if (nr <= 0 || nr > a.max_rows || nr > RPT * nt) return;   // uniform per workgroup (host checks the plan)
+    float4* buf0 = chain_smem;
+    float4* buf1 = chain_smem + a.max_rows;
+    int32_t cols[RPT][CHAIN_DEG];
+    float wts[RPT][CHAIN_DEG];
+    int deg[RPT];
+    float rs[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = tid + i * nt;
+        deg[i] = 0; rs[i] = 1.f;
+        if (r < nr) {
+            const int64_t grow = (int64_t)r0 + r;
+            buf0[r] = bg_ld4(a.x0 + grow * a.ldx + cc);
+            const int32_t kb = a.rowptr[grow];
+            int d = a.rowptr[grow + 1] - kb;
+            d = d < CHAIN_DEG ? d : CHAIN_DEG;                  // never clipped on a checked plan (max_deg <= CHAIN_DEG)
+            deg[i] = d;
+            if (a.row_mode) rs[i] = a.row_scale[grow];
+#pragma unroll
+            for (int j = 0; j < CHAIN_DEG; ++j) {
+                cols[i][j] = 0; wts[i][j] = 1.f;
+                if (j < d) {
+                    int32_t c = a.col[kb + j] - r0;
+                    c = (uint32_t)c < (uint32_t)nr ? c : 0;     // never taken on a checked plan
+                    cols[i][j] = c;
+                    if (a.col_mode) wts[i][j] = apply_scale(1.f, a.col_scale[r0 + c], a.col_mode);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int step = 1; step <= a.n_steps; ++step) {
+        const float4* src = (step & 1) ? buf0 : buf1;
+        float4* dst = (step & 1) ? buf1 : buf0;
+        const float* addk = a.add ? a.add + (int64_t)(step - 1) * a.add_step : nullptr;
+        float* outk = (a.out_step != 0 || step == a.n_steps) ? a.out + (int64_t)(step - 1) * a.out_step : nullptr;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int r = tid + i * nt;
+            if (r < nr) {
+                const int64_t grow = (int64_t)r0 + r;
+                float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (addk) ad = bg_ld4(addk + grow * a.ld_add + cc);
+                float4 v[CHAIN_DEG];
+#pragma unroll
+                for (int j = 0; j < CHAIN_DEG; ++j)
+                    if (j < deg[i]) v[j] = src[cols[i][j]];
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < CHAIN_DEG; ++j)
+                    if (j < deg[i]) acc = a.col_mode ? bg_fma4(wts[i][j], v[j], acc) : bg_add4(acc, v[j]);
+                if (a.row_mode) {
+                    acc.x = apply_scale(acc.x, rs[i], a.row_mode); acc.y = apply_scale(acc.y, rs[i], a.row_mode);
+                    acc.z = apply_scale(acc.z, rs[i], a.row_mode); acc.w = apply_scale(acc.w, rs[i], a.row_mode);
+                }
+                if (addk) acc = bg_add4(acc, ad);
+                dst[r] = acc;
+                if (outk) bg_st4(outk + grow * a.ldo + cc, acc);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int RPT>
+int launch_chain_short(const ChainArgs& a, int64_t n_blk, int64_t W, int nt, hipStream_t s) {
+    auto kern = k_spmm_chain_short<RPT>;
+    const size_t lds = (size_t)a.max_rows * 32;
+    if (lds > 65536) {
+        static bool raised[BG_SEG_MAX_DEVICES] = {};
+        int dev = 0;
+        BG_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= BG_SEG_MAX_DEVICES) return BG_ERR_ARG;
+        if (!raised[dev]) {
+            BG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)BG_CHAIN_LDS_LIMIT));
+            raised[dev] = true;
+        }
+    }
+    dim3 grid((unsigned)n_blk, (unsigned)(W / 4));
+    kern<<<grid, nt, lds, s>>>(a);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -456,6 +668,36 @@ int bg_spmm_add_f32(const float* x, int64_t ldx, const int32_t* rowptr, const in
     SpmmArgs a{x, ldx, rowptr, col, nullptr, nullptr, row_scale, row_mode, col_scale, col_mode, out, ldo, n_rows, 0,
                add1, ld1, add2, ld2};
     return spmm_dispatch(a, H, (hipStream_t)stream);
+}
+
+int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                      const float* row_scale, int row_mode, const float* col_scale, int col_mode,
+                      const int32_t* blk_ptr, int64_t n_blk, int64_t max_rows, int64_t max_nnz, int64_t max_deg,
+                      const float* add, int64_t ld_add, int64_t add_step,
+                      float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, bgStream stream) {
+    if (n_blk < 0 || W < 0 || n_steps < 0 || max_rows < 0 || max_nnz < 0 || max_deg < 0) return BG_ERR_ARG;
+    if (n_blk == 0 || W == 0 || n_steps == 0 || max_rows == 0) return BG_OK;
+    if (!x0 || !rowptr || !col || !blk_ptr || !out || ldx < W || ldo < W || (add && ld_add < W)) return BG_ERR_ARG;
+    if ((row_mode && !row_scale) || (col_mode && !col_scale)) return BG_ERR_ARG;
+    if (W % 4 != 0 || n_blk > 65535 || W / 4 > 65535 || n_steps > (1 << 20)) return BG_ERR_SHAPE;
+    if (!bg_aligned16(x0) || !bg_aligned16(out) || ldx % 4 != 0 || ldo % 4 != 0 || out_step % 4 != 0 ||
+        (add && (!bg_aligned16(add) || ld_add % 4 != 0 || add_step % 4 != 0))) return BG_ERR_ALIGN;
+    if (max_rows > (1 << 20) || max_nnz > (1 << 26)) return BG_ERR_SHAPE;
+    ChainArgs a{x0, ldx, rowptr, col, row_scale, row_mode, col_scale, col_mode, blk_ptr, (int)max_rows, (int)max_nnz,
+                add, ld_add, add_step, out, ldo, out_step, (int)n_steps};
+    hipStream_t s = (hipStream_t)stream;
+    if (max_deg <= CHAIN_DEG && max_rows <= 2048) {
+        // short rows: indices in registers, 1 or 2 rows per thread (4 rows per thread spills)
+        if (max_rows <= 256) return launch_chain_short<1>(a, n_blk, W, 256, s);
+        if (max_rows <= 512) return launch_chain_short<1>(a, n_blk, W, 512, s);
+        if (max_rows <= 1024) return launch_chain_short<1>(a, n_blk, W, 1024, s);
+        return launch_chain_short<2>(a, n_blk, W, 1024, s);
+    }
+    size_t lds = chain_lds_bytes(max_rows, max_nnz, true);
+    if (lds <= BG_CHAIN_LDS_LIMIT) return launch_chain<true>(a, n_blk, W, lds, s);
+    lds = chain_lds_bytes(max_rows, max_nnz, false);
+    if (lds <= BG_CHAIN_LDS_LIMIT) return launch_chain<false>(a, n_blk, W, lds, s);
+    return BG_ERR_SHAPE;          // a diagonal block does not fit in LDS: run the steps as separate launches
 }
 
 int bg_segreduce_sum_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,

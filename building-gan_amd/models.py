@@ -353,8 +353,7 @@ class VoxelGNN_D(nn.Module):
             ds = (width + 3) // 4 * 4
             Z = torch.zeros(feat.shape[0], (self.layer_num + 1) * ds, device=feat.device)
             Z[:, :width] = torch.cat(cols, dim=1)
-            for k in range(1, self.layer_num + 1):
-                ops.spmm_raw(plan.vox_mean, Z[:, (k - 1) * ds:k * ds], out=Z[:, k * ds:(k + 1) * ds])
+            ops.power_chain_raw(plan.vox_mean, Z, self.layer_num, ds, plan.vox_blocks)
             plan.ops[key] = Z
         return Z
 
@@ -397,10 +396,8 @@ class VoxelGNN_D(nn.Module):
         ds = Zs.shape[1] // (L + 1)
         dl = (l.shape[1] + 3) // 4 * 4
         W = self.coefficients(feat.shape[1], ds, dl)
-        zl = [F.pad(l, (0, dl - l.shape[1]))]
-        for _ in range(L):
-            zl.append(SpMM.apply(zl[-1], plan.vox_mean))
-        return linear([Zs, torch.cat(zl, dim=1)], W, w_t=True)
+        zl = ops.PowerChain.apply(F.pad(l, (0, dl - l.shape[1])), plan.vox_mean, L, plan.vox_blocks)
+        return linear([Zs, zl.view(zl.shape[0], -1)], W, w_t=True)
 
     def collapsed_multi(self, feat, labels, plan, pdm4):
         """v_L of several label sets that share the graph (the passes of one critic update), labels
@@ -417,8 +414,7 @@ class VoxelGNN_D(nn.Module):
         Zk = torch.zeros(N, L + 1, P * dl, device=feat.device)
         for p, l in enumerate(labels):
             Zk[:, 0, p * dl:p * dl + n_lab] = l.detach()
-        for k in range(L):
-            ops.spmm_raw(plan.vox_mean, Zk[:, k], out=Zk[:, k + 1])
+        ops.power_chain_raw(plan.vox_mean, Zk, L, P * dl, plan.vox_blocks)
         Zp = Zk.view(N, L + 1, P, dl).permute(0, 2, 1, 3).contiguous().view(N, P, (L + 1) * dl)
         S = linear([Zs], Ws, w_t=True)
         return [linear([Zp[:, p]], Wl, pre_add=S, w_t=True) for p in range(P)], Wl, dl
@@ -547,11 +543,9 @@ class DiscriminatorVoxel(nn.Module):
             gpools.append(torch.autograd.grad(val, pooled, torch.ones_like(val), create_graph=True)[0])
         G2 = ops.ScatterArgPair.apply(gpools[0], arg_b, gpools[1], arg_s, N)       # [2N, 2H]: building rows first
         X = ops.MatMul.apply(G2, Wl, False, True)                                  # [2N, (L+1)*dl]
-        # unbind: ONE backward node (a stack) for the L+1 slices instead of a zero-fill + add per slice
-        Ys = X.view(2, N, L + 1, dl).permute(1, 2, 0, 3).reshape(N, L + 1, 2 * dl).unbind(dim=1)
-        acc = Ys[L]
-        for k in range(L - 1, -1, -1):
-            acc = ops.SpMMAdd.apply(acc, Ys[k], plan.vox_mean.T)
+        # sum_k (A^T)^k Y_k over both outputs' columns side by side: one launch on block-diagonal plans
+        Ys = X.view(2, N, L + 1, dl).permute(1, 2, 0, 3).reshape(N, L + 1, 2 * dl)
+        acc = ops.HornerChain.apply(Ys, plan.vox_mean.T, plan.vox_blocks)
         if stacked:
             return val_b_all, val_s_all, acc.view(N, 2, dl)      # the pad columns are exactly zero
         grad_b, _, grad_s, _ = acc.split([n_lab, dl - n_lab, n_lab, dl - n_lab], dim=1)

@@ -183,6 +183,72 @@ def scatter_arg_raw(g: torch.Tensor, arg: torch.Tensor, n_rows: int, out: Option
     return out
 
 
+_CHAIN_LDS_LIMIT = 160 * 1024      # csrc/segment.hip: BG_CHAIN_LDS_LIMIT
+
+
+def _chain_fits(op: LinOp, blocks, W: int, *ts) -> bool:
+    """Can bg_spmm_chain_f32 run this operator?  (square block-diagonal CSR with explicit columns, the
+    largest block's rows resident in LDS, 16-byte operands)"""
+    c = op.csr
+    if blocks is None or c.col is None or c.n_rows != c.n_cols or W % 4 != 0 or W == 0:
+        return False
+    if blocks.max_rows * 40 + 4 * (blocks.max_rows + 1) > _CHAIN_LDS_LIMIT:
+        return False
+    return all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 for t in ts)
+
+
+def _chain_launch(op: LinOp, blocks, x0, ldx, add, ld_add, add_step, out, ldo, out_step, n_steps, W):
+    """x0 / add / out are raw device addresses (ints); pitches and steps in floats."""
+    lib = _lib.load()
+    c = op.csr
+    check(lib.bg_spmm_chain_f32(x0, ldx, ptr(c.rowptr), ptr(c.col), ptr(op.row_scale), op.row_mode,
+                                ptr(op.col_scale), op.col_mode, ptr(blocks.ptr), blocks.n, blocks.max_rows,
+                                blocks.max_nnz, blocks.max_deg, add, ld_add, add_step, out, ldo, out_step, n_steps, W, stream()),
+          "bg_spmm_chain_f32")
+
+
+def power_chain_raw(op: LinOp, Z: torch.Tensor, L: int, W: int, blocks=None) -> torch.Tensor:
+    """In place on Z [N, (L+1)*W] (or [N, L+1, W]; row pitch = Z.stride(0)): column group k receives
+    op^k applied to column group 0, k = 1..L.  One launch when the operator is block diagonal with
+    LDS-sized blocks (plan.vox_blocks), else L launches."""
+    _lib.require_device(Z, "power_chain")
+    N = Z.shape[0]
+    Z2 = Z.view(N, -1)
+    if Z2.dtype != torch.float32 or Z2.stride(1) != 1 or Z2.shape[1] < (L + 1) * W or N != op.csr.n_cols:
+        raise _lib.BganError("power_chain: Z must be fp32 [N, >= (L+1)*W] with unit inner stride, N = the plan's rows")
+    if L <= 0 or N == 0:
+        return Z
+    if _chain_fits(op, blocks, W, Z2):
+        ld = Z2.stride(0)
+        _chain_launch(op, blocks, Z2.data_ptr(), ld, None, 0, 0, Z2.data_ptr() + 4 * W, ld, W, L, W)
+        return Z
+    for k in range(1, L + 1):
+        spmm_raw(op, Z2[:, (k - 1) * W:k * W], out=Z2[:, k * W:(k + 1) * W])
+    return Z
+
+
+def horner_chain_raw(op: LinOp, Y: torch.Tensor, L: int, W: int, blocks=None) -> torch.Tensor:
+    """sum_k op^k Y_k for Y [N, (L+1)*W] (column group k = Y_k), evaluated as
+    acc = Y_L; acc = op(acc) + Y_k for k = L-1..0.  One launch under the conditions of power_chain_raw."""
+    _lib.require_device(Y, "horner_chain")
+    N = Y.shape[0]
+    Y2 = _f32c(Y.view(N, -1))
+    if Y2.shape[1] < (L + 1) * W or N != op.csr.n_cols:
+        raise _lib.BganError("horner_chain: Y must be [N, >= (L+1)*W], N = the plan's rows")
+    if L <= 0 or N == 0:
+        return Y2[:, L * W:(L + 1) * W].clone()
+    out = torch.empty(N, W, dtype=torch.float32, device=Y.device)
+    if _chain_fits(op, blocks, W, Y2, out):
+        ld = Y2.stride(0)
+        base = Y2.data_ptr()
+        _chain_launch(op, blocks, base + 4 * L * W, ld, base + 4 * (L - 1) * W, ld, -W, out.data_ptr(), W, 0, L, W)
+        return out
+    acc = Y2[:, L * W:(L + 1) * W]
+    for k in range(L - 1, -1, -1):
+        acc = spmm_add_raw(op, acc, Y2[:, k * W:(k + 1) * W], out=out if k == 0 else None)
+    return out
+
+
 _PtrArr4 = C.c_void_p * 4
 _I64Arr4 = C.c_int64 * 4
 
@@ -296,6 +362,37 @@ class SpMMAdd(torch.autograd.Function):
     def backward(ctx, g):
         gx = SpMM.apply(g, ctx.op.T) if ctx.needs_input_grad[0] else None
         return gx, (g if ctx.needs_input_grad[1] else None), None
+
+
+class PowerChain(torch.autograd.Function):
+    """Z [N, L+1, W] = (x, op x, .., op^L x); the backward is a HornerChain over the transposed operator."""
+
+    @staticmethod
+    def forward(ctx, x, op: LinOp, L: int, blocks):
+        N, W = x.shape
+        Z = torch.empty(N, L + 1, W, dtype=torch.float32, device=x.device)
+        Z[:, 0].copy_(x)
+        power_chain_raw(op, Z, L, W, blocks)
+        ctx.op, ctx.L, ctx.blocks = op, L, blocks
+        return Z
+
+    @staticmethod
+    def backward(ctx, G):
+        return HornerChain.apply(G, ctx.op.T, ctx.blocks), None, None, None
+
+
+class HornerChain(torch.autograd.Function):
+    """sum_k op^k Y[:, k] for Y [N, L+1, W]; the backward is a PowerChain over the transposed operator."""
+
+    @staticmethod
+    def forward(ctx, Y, op: LinOp, blocks):
+        N, L1, W = Y.shape
+        ctx.op, ctx.L, ctx.blocks = op, L1 - 1, blocks
+        return horner_chain_raw(op, Y.contiguous(), L1 - 1, W, blocks)
+
+    @staticmethod
+    def backward(ctx, g):
+        return PowerChain.apply(g.contiguous(), ctx.op.T, ctx.L, ctx.blocks), None, None
 
 
 class SpMMW(torch.autograd.Function):

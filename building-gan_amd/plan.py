@@ -47,6 +47,16 @@ class Csr:
         return self.chunk_ptr is not None and self.n_rows >= 32 and 0 < self.max_len <= 4096
 
 
+@dataclass
+class VoxelBlocks:
+    """Diagonal blocks of a square operator over the voxels: block b = rows [ptr[b], ptr[b+1])."""
+    ptr: torch.Tensor          # int32 [n + 1]
+    n: int
+    max_rows: int
+    max_nnz: int
+    max_deg: int = 1 << 30     # longest row of the operator or of its transpose
+
+
 class LinOp:
     """A sparse linear map  y = diag(rs) * P * diag(cs) * x  given by a Csr, with its transpose."""
 
@@ -260,8 +270,16 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     measured = b.chunked + [cv]                       # CSRs whose longest segment the networks want to know
     extra = torch.stack([lvl_max.to(torch.int32), _min_len(vfw), _min_len(pf), _min_len(cv), _min_len(st)] +
                         [(c.rowptr[1:] - c.rowptr[:-1]).max() if c.n_rows > 0 else lvl_max.new_zeros(()).to(torch.int32)
-                         for c in measured] + [(n_per_graph * n_per_graph).sum().to(torch.int32)])
-    flags, (max_level, min_vdeg, min_pdeg, min_cross, min_story, *max_lens, nnz_ss) = b.finish(extra)
+                         for c in measured] + [(n_per_graph * n_per_graph).sum().to(torch.int32)] +
+                        # diagonal blocks of the voxel operator (one per graph): edges that leave their graph, and
+                        # the largest number of edges inside one graph
+                        [(vbi[ve[0]] != vbi[ve[1]]).sum().to(torch.int32),
+                         (lambda at: (at[1:] - at[:-1]).max() if B > 0 else lvl_max.new_zeros(()).to(torch.int32))(
+                             vfw.rowptr[gr.rowptr.long()]),
+                         torch.maximum((vfw.rowptr[1:] - vfw.rowptr[:-1]).max(), (vrv.rowptr[1:] - vrv.rowptr[:-1]).max())
+                         if Nv > 0 else lvl_max.new_zeros(()).to(torch.int32)])
+    (flags, (max_level, min_vdeg, min_pdeg, min_cross, min_story, *max_lens, nnz_ss, n_leaving, blk_nnz, vox_max_deg)
+     ) = b.finish(extra)
     # stories x stories: row s lists the stories of s's graph, scaled by 1 / their number -- the building
     # mean gathered back to the stories as ONE operator (its size is known only now, after the sync)
     nnz_ss = int(nnz_ss)
@@ -277,6 +295,13 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     for c, ml in zip(measured, max_lens):
         c.max_len = int(ml)
     edge_by_program.max_len = cp.max_len
+    # voxel rows of a graph are contiguous and no voxel edge leaves its graph (PyG batching,
+    # reference Data/VolumeDesignGraph.py:60-72): A and A^T are block diagonal, which lets a chain of
+    # applications run as one launch (ops.power_chain_raw / horner_chain_raw)
+    if B > 0 and Nv > 0 and flags["voxel_by_graph"][2] == 0 and n_leaving == 0:
+        o["vox_blocks"] = VoxelBlocks(gr.rowptr, B, gr.max_len, int(blk_nnz), int(vox_max_deg))
+    else:
+        o["vox_blocks"] = None
     o["max_level"] = int(max_level)
     o["vox_all_has"], o["prog_all_has"] = min_vdeg > 0, min_pdeg > 0
     o["stories_all_nonempty"] = min_story > 0       # then max over a graph = max over its stories' maxima

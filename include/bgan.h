@@ -90,6 +90,25 @@ int bg_spmm_add_f32(const float* x, int64_t ldx, const int32_t* rowptr, const in
                     const float* add1, int64_t ld1, const float* add2, int64_t ld2,
                     float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream);
 
+/* n_steps applications of one BLOCK-DIAGONAL square operator in a single launch:
+ *   y_0 = x0 ([n, W], pitch ldx);  y_k = rs * P (cs * y_{k-1}) + add_k,  k = 1..n_steps
+ * with P, rs, cs as in bg_spmm_f32 (no edge weights), add_k = add + (k-1)*add_step (pitch ld_add; add
+ * may be NULL; add_step may be negative).  y_k is written to out + (k-1)*out_step (pitch ldo);
+ * out_step == 0 keeps only y_{n_steps}, at out.  Rows [blk_ptr[b], blk_ptr[b+1]) form diagonal block b
+ * (the voxels of one graph): every column index of those rows must lie in the same range; max_rows /
+ * max_nnz bound the rows / slots of a block, max_deg the slots of a row (<= 8: the column ids live in
+ * registers).  One workgroup per (block, 4 columns) keeps the block in LDS between steps; BG_ERR_SHAPE when a block does not fit (the caller then launches the steps one by
+ * one with bg_spmm_add_f32).  W % 4 == 0, 16-byte aligned operands.  Each step is the same arithmetic
+ * in the same order as the separate launch.
+ * replaces: the repeated propagate() of one VoxelBlock over the SAME operator, Model/models.py:227-228
+ * (12 layers of the discriminator's linear voxel GNN, evaluated as operator powers on the input columns,
+ * and the transposed chain of its input gradient, Model/losses.py:83-84).                          */
+int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                      const float* row_scale, int row_mode, const float* col_scale, int col_mode,
+                      const int32_t* blk_ptr, int64_t n_blk, int64_t max_rows, int64_t max_nnz, int64_t max_deg,
+                      const float* add, int64_t ld_add, int64_t add_step,
+                      float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, bgStream stream);
+
 /* Same contraction for LONG rows, two phases: phase 1 reduces chunks of at most rows_per_chunk
  * slots (chunk_ptr from bg_plan_chunks, n_chunks_ub >= chunk_ptr[n_rows]) into
  * partial[n_chunks_ub, H]; phase 2 adds a row's partials in chunk order.  Deterministic.

@@ -390,3 +390,94 @@ def test_splitk_small_output_reduce(cuda):
     out = ops.gemm_tn_raw(g.to(cuda), x.to(cuda))
     ref = g.double().t() @ x.double()
     assert float((out.cpu().double() - ref).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("preset,ragged,W,L", [("small", True, 8, 5), ("dataset", False, 32, 12), ("dataset", False, 24, 12),
+                                               ("tiny", False, 4, 1)])
+def test_operator_chain_matches_separate_launches(cuda, preset, ragged, W, L):
+    """bg_spmm_chain_f32 (a workgroup per graph, rows resident in LDS between steps) against the same steps
+    as separate bg_spmm_f32 / bg_spmm_add_f32 launches: same slot order and scale arithmetic, so the
+    mean-aggregation powers are bit-exact; and against the dense fp64 operator."""
+    from building_gan_amd import ops
+    g, p = _plan(_batch(preset, 3, ragged), cuda)
+    blocks = p.vox_blocks
+    assert blocks is not None and blocks.n == p.B
+    gen = torch.Generator().manual_seed(5)
+    N = p.Nv
+    x = (torch.rand(N, W, generator=gen) * 2 - 1).to(cuda)
+    import dataclasses
+    assert blocks.max_deg <= 8                                   # grid graphs: the register-index kernel
+    general = dataclasses.replace(blocks, max_deg=1 << 20)       # same plan through the LDS-index kernel
+    for op in (p.vox_mean, p.vox_mean.T):
+        for blk in (blocks, general):
+            # powers, written into a wider buffer (row pitch > (L+1)*W exercises the pitch arguments)
+            Z = torch.zeros(N, (L + 1) * W + 4, device=cuda)
+            Z[:, :W] = x
+            Zref = Z.clone()
+            ops.power_chain_raw(op, Z, L, W, blk)
+            ops.power_chain_raw(op, Zref, L, W, None)              # L separate launches
+            assert torch.equal(Z, Zref)
+            # Horner form with addends
+            Y = (torch.rand(N, L + 1, W, generator=gen) * 2 - 1).to(cuda)
+            acc = ops.horner_chain_raw(op, Y, L, W, blk)
+            ref = ops.horner_chain_raw(op, Y, L, W, None)
+            assert torch.equal(acc, ref)
+    # dense fp64 statement of the mean-aggregation operator (oracle: scatter-mean over in-edges)
+    ve = g.voxel_edge.cpu()
+    A = torch.zeros(N, N, dtype=torch.float64)
+    A.index_put_((ve[1], ve[0]), torch.ones(ve.shape[1], dtype=torch.float64), accumulate=True)
+    A = A / A.sum(1, keepdim=True).clamp(min=1)
+    Z = torch.zeros(N, L + 1, W, device=cuda)
+    Z[:, 0] = x
+    ops.power_chain_raw(p.vox_mean, Z, L, W, blocks)
+    cur = x.double().cpu()
+    for k in range(1, L + 1):
+        cur = A @ cur
+        np.testing.assert_allclose(Z[:, k].cpu().numpy(), cur.numpy(), rtol=RTOL, atol=ATOL)
+
+
+def test_operator_chain_autograd_pair(cuda):
+    """PowerChain / HornerChain are each other's backward: gradients against a dense fp64 statement."""
+    from building_gan_amd import ops
+    g, p = _plan(_batch("small", 4, True), cuda)
+    N, W, L = p.Nv, 8, 4
+    ve = g.voxel_edge.cpu()
+    A = torch.zeros(N, N, dtype=torch.float64)
+    A.index_put_((ve[1], ve[0]), torch.ones(ve.shape[1], dtype=torch.float64), accumulate=True)
+    A = A / A.sum(1, keepdim=True).clamp(min=1)
+    gen = torch.Generator().manual_seed(6)
+    x = (torch.rand(N, W, generator=gen) * 2 - 1)
+    Gz = (torch.rand(N, L + 1, W, generator=gen) * 2 - 1)
+    xd = x.double().requires_grad_(True)
+    Zd = torch.stack([torch.linalg.matrix_power(A, k) @ xd for k in range(L + 1)], dim=1)
+    (Zd * Gz.double()).sum().backward()
+    xg = x.to(cuda).requires_grad_(True)
+    Z = ops.PowerChain.apply(xg, p.vox_mean, L, p.vox_blocks)
+    (Z * Gz.to(cuda)).sum().backward()
+    np.testing.assert_allclose(Z.detach().cpu().numpy(), Zd.detach().numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xd.grad.numpy(), rtol=RTOL, atol=ATOL)
+    # Horner over the transposed operator, gradient with respect to every addend
+    Yd = Gz.double().requires_grad_(True)
+    out_d = sum(torch.linalg.matrix_power(A.t(), k) @ Yd[:, k] for k in range(L + 1))
+    (out_d * x.double()).sum().backward()
+    Yg = Gz.to(cuda).requires_grad_(True)
+    out = ops.HornerChain.apply(Yg, p.vox_mean.T, p.vox_blocks)
+    (out * x.to(cuda)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out_d.detach().numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(Yg.grad.cpu().numpy(), Yd.grad.numpy(), rtol=RTOL, atol=ATOL)
+
+
+def test_operator_chain_rejects_oversized_blocks(cuda):
+    """A diagonal block that cannot live in LDS is refused (BG_ERR_SHAPE); the host then runs the steps one by one."""
+    from building_gan_amd import _lib, ops
+    from building_gan_amd.plan import VoxelBlocks
+    g, p = _plan(_batch("small", 4, True), cuda)
+    big = VoxelBlocks(p.vox_blocks.ptr, p.vox_blocks.n, 1 << 16, 1 << 18)
+    assert not ops._chain_fits(p.vox_mean, big, 4, torch.zeros(p.Nv, 8, device=cuda))
+    lib = _lib.load()
+    x = torch.zeros(p.Nv, 8, device=cuda)
+    c = p.vox_mean.csr
+    rc = lib.bg_spmm_chain_f32(x.data_ptr(), 8, c.rowptr.data_ptr(), c.col.data_ptr(), None, 0, None, 0,
+                               big.ptr.data_ptr(), big.n, big.max_rows, big.max_nnz, 6, None, 0, 0,
+                               x.data_ptr() + 16, 8, 0, 1, 4, torch.cuda.current_stream().cuda_stream)
+    assert rc == -2
