@@ -541,12 +541,12 @@ int launch_chain(const ChainArgs& a, int64_t n_blk, int64_t W, size_t lds, hipSt
     return BG_OK;
 }
 
-// Fast form for short rows (every row of the operator has at most CHAIN_DEG slots, as on voxel grids: six
+// Fast form for short rows (every row of the operator has at most DEG slots, as on voxel grids: six
 // neighbours): each thread keeps the local column ids (and column weights) of its RPT rows in registers,
-// so a step is RPT x deg independent LDS reads per thread and one barrier; no index tables in LDS.
-constexpr int CHAIN_DEG = 8;
-
-template <int RPT>
+// rows shorter than DEG are padded with a slot that points at an all-zero LDS row (x + 0 = x exactly),
+// so a step is RPT x DEG independent LDS reads per thread, straight-line code and one barrier; no index
+// tables in LDS.
+template <int RPT, int DEG>
 __global__ __launch_bounds__(1024) void k_spmm_chain_short(ChainArgs a) {
     extern __shared__ float4 chain_smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -554,32 +554,36 @@ __global__ __launch_bounds__(1024) void k_spmm_chain_short(ChainArgs a) {
     const int32_t nr = a.blk_ptr[blockIdx.x + 1] - r0;
     const int cc = 4 * blockIdx.y;
     if (nr <= 0 || nr > a.max_rows || nr > RPT * nt) return;   // uniform per workgroup (host checks the plan)
+    const int zero_slot = a.max_rows;                           // both images carry one extra, all-zero row
     float4* buf0 = chain_smem;
-    float4* buf1 = chain_smem + a.max_rows;
-    int32_t cols[RPT][CHAIN_DEG];
-    float wts[RPT][CHAIN_DEG];
-    int deg[RPT];
+    float4* buf1 = chain_smem + (a.max_rows + 1);
+    int32_t cols[RPT][DEG];
+    float wts[RPT][DEG];
     float rs[RPT];
+    if (tid == 0) {
+        buf0[zero_slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        buf1[zero_slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int r = tid + i * nt;
-        deg[i] = 0; rs[i] = 1.f;
+        rs[i] = 1.f;
+#pragma unroll
+        for (int j = 0; j < DEG; ++j) { cols[i][j] = zero_slot; wts[i][j] = 0.f; }
         if (r < nr) {
             const int64_t grow = (int64_t)r0 + r;
             buf0[r] = bg_ld4(a.x0 + grow * a.ldx + cc);
             const int32_t kb = a.rowptr[grow];
-            int d = a.rowptr[grow + 1] - kb;
-            d = d < CHAIN_DEG ? d : CHAIN_DEG;                  // never clipped on a checked plan (max_deg <= CHAIN_DEG)
-            deg[i] = d;
+            const int d = a.rowptr[grow + 1] - kb;              // <= DEG on a checked plan (max_deg)
             if (a.row_mode) rs[i] = a.row_scale[grow];
 #pragma unroll
-            for (int j = 0; j < CHAIN_DEG; ++j) {
-                cols[i][j] = 0; wts[i][j] = 1.f;
+            for (int j = 0; j < DEG; ++j) {
                 if (j < d) {
-                    int32_t c = a.col[kb + j] - r0;
-                    c = (uint32_t)c < (uint32_t)nr ? c : 0;     // never taken on a checked plan
-                    cols[i][j] = c;
-                    if (a.col_mode) wts[i][j] = apply_scale(1.f, a.col_scale[r0 + c], a.col_mode);
+                    const int32_t c = a.col[kb + j] - r0;
+                    if ((uint32_t)c < (uint32_t)nr) {           // always, on a checked plan
+                        cols[i][j] = c;
+                        if (a.col_mode) wts[i][j] = apply_scale(1.f, a.col_scale[r0 + c], a.col_mode);
+                    }
                 }
             }
         }
@@ -597,14 +601,17 @@ __global__ __launch_bounds__(1024) void k_spmm_chain_short(ChainArgs a) {
                 const int64_t grow = (int64_t)r0 + r;
                 float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (addk) ad = bg_ld4(addk + grow * a.ld_add + cc);
-                float4 v[CHAIN_DEG];
+                float4 v[DEG];
 #pragma unroll
-                for (int j = 0; j < CHAIN_DEG; ++j)
-                    if (j < deg[i]) v[j] = src[cols[i][j]];
+                for (int j = 0; j < DEG; ++j) v[j] = src[cols[i][j]];
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.col_mode) {
 #pragma unroll
-                for (int j = 0; j < CHAIN_DEG; ++j)
-                    if (j < deg[i]) acc = a.col_mode ? bg_fma4(wts[i][j], v[j], acc) : bg_add4(acc, v[j]);
+                    for (int j = 0; j < DEG; ++j) acc = bg_fma4(wts[i][j], v[j], acc);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < DEG; ++j) acc = bg_add4(acc, v[j]);
+                }
                 if (a.row_mode) {
                     acc.x = apply_scale(acc.x, rs[i], a.row_mode); acc.y = apply_scale(acc.y, rs[i], a.row_mode);
                     acc.z = apply_scale(acc.z, rs[i], a.row_mode); acc.w = apply_scale(acc.w, rs[i], a.row_mode);
@@ -618,10 +625,10 @@ __global__ __launch_bounds__(1024) void k_spmm_chain_short(ChainArgs a) {
     }
 }
 
-template <int RPT>
+template <int RPT, int DEG>
 int launch_chain_short(const ChainArgs& a, int64_t n_blk, int64_t W, int nt, hipStream_t s) {
-    auto kern = k_spmm_chain_short<RPT>;
-    const size_t lds = (size_t)a.max_rows * 32;
+    auto kern = k_spmm_chain_short<RPT, DEG>;
+    const size_t lds = (size_t)(a.max_rows + 1) * 32;
     if (lds > 65536) {
         static bool raised[BG_SEG_MAX_DEVICES] = {};
         int dev = 0;
@@ -637,6 +644,14 @@ int launch_chain_short(const ChainArgs& a, int64_t n_blk, int64_t W, int nt, hip
     kern<<<grid, nt, lds, s>>>(a);
     BG_LAUNCH_CHECK();
     return BG_OK;
+}
+
+template <int DEG>
+int dispatch_chain_short(const ChainArgs& a, int64_t n_blk, int64_t W, hipStream_t s) {
+    if (a.max_rows <= 256) return launch_chain_short<1, DEG>(a, n_blk, W, 256, s);
+    if (a.max_rows <= 512) return launch_chain_short<1, DEG>(a, n_blk, W, 512, s);
+    if (a.max_rows <= 1024) return launch_chain_short<1, DEG>(a, n_blk, W, 1024, s);
+    return launch_chain_short<2, DEG>(a, n_blk, W, 1024, s);
 }
 
 }  // namespace
@@ -686,12 +701,9 @@ int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const
     ChainArgs a{x0, ldx, rowptr, col, row_scale, row_mode, col_scale, col_mode, blk_ptr, (int)max_rows, (int)max_nnz,
                 add, ld_add, add_step, out, ldo, out_step, (int)n_steps};
     hipStream_t s = (hipStream_t)stream;
-    if (max_deg <= CHAIN_DEG && max_rows <= 2048) {
+    if (max_deg <= 8 && max_rows <= 2048) {
         // short rows: indices in registers, 1 or 2 rows per thread (4 rows per thread spills)
-        if (max_rows <= 256) return launch_chain_short<1>(a, n_blk, W, 256, s);
-        if (max_rows <= 512) return launch_chain_short<1>(a, n_blk, W, 512, s);
-        if (max_rows <= 1024) return launch_chain_short<1>(a, n_blk, W, 1024, s);
-        return launch_chain_short<2>(a, n_blk, W, 1024, s);
+        return max_deg <= 6 ? dispatch_chain_short<6>(a, n_blk, W, s) : dispatch_chain_short<8>(a, n_blk, W, s);
     }
     size_t lds = chain_lds_bytes(max_rows, max_nnz, true);
     if (lds <= BG_CHAIN_LDS_LIMIT) return launch_chain<true>(a, n_blk, W, lds, s);
