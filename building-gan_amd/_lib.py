@@ -46,6 +46,11 @@ SIGNATURES = {
                              _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "bg_mask_gumbel_f32": [_p, _i64, _p, _p, _p, _i64, _p],
     "bg_mask_gumbel_bwd_f32": [_p, _p, _p, _p, _i64, _p],
+    "bg_gp_sample_f32": [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p],
+    "bg_pack_columns_f32": [_p, _p, _int, _i64, _i64, _p, _i64, _i64, _p],
+    "bg_construct_output_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _p],
+    "bg_critic_loss_f32": [_p, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _f, _p, _p, _p],
+    "bg_critic_loss_bwd_f32": [_p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _f, _p, _p, _p, _p],
     "bg_gemm_f32": [_int, _int, _i64, _i64, _int, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _int, _f, _p, _i64, _p, _i64,
                     _p, _p],
     "bg_gemm_tn_splitk_f32": [_i64, _i64, _p, _i64, _int, _p, _p, _p, _p, _i64, _p, _i32, _p],

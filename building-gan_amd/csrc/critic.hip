@@ -1,0 +1,230 @@
+// Small per-voxel kernels around the critic update and the generator's output stage: each replaces a
+// chain of stock elementwise / reduction / scatter launches of a few microseconds of work apiece
+// (the step is launch-bound at batch 8), keeping the reference's operation order.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_CLASS = 8;
+
+// reference Model/losses.py:76-79: mixed = label*u + out*(1-u); nonzero = (max(mixed) != 0);
+// sample = ((onehot(first argmax) - mixed) + mixed) * nonzero.  No fused multiply-adds: every product and
+// sum is rounded separately, as the separate elementwise launches of the reference do.
+__global__ void k_gp_sample(const float* __restrict__ label, int64_t ldl, const float* __restrict__ out, int64_t ldo,
+                            const float* __restrict__ u, float* __restrict__ sample, int64_t lds, int64_t n, int C) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const float uv = u[v];
+    const float one_minus = __fsub_rn(1.f, uv);
+    float m[MAX_CLASS];
+    float best = 0.f; int arg = 0;
+#pragma unroll
+    for (int j = 0; j < MAX_CLASS; ++j) {
+        if (j < C) {
+            m[j] = __fadd_rn(__fmul_rn(label[v * ldl + j], uv), __fmul_rn(out[v * ldo + j], one_minus));
+            if (j == 0 || m[j] > best) { best = m[j]; arg = j; }
+        }
+    }
+    const float nonzero = best != 0.f ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_CLASS; ++j) {
+        if (j < C) {
+            const float hard = __fadd_rn(__fsub_rn(j == arg ? 1.f : 0.f, m[j]), m[j]);
+            sample[v * lds + j] = __fmul_rn(hard, nonzero);
+        }
+    }
+}
+
+// dst[v, p*group + j] = j < C ? src_p[v, j] : 0   for p < n_src, j < group
+struct PackArgs { const float* src[4]; int64_t ld[4]; };
+__global__ void k_pack_columns(PackArgs a, int n_src, int C, int group, float* __restrict__ dst, int64_t ldd, int64_t n) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int width = n_src * group;
+    if (t >= n * width) return;
+    const int64_t v = t / width; const int c = (int)(t % width);
+    const int p = c / group, j = c % group;
+    dst[v * ldd + c] = j < C ? a.src[p][v * a.ld[p] + j] : 0.f;
+}
+
+// reference Model/models.py:128-141 (Attention.construct_output) + util_graph.py:44-48, one thread per voxel
+// over its cross edges in slot order (= edge order: the edges are voxel-major): first arg-max slot of
+// att_hard * mask_hard, the hard and soft class-label sums, both multiplied by the hard mask.
+__global__ void k_construct_output(const float* __restrict__ mask_hard, const float* __restrict__ att_hard,
+                                   const float* __restrict__ att_soft, const int32_t* __restrict__ rowptr,
+                                   const int32_t* __restrict__ col, const float* __restrict__ cls, int64_t ldc, int C,
+                                   float* __restrict__ out, float* __restrict__ soft_out, int64_t* __restrict__ idx,
+                                   int64_t n) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const float mh = mask_hard[v];
+    float hs[MAX_CLASS], ss[MAX_CLASS];
+#pragma unroll
+    for (int j = 0; j < MAX_CLASS; ++j) { hs[j] = 0.f; ss[j] = 0.f; }
+    float best = 0.f; int32_t arg = -1;
+    for (int32_t k = rowptr[v]; k < rowptr[v + 1]; ++k) {
+        const float ah = att_hard[k], as = att_soft[k];
+        const float logit = __fmul_rn(ah, mh);
+        if (arg < 0 || logit > best) { best = logit; arg = k; }
+        const float* c = cls + (int64_t)col[k] * ldc;
+#pragma unroll
+        for (int j = 0; j < MAX_CLASS; ++j) {
+            if (j < C) {
+                const float cj = c[j];
+                hs[j] = __fadd_rn(hs[j], __fmul_rn(ah, cj));
+                ss[j] = __fadd_rn(ss[j], __fmul_rn(as, cj));
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAX_CLASS; ++j) {
+        if (j < C) {
+            out[v * C + j] = __fmul_rn(mh, hs[j]);
+            soft_out[v * C + j] = __fmul_rn(mh, ss[j]);
+        }
+    }
+    idx[v] = arg >= 0 ? (int64_t)col[arg] : -1;
+}
+
+// WGAN-GP critic objective (reference Model/losses.py:14-19,85-87 with global-count means):
+//   loss = <val_b, wb> + <val_s, ws> + coef * sum_r (||g_r|| - 1)^2      over the n_rows rows g_r of `grads`
+// Phase 1 writes one partial sum per workgroup (fixed order inside a workgroup), phase 2 adds the
+// partials in order: deterministic.
+constexpr int LOSS_BLOCKS = 64;
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = bg_wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    if (threadIdx.x == 0) s = (red[0] + red[1]) + (red[2] + red[3]);
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_critic_loss_partial(const float* __restrict__ val_b, const float* __restrict__ wb, int64_t nb,
+                                                             const float* __restrict__ val_s, const float* __restrict__ ws, int64_t ns,
+                                                             const float* __restrict__ grads, int64_t ldg, int64_t n_rows, int W,
+                                                             float coef, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (int64_t i = t0; i < nb; i += stride) acc = fmaf(val_b[i], wb[i], acc);
+    for (int64_t i = t0; i < ns; i += stride) acc = fmaf(val_s[i], ws[i], acc);
+    float pen = 0.f;
+    for (int64_t r = t0; r < n_rows; r += stride) {
+        const float* g = grads + r * ldg;
+        float sq = 0.f;
+        for (int j = 0; j < W; ++j) sq = fmaf(g[j], g[j], sq);
+        const float d = sqrtf(sq) - 1.f;
+        pen = fmaf(d, d, pen);
+    }
+    acc = fmaf(coef, pen, acc);
+    const float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    __syncthreads();
+    const float sp = block_sum_256(pen, red);
+    if (threadIdx.x == 0) partial[LOSS_BLOCKS + blockIdx.x] = sp;
+}
+
+__global__ void k_critic_loss_final(const float* __restrict__ partial, int n, float* __restrict__ loss) {
+    if (threadIdx.x < 2 && blockIdx.x == 0) {      // loss[0] = the objective, loss[1] = the bare penalty sum
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += partial[threadIdx.x * n + i];
+        loss[threadIdx.x] = s;
+    }
+}
+
+// gradient of the objective, scaled by the upstream scalar go[0]:
+//   d val_b = go * wb ; d val_s = go * ws ; d g_r = go * coef * 2 (||g_r|| - 1) / ||g_r|| * g_r  (0 where ||g_r|| = 0)
+__global__ void k_critic_loss_bwd(const float* __restrict__ go, const float* __restrict__ wb, int64_t nb,
+                                  const float* __restrict__ ws, int64_t ns,
+                                  const float* __restrict__ grads, int64_t ldg, int64_t n_rows, int W, float coef,
+                                  float* __restrict__ d_val_b, float* __restrict__ d_val_s, float* __restrict__ d_grads) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float g0 = go[0];
+    if (t < nb && d_val_b) d_val_b[t] = g0 * wb[t];
+    if (t < ns && d_val_s) d_val_s[t] = g0 * ws[t];
+    if (t < n_rows && d_grads) {
+        const float* g = grads + t * ldg;
+        float sq = 0.f;
+        for (int j = 0; j < W; ++j) sq = fmaf(g[j], g[j], sq);
+        const float nrm = sqrtf(sq);
+        const float f = nrm > 0.f ? g0 * coef * 2.f * (nrm - 1.f) / nrm : 0.f;
+        for (int j = 0; j < W; ++j) d_grads[t * W + j] = f * g[j];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bg_gp_sample_f32(const float* label, int64_t ldl, const float* out, int64_t ldo, const float* u,
+                     float* sample, int64_t lds, int64_t n, int64_t C, bgStream stream) {
+    if (n < 0 || C < 0) return BG_ERR_ARG;
+    if (n == 0 || C == 0) return BG_OK;
+    if (!label || !out || !u || !sample || ldl < C || ldo < C || lds < C) return BG_ERR_ARG;
+    if (C > MAX_CLASS) return BG_ERR_SHAPE;
+    k_gp_sample<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(label, ldl, out, ldo, u, sample, lds, n, (int)C);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_pack_columns_f32(const float* const* src, const int64_t* ld, int n_src, int64_t C, int64_t group,
+                        float* dst, int64_t ldd, int64_t n, bgStream stream) {
+    if (n < 0 || C < 0 || group < C || n_src < 1 || n_src > 4) return BG_ERR_ARG;
+    if (n == 0 || group == 0) return BG_OK;
+    if (!src || !ld || !dst || ldd < n_src * group) return BG_ERR_ARG;
+    PackArgs a{};
+    for (int p = 0; p < n_src; ++p) {
+        if (!src[p] || ld[p] < C) return BG_ERR_ARG;
+        a.src[p] = src[p]; a.ld[p] = ld[p];
+    }
+    k_pack_columns<<<bg_grid_for(n * n_src * group, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(a, n_src, (int)C, (int)group,
+                                                                                                    dst, ldd, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_construct_output_f32(const float* mask_hard, const float* att_hard, const float* att_soft,
+                            const int32_t* rowptr, const int32_t* col, const float* cls, int64_t ldc, int64_t C,
+                            float* out, float* soft_out, int64_t* idx, int64_t n_vox, bgStream stream) {
+    if (n_vox < 0 || C < 0) return BG_ERR_ARG;
+    if (n_vox == 0) return BG_OK;
+    if (!mask_hard || !att_hard || !att_soft || !rowptr || !col || !cls || !out || !soft_out || !idx || ldc < C) return BG_ERR_ARG;
+    if (C > MAX_CLASS) return BG_ERR_SHAPE;
+    k_construct_output<<<bg_grid_for(n_vox, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(mask_hard, att_hard, att_soft, rowptr, col,
+                                                                                            cls, ldc, (int)C, out, soft_out, idx, n_vox);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_critic_loss_f32(const float* val_b, const float* wb, int64_t nb, const float* val_s, const float* ws, int64_t ns,
+                       const float* grads, int64_t ldg, int64_t n_rows, int64_t W, float coef,
+                       float* partial, float* loss, bgStream stream) {
+    if (nb < 0 || ns < 0 || n_rows < 0 || W < 0) return BG_ERR_ARG;
+    if (!partial || !loss || (nb > 0 && (!val_b || !wb)) || (ns > 0 && (!val_s || !ws))) return BG_ERR_ARG;
+    if (n_rows > 0 && (!grads || ldg < W)) return BG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    k_critic_loss_partial<<<LOSS_BLOCKS, 256, 0, s>>>(val_b, wb, nb, val_s, ws, ns, grads, ldg, n_rows, (int)W, coef, partial);
+    BG_LAUNCH_CHECK();
+    k_critic_loss_final<<<1, 64, 0, s>>>(partial, LOSS_BLOCKS, loss);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_critic_loss_bwd_f32(const float* go, const float* wb, int64_t nb, const float* ws, int64_t ns,
+                           const float* grads, int64_t ldg, int64_t n_rows, int64_t W, float coef,
+                           float* d_val_b, float* d_val_s, float* d_grads, bgStream stream) {
+    if (nb < 0 || ns < 0 || n_rows < 0 || W < 0 || !go) return BG_ERR_ARG;
+    if ((d_val_b && !wb) || (d_val_s && !ws) || (d_grads && (!grads || ldg < W))) return BG_ERR_ARG;
+    int64_t work = nb > ns ? nb : ns;
+    if (n_rows > work) work = n_rows;
+    if (work == 0) return BG_OK;
+    k_critic_loss_bwd<<<bg_grid_for(work, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(go, wb, nb, ws, ns, grads, ldg, n_rows, (int)W,
+                                                                                          coef, d_val_b, d_val_s, d_grads);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+}  // extern "C"

@@ -29,6 +29,7 @@ NUMBER_OF_CLASS = 6  # /root/reference/Data/GraphConstructor.py:9
 COMPOSE_BLOCKS = True  # collapse messageMLP into updateMLP where legal (VoxelBlock.compose)
 COMPOSE_STACK = True   # run the discriminator's 12 composed layers as one autograd node (ops.AffineStack)
 FUSE_STORY_TERM = True  # generator block: story mean + its projections in one launch when no graph is built
+FUSE_OUTPUT = True     # construct_output as one launch when no autograd graph is being built
 FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is being built
 COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
 
@@ -208,6 +209,10 @@ class Attention(nn.Module):
 
     @staticmethod
     def construct_output(program_class_feature, num_voxel, att, mask, plan, cross_edge_program_index):
+        if (FUSE_OUTPUT and not torch.is_grad_enabled() and program_class_feature.shape[1] <= 8
+                and plan.ops["flags"]["cross_by_voxel"][1] == 0):
+            # nothing will be differentiated: one launch (slots are in edge order on voxel-major cross edges)
+            return ops.construct_output_raw(mask["hard"], att["hard"], att["soft"], plan, program_class_feature)
         on_edge = SpMM.apply(mask["hard"], plan.edge_voxel_gather)
         arg = ops.seg_argmax(att["hard"] * on_edge, plan)
         max_out_program_index = cross_edge_program_index[arg.long()]
@@ -411,9 +416,8 @@ class VoxelGNN_D(nn.Module):
         dl = (n_lab + 3) // 4 * 4
         W = self.coefficients(feat.shape[1], ds, dl)
         Ws, Wl = W.split([(L + 1) * ds, (L + 1) * dl], dim=0)
-        Zk = torch.zeros(N, L + 1, P * dl, device=feat.device)
-        for p, l in enumerate(labels):
-            Zk[:, 0, p * dl:p * dl + n_lab] = l.detach()
+        Zk = torch.empty(N, L + 1, P * dl, device=feat.device)       # group 0 packed here, the rest by the chain
+        ops.pack_columns_raw([l.detach() for l in labels], dl, Zk.view(N, -1))
         ops.power_chain_raw(plan.vox_mean, Zk, L, P * dl, plan.vox_blocks)
         Zp = Zk.view(N, L + 1, P, dl).permute(0, 2, 1, 3).contiguous().view(N, P, (L + 1) * dl)
         S = linear([Zs], Ws, w_t=True)

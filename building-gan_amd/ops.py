@@ -788,6 +788,98 @@ def seg_argmax(logit: torch.Tensor, plan) -> torch.Tensor:
     return arg
 
 
+
+# ------------------------------------------------------------------------------- critic-update glue
+def gp_sample_raw(label: torch.Tensor, out: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    """The gradient penalty's sample point (reference losses.py:76-79) in one launch; inputs are data."""
+    lib = _lib.load()
+    _lib.require_device(label, "gp_sample")
+    l2, o2, u2 = _f32c(label), _f32c(out), _f32c(u.reshape(-1))
+    n, Cn = l2.shape
+    if tuple(o2.shape) != (n, Cn) or u2.numel() != n:
+        raise _lib.BganError("gp_sample: label / out must be [n, C] and u must hold n weights")
+    sample = torch.empty(n, Cn, dtype=torch.float32, device=label.device)
+    check(lib.bg_gp_sample_f32(ptr(l2), _ld(l2), ptr(o2), _ld(o2), ptr(u2), ptr(sample), Cn, n, Cn, stream()),
+          "bg_gp_sample_f32")
+    return sample
+
+
+def pack_columns_raw(srcs: Sequence[torch.Tensor], group: int, dst: torch.Tensor) -> torch.Tensor:
+    """dst[:, p*group + j] = srcs[p][:, j] (zero for j >= C): label sets side by side in padded column groups."""
+    lib = _lib.load()
+    ss = [_f32c(t) for t in srcs]
+    n, Cn = ss[0].shape
+    if len(ss) > 4 or any(tuple(t.shape) != (n, Cn) for t in ss) or dst.shape[0] != n or dst.stride(-1) != 1:
+        raise _lib.BganError("pack_columns: 1..4 sources of one shape, dst with matching rows")
+    pa = _PtrArr4(*([t.data_ptr() for t in ss] + [None] * (4 - len(ss))))
+    la = _I64Arr4(*([_ld(t) for t in ss] + [0] * (4 - len(ss))))
+    check(lib.bg_pack_columns_f32(pa, la, len(ss), Cn, group, ptr(dst), dst.stride(0), n, stream()), "bg_pack_columns_f32")
+    return dst
+
+
+def construct_output_raw(mask_hard, att_hard, att_soft, plan, cls):
+    """Attention.construct_output without an autograd graph: (out [Nv,C], soft_out [Nv,C], idx [Nv] int64)."""
+    lib = _lib.load()
+    _lib.require_device(mask_hard, "construct_output")
+    cv = plan.cross_v
+    mh, ah, asf, c2 = (_f32c(mask_hard.reshape(-1)), _f32c(att_hard.reshape(-1)), _f32c(att_soft.reshape(-1)), _f32c(cls))
+    if mh.numel() != cv.n_rows or ah.numel() != cv.nnz or asf.numel() != cv.nnz or c2.shape[0] != cv.n_cols:
+        raise _lib.BganError("construct_output: operand sizes do not match the plan")
+    n, Cn = cv.n_rows, c2.shape[1]
+    out = torch.empty(n, Cn, dtype=torch.float32, device=mh.device)
+    soft = torch.empty(n, Cn, dtype=torch.float32, device=mh.device)
+    idx = torch.empty(n, dtype=torch.int64, device=mh.device)
+    check(lib.bg_construct_output_f32(ptr(mh), ptr(ah), ptr(asf), ptr(cv.rowptr), ptr(cv.col), ptr(c2), _ld(c2), Cn,
+                                      ptr(out), ptr(soft), ptr(idx), n, stream()), "bg_construct_output_f32")
+    return out, soft, idx
+
+
+class CriticLoss(torch.autograd.Function):
+    """(<val_b, wb> + <val_s, ws> + coef * sum_r (||grads_r|| - 1)^2,  sum_r (||grads_r|| - 1)^2) as one node (two
+    launches forward, one backward); first-order autograd; the second output is for logging.  ``grads``
+    [.., W] may be None (no penalty)."""
+
+    @staticmethod
+    def forward(ctx, val_b, val_s, grads, wb, ws, coef: float):
+        lib = _lib.load()
+        vb, vs = _f32c(val_b.reshape(-1)), _f32c(val_s.reshape(-1))
+        if vb.numel() != wb.numel() or vs.numel() != ws.numel():
+            raise _lib.BganError("critic_loss: weights must match the values")
+        g2 = None
+        if grads is not None:
+            g2 = _f32c(grads.reshape(-1, grads.shape[-1]))
+        dev = vb.device
+        partial = torch.empty(128, dtype=torch.float32, device=dev)
+        loss = torch.empty(2, dtype=torch.float32, device=dev)
+        n_rows, W = (g2.shape if g2 is not None else (0, 0))
+        check(lib.bg_critic_loss_f32(ptr(vb), ptr(wb), vb.numel(), ptr(vs), ptr(ws), vs.numel(), ptr(g2),
+                                     _ld(g2) if g2 is not None else 0, n_rows, W, float(coef), ptr(partial), ptr(loss),
+                                     stream()), "bg_critic_loss_f32")
+        ctx.coef = float(coef)
+        ctx.shapes = (val_b.shape, val_s.shape, None if grads is None else grads.shape)
+        ctx.save_for_backward(wb, ws, g2)
+        total, pen = loss[0], loss[1]
+        ctx.mark_non_differentiable(pen)
+        return total, pen
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go, _gpen):
+        lib = _lib.load()
+        wb, ws, g2 = ctx.saved_tensors
+        sb, ss, sg = ctx.shapes
+        dev = wb.device
+        go = _f32c(go.reshape(1))
+        db = torch.empty(sb, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        ds = torch.empty(ss, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        dg = torch.empty(sg, dtype=torch.float32, device=dev) if (g2 is not None and ctx.needs_input_grad[2]) else None
+        n_rows, W = (g2.shape if g2 is not None else (0, 0))
+        check(lib.bg_critic_loss_bwd_f32(ptr(go), ptr(wb), wb.numel(), ptr(ws), ws.numel(), ptr(g2),
+                                         _ld(g2) if g2 is not None else 0, n_rows, W, ctx.coef, ptr(db), ptr(ds), ptr(dg),
+                                         stream()), "bg_critic_loss_bwd_f32")
+        return db, ds, dg, None, None, None
+
+
 def adam_step(param, grad, m, v, lr, beta1, beta2, eps, step, step_dev=None):
     """``step`` (host int) or ``step_dev`` (int32 device tensor holding the step count)."""
     lib = _lib.load()

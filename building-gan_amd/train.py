@@ -222,12 +222,14 @@ class Trainer:
                 gp = None
                 fused = None
                 if fused_ok:
-                    sample = (self._gp_sample(batch.voxel_label.detach(), soft_out.detach(), u)
-                              if self.gp_lambda != 0 else None)
+                    sample = None
+                    if self.gp_lambda != 0:      # labels are data in the fused pass: the sample point in one launch
+                        sample = ops.gp_sample_raw(batch.voxel_label, soft_out.detach(),
+                                                   u if u is not None else torch.rand(out.shape[0], device=dev))
                     fused = D.critic_terms(batch, batch.voxel_label, out.detach(), sample, stacked=True)
                 if fused is not None:
                     val_b_all, val_s_all, grads = fused
-                    if grads is not None:          # both penalties at once: grads[:, 0] and grads[:, 1]
+                    if grads is not None and self.gan_loss != "WGANGP":   # both penalties at once: grads[:, 0] and grads[:, 1]
                         gp = ((grads.norm(2, 2) - 1) ** 2).sum() / Nvg
                 else:
                     fake_b, fake_s = D(detach_batch(batch), out.detach())
@@ -238,8 +240,11 @@ class Trainer:
         if do_d:
             if fused is not None and self.gan_loss == "WGANGP":
                 # -E[real] + E[fake] over graphs and over stories as two dot products with +-1/count weights
+                # and the penalty lambda/Nv * sum (||grad|| - 1)^2 over both outputs' gradients: ONE node
                 wb, ws = self._critic_weights(val_b_all.shape[0] // 2, val_s_all.shape[0] // 2, Bg, Sg, dev)
-                d_loss = torch.dot(val_b_all.view(-1), wb) + torch.dot(val_s_all.view(-1), ws)
+                d_loss, pen = ops.CriticLoss.apply(val_b_all, val_s_all, grads, wb, ws, self.gp_lambda / Nvg)
+                if grads is not None:
+                    stats["gp"] = pen / Nvg
             else:
                 if fused is not None:
                     (real_b, fake_b), (real_s, fake_s) = val_b_all.chunk(2, dim=0), val_s_all.chunk(2, dim=0)

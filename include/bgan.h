@@ -217,6 +217,48 @@ int bg_attention_fwd_f32(const float* a, int64_t lda, const float* logits, int64
                          float* soft0, float* hard0, float* soft, float* hard,
                          float* out, int64_t ldo, int64_t n_vox, int64_t H, bgStream stream);
 
+/* ------------------------------------------------------------------ critic update ------ */
+
+/* The sample at which the gradient penalty is taken: mixed = label*u + out*(1-u) (u [n]: one weight per
+ * voxel), nonzero = (max_j mixed != 0), sample = ((onehot(first argmax) - mixed) + mixed) * nonzero;
+ * every product / sum rounded separately (no fma), C <= 8 classes.
+ * replaces: Model/losses.py:77-79 (incl. util.py:6-10 softmax_to_hard): 13 elementwise / reduce /
+ * scatter launches.                                                                             */
+int bg_gp_sample_f32(const float* label, int64_t ldl, const float* out, int64_t ldo, const float* u,
+                     float* sample, int64_t lds, int64_t n, int64_t C, bgStream stream);
+
+/* dst[v, p*group + j] = j < C ? src[p][v, j] : 0 for p < n_src (<= 4), j < group: several label sets side
+ * by side in zero-padded column groups (the step-0 operand of bg_spmm_chain_f32).
+ * replaces: torch.zeros + one strided copy per label set in front of Model/models.py:221 (label_enc). */
+int bg_pack_columns_f32(const float* const* src, const int64_t* ld, int n_src, int64_t C, int64_t group,
+                        float* dst, int64_t ldd, int64_t n, bgStream stream);
+
+/* Generator output stage, forward only, one thread per voxel over its cross edges (CSR by voxel, slots in
+ * edge order): idx[v] = col of the first maximum of att_hard*mask_hard; out[v,:] = mask_hard * sum att_hard *
+ * cls[col,:]; soft_out likewise with att_soft.  out / soft_out are [n_vox, C] contiguous, C <= 8.
+ * replaces: Model/models.py:128-141 (Attention.construct_output) + util_graph.py:44-48 when nothing is
+ * differentiated.                                                                               */
+int bg_construct_output_f32(const float* mask_hard, const float* att_hard, const float* att_soft,
+                            const int32_t* rowptr, const int32_t* col, const float* cls, int64_t ldc, int64_t C,
+                            float* out, float* soft_out, int64_t* idx, int64_t n_vox, bgStream stream);
+
+/* WGAN-GP critic objective in two launches:
+ *   loss[0] = <val_b, wb> + <val_s, ws> + coef * sum_r (||grads[r, 0:W]|| - 1)^2 ,  r < n_rows
+ * (wb / ws carry the -+1/count weights of the real / fake means; grads may be NULL with n_rows = 0);
+ * loss[1] = the bare penalty sum (for logging).  partial: float[128] workspace.  Deterministic (fixed
+ * partition, partials added in order).
+ * replaces: Model/losses.py:16-19,85-87 and the d_loss sum of train.py:98.                      */
+int bg_critic_loss_f32(const float* val_b, const float* wb, int64_t nb, const float* val_s, const float* ws, int64_t ns,
+                       const float* grads, int64_t ldg, int64_t n_rows, int64_t W, float coef,
+                       float* partial, float* loss, bgStream stream);
+
+/* Its gradient for the upstream scalar go[0]: d_val_b = go*wb, d_val_s = go*ws,
+ * d_grads[r,:] = go * coef * 2 (||g_r|| - 1) / ||g_r|| * g_r (0 where the norm is 0); d_grads is [n_rows, W]
+ * contiguous; any output may be NULL.                                                           */
+int bg_critic_loss_bwd_f32(const float* go, const float* wb, int64_t nb, const float* ws, int64_t ns,
+                           const float* grads, int64_t ldg, int64_t n_rows, int64_t W, float coef,
+                           float* d_val_b, float* d_val_s, float* d_grads, bgStream stream);
+
 /* ------------------------------------------------------------------ dense (fp32 MFMA) --- */
 
 #define BG_ACT_NONE 0

@@ -482,3 +482,97 @@ def test_operator_chain_rejects_oversized_blocks(cuda):
                                big.ptr.data_ptr(), big.n, big.max_rows, big.max_nnz, 6, None, 0, 0,
                                x.data_ptr() + 16, 8, 0, 1, 4, torch.cuda.current_stream().cuda_stream)
     assert rc == -2
+
+
+def test_gp_sample_matches_reference_formula(cuda):
+    """bg_gp_sample_f32 against the reference's elementwise chain (losses.py:76-79) on the CPU: bit-exact,
+    including void voxels (all-zero rows -> sample 0) and exact ties (first index wins)."""
+    from building_gan_amd import ops
+    from oracle.pointer import softmax_to_hard
+    gen = torch.Generator().manual_seed(9)
+    n = 5000
+    label = torch.zeros(n, 6)
+    cls = torch.randint(0, 7, (n,), generator=gen)
+    label[torch.arange(n)[cls < 6], cls[cls < 6]] = 1.0          # class 6 = void: all-zero row
+    out = torch.rand(n, 6, generator=gen) * (torch.rand(n, 1, generator=gen) > 0.3)   # masked rows are zero
+    out[:50] = 0.25                                               # ties
+    label[:50] = 0.0
+    u = torch.rand(n, 1, generator=gen)
+    mixed = label * u + out * (1 - u)
+    nonzero = (mixed.max(dim=-1)[0] != 0).type(torch.float32).view(-1, 1)
+    ref = softmax_to_hard(mixed, -1) * nonzero
+    got = ops.gp_sample_raw(label.to(cuda), out.to(cuda), u.to(cuda))
+    assert torch.equal(got.cpu(), ref)
+
+
+def test_pack_columns(cuda):
+    from building_gan_amd import ops
+    gen = torch.Generator().manual_seed(10)
+    srcs = [torch.rand(777, 6, generator=gen) for _ in range(3)]
+    dst = torch.full((777, 13 * 24), -1.0, device=cuda)
+    ops.pack_columns_raw([s.to(cuda) for s in srcs], 8, dst)
+    ref = torch.cat([torch.nn.functional.pad(s, (0, 2)) for s in srcs], dim=1)
+    assert torch.equal(dst[:, :24].cpu(), ref)
+    assert bool((dst[:, 24:] == -1.0).all())
+
+
+def test_construct_output_fused_matches_oracle(cuda):
+    """bg_construct_output_f32 (no autograd graph) against the oracle's construct_output: labels within fp32
+    rounding of the scatter sums, arg-max program index bit-exact (ties and masked voxels: first edge)."""
+    from building_gan_amd import ops
+    from oracle.networks import Attention as OA
+    cpu = _batch("small", 11, True)
+    import copy
+    g, p = _plan(copy.deepcopy(cpu), cuda)
+    gen = torch.Generator().manual_seed(11)
+    Nv, Ec = p.Nv, p.Ec
+    mask_hard = (torch.rand(Nv, 1, generator=gen) > 0.4).float()
+    att_soft = torch.rand(Ec, 1, generator=gen)
+    cev = cpu.cross_edge_voxel_index_select
+    win = torch.zeros(Ec, 1)
+    first = torch.zeros(Nv, dtype=torch.long).scatter_reduce_(0, cev, torch.arange(Ec), "amin", include_self=False)
+    last = torch.zeros(Nv, dtype=torch.long).scatter_reduce_(0, cev, torch.arange(Ec), "amax", include_self=False)
+    pick = first + (torch.rand(Nv, generator=gen) * (last - first + 1).float()).long().clamp(max=10 ** 9)
+    pick = torch.minimum(pick, last)
+    win[pick] = 1.0
+    att_hard = (win - att_soft) + att_soft                      # straight-through values, not exactly 1.0
+    att = {"hard": att_hard, "soft": att_soft}
+    mask = {"hard": mask_hard, "soft": mask_hard}
+    ro = OA.construct_output(cpu.program_class_feature, Nv, att, mask, cpu.cross_edge_program_index_select, cev)
+    out, soft, idx = ops.construct_output_raw(mask_hard.to(cuda), att_hard.to(cuda), att_soft.to(cuda), p,
+                                              g.program_class_feature)
+    np.testing.assert_allclose(out.cpu().numpy(), ro[0].numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(soft.cpu().numpy(), ro[1].numpy(), rtol=1e-6, atol=1e-7)
+    assert torch.equal(idx.cpu(), ro[2])
+
+
+def test_critic_loss_node(cuda):
+    """ops.CriticLoss against the stock formula: value, penalty and all three gradients."""
+    from building_gan_amd import ops
+    gen = torch.Generator().manual_seed(12)
+    B, S, N = 8, 80, 3000
+    vb = torch.randn(2 * B, 1, generator=gen, dtype=torch.float64)
+    vs = torch.randn(2 * S, 1, generator=gen, dtype=torch.float64)
+    gr = torch.randn(N, 2, 8, generator=gen, dtype=torch.float64)
+    gr[:, :, 6:] = 0
+    gr[5] = 0                                                     # a zero-norm row: gradient 0, value (0-1)^2
+    wb = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B)])
+    ws = torch.cat([torch.full((S,), -1.0 / S), torch.full((S,), 1.0 / S)])
+    coef = 10.0 / N
+    for t in (vb, vs, gr):
+        t.requires_grad_(True)
+    pen_ref = ((gr.norm(2, 2) - 1) ** 2).sum()
+    ref = torch.dot(vb.view(-1), wb.double()) + torch.dot(vs.view(-1), ws.double()) + coef * pen_ref
+    (3.0 * ref).backward()
+    hb, hs, hg = (t.detach().float().to(cuda).requires_grad_(True) for t in (vb, vs, gr))
+    loss, pen = ops.CriticLoss.apply(hb, hs, hg, wb.to(cuda), ws.to(cuda), coef)
+    (3.0 * loss).backward()
+    np.testing.assert_allclose(float(loss.detach()), float(ref.detach()), rtol=1e-5)
+    np.testing.assert_allclose(float(pen), float(pen_ref.detach()), rtol=1e-5)
+    np.testing.assert_allclose(hb.grad.cpu().numpy(), vb.grad.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(hs.grad.cpu().numpy(), vs.grad.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(hg.grad.cpu().numpy(), gr.grad.numpy(), rtol=1e-4, atol=1e-8)
+    # without a penalty
+    loss2, _ = ops.CriticLoss.apply(hb.detach(), hs.detach(), None, wb.to(cuda), ws.to(cuda), 0.0)
+    np.testing.assert_allclose(float(loss2), float(torch.dot(vb.view(-1), wb.double()) + torch.dot(vs.view(-1), ws.double())),
+                               rtol=1e-5, atol=1e-6)
