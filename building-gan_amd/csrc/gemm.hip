@@ -940,8 +940,10 @@ int bg_colsum_f32(const float* x, int64_t ldx, int64_t M, int64_t N, float* part
     hipStream_t s = (hipStream_t)stream;
     const int rows_per_block = (int)((M + n_blocks - 1) / n_blocks);
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)n_blocks);
-    k_colsum_partial<<<grid, 256, 0, s>>>(x, ldx, M, N, rows_per_block > 0 ? rows_per_block : 1, partial);
+    // one row block: its "partial" row is the result (same value as the two-phase form would produce)
+    k_colsum_partial<<<grid, 256, 0, s>>>(x, ldx, M, N, rows_per_block > 0 ? rows_per_block : 1, n_blocks == 1 ? out : partial);
     BG_LAUNCH_CHECK();
+    if (n_blocks == 1) return BG_OK;
     k_colsum_final<<<bg_grid_for(N, 4), 256, 0, s>>>(partial, n_blocks, N, out);
     BG_LAUNCH_CHECK();
     return BG_OK;

@@ -29,6 +29,7 @@ NUMBER_OF_CLASS = 6  # /root/reference/Data/GraphConstructor.py:9
 COMPOSE_BLOCKS = True  # collapse messageMLP into updateMLP where legal (VoxelBlock.compose)
 COMPOSE_STACK = True   # run the discriminator's 12 composed layers as one autograd node (ops.AffineStack)
 FUSE_STORY_TERM = True  # generator block: story mean + its projections in one launch when no graph is built
+FUSE_PROGRAM_BLOCK = True   # ProgramBlock: one launch for both aggregations, residual in the epilogue (no-grad passes)
 FUSE_OUTPUT = True     # construct_output as one launch when no autograd graph is being built
 FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is being built
 COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
@@ -125,6 +126,15 @@ class ProgramBlock(nn.Module):
         self.messageMLP = MLP([2 * hidden_dim, hidden_dim])
         self.updateMLP = MLP([3 * hidden_dim, hidden_dim], act="leaky")
 
+    def forward_residual(self, feature, plan):
+        """feature + block(feature) when nothing is differentiated: both aggregations in one launch
+        (plan.prog_pair), the residual in the second product's epilogue."""
+        n = feature.shape[0]
+        both = ops.spmm_raw(plan.prog_pair, feature)                 # [2 Np, H]: in-edge mean | ratio x class-slot mean
+        aggr = run_mlp(self.messageMLP, [feature, both[:n]], row_scale=plan.prog_has)
+        lin, act = self.updateMLP[0], self.updateMLP[1]
+        return linear([feature, aggr, both[n:]], lin.weight, lin.bias, ACT_LEAKY, act.negative_slope, residual=feature)
+
     def forward(self, feature, plan, class_feature):
         gm = SpMM.apply(feature, plan.prog_mean)
         aggr = run_mlp(self.messageMLP, [feature, gm], row_scale=plan.prog_has)
@@ -142,8 +152,9 @@ class ProgramGNN(nn.Module):
 
     def forward(self, cf, slf, tr, z, plan):
         x = run_mlp(self.enc, torch.cat([cf, slf.view(-1, 1), z], dim=-1))
+        fused = FUSE_PROGRAM_BLOCK and not torch.is_grad_enabled() and "prog_pair" in plan.ops
         for _ in range(self.layer_num):
-            x = x + self.block(x, plan, tr)
+            x = self.block.forward_residual(x, plan) if fused else x + self.block(x, plan, tr)
         return x
 
 

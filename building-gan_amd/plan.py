@@ -42,9 +42,9 @@ class Csr:
 
     @property
     def row_per_workgroup(self) -> bool:
-        """Many segments of moderate length (stories, program nodes): one launch with a workgroup per
-        segment instead of the two-phase chunk reduction."""
-        return self.chunk_ptr is not None and self.n_rows >= 32 and 0 < self.max_len <= 4096
+        """Many segments of moderate length (stories, program nodes) or a few short ones (the stories of
+        a graph): one launch with a workgroup per segment instead of the two-phase chunk reduction."""
+        return self.chunk_ptr is not None and ((self.n_rows >= 32 and 0 < self.max_len <= 4096) or 0 < self.max_len <= 256)
 
 
 @dataclass
@@ -267,6 +267,7 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     def _min_len(c):
         return (c.rowptr[1:] - c.rowptr[:-1]).min() if c.n_rows > 0 else torch.ones((), dtype=torch.int32, device=dev)
     n_per_graph = (sgr.rowptr[1:] - sgr.rowptr[:-1]).to(torch.int64)            # stories of every graph
+    n_per_slot = (slot.rowptr[1:] - slot.rowptr[:-1]).to(torch.int64)           # program nodes of every class slot
     measured = b.chunked + [cv]                       # CSRs whose longest segment the networks want to know
     extra = torch.stack([lvl_max.to(torch.int32), _min_len(vfw), _min_len(pf), _min_len(cv), _min_len(st)] +
                         [(c.rowptr[1:] - c.rowptr[:-1]).max() if c.n_rows > 0 else lvl_max.new_zeros(()).to(torch.int32)
@@ -277,9 +278,10 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
                          (lambda at: (at[1:] - at[:-1]).max() if B > 0 else lvl_max.new_zeros(()).to(torch.int32))(
                              vfw.rowptr[gr.rowptr.long()]),
                          torch.maximum((vfw.rowptr[1:] - vfw.rowptr[:-1]).max(), (vrv.rowptr[1:] - vrv.rowptr[:-1]).max())
-                         if Nv > 0 else lvl_max.new_zeros(()).to(torch.int32)])
-    (flags, (max_level, min_vdeg, min_pdeg, min_cross, min_story, *max_lens, nnz_ss, n_leaving, blk_nnz, vox_max_deg)
-     ) = b.finish(extra)
+                         if Nv > 0 else lvl_max.new_zeros(()).to(torch.int32),
+                         (n_per_slot * n_per_slot).sum().to(torch.int32)])
+    (flags, (max_level, min_vdeg, min_pdeg, min_cross, min_story, *max_lens, nnz_ss, n_leaving, blk_nnz, vox_max_deg,
+             nnz_slot)) = b.finish(extra)
     # stories x stories: row s lists the stories of s's graph, scaled by 1 / their number -- the building
     # mean gathered back to the stories as ONE operator (its size is known only now, after the sync)
     nnz_ss = int(nnz_ss)
@@ -292,6 +294,21 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
         col_ss = sgr.col.to(torch.int64)[sgr.rowptr.to(torch.int64)[story_graph[row_of]] + within]
         ss = Csr(rp.to(torch.int32), col_ss.to(torch.int32), None, S, S, nnz_ss, count=deg.to(torch.float32))
         o["story_building_mean"] = LinOp(ss, ss.count, SCALE_DIV)
+    # program graph, both aggregations of a ProgramBlock as ONE operator with 2 Np rows: row i = mean over the
+    # in-edges of node i; row Np + i = target ratio of i's class slot x mean over the nodes of that slot
+    # (avg_pool_x(size=6) * ratio, gathered back: reference models.py:71-72).  Scales are multipliers.
+    nnz_slot = int(nnz_slot)
+    if Np > 0:
+        deg = n_per_slot[pcc]                                                     # [Np]
+        rp = torch.zeros(Np + 1, dtype=torch.int64, device=dev)
+        rp[1:] = torch.cumsum(deg, 0)
+        row_of = torch.repeat_interleave(ar_p, deg, output_size=nnz_slot)
+        within = torch.arange(nnz_slot, dtype=torch.int64, device=dev) - rp[row_of]
+        col_sl = slot.col.to(torch.int64)[slot.rowptr.to(torch.int64)[pcc[row_of]] + within]
+        rowptr2 = torch.cat([pf.rowptr.to(torch.int64), p.Ep + rp[1:]]).to(torch.int32)
+        col2 = torch.cat([pf.col, col_sl.to(torch.int32)])
+        scale2 = torch.cat([1.0 / pf.count, graph.program_target_ratio.to(torch.float32).view(-1)[pcc] / slot.count[pcc]])
+        o["prog_pair"] = LinOp(Csr(rowptr2, col2, None, 2 * Np, Np, p.Ep + nnz_slot), scale2.contiguous(), SCALE_MUL)
     for c, ml in zip(measured, max_lens):
         c.max_len = int(ml)
     edge_by_program.max_len = cp.max_len

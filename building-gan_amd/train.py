@@ -198,7 +198,8 @@ class Trainer:
         self.opt_d.zero_grad()
         if program_z is None:
             program_z = torch.rand(batch.program_class_feature.shape[0], self.noise_dim, device=dev)
-        if voxel_z is None:
+        if voxel_z is None and getattr(getattr(G, "voxelGNN", None), "noise_dim", 1) != 0:
+            # (the reference draws it every iteration, train.py:86, and its generator never reads it: models.py:239)
             voxel_z = torch.rand(batch.voxel_feature.shape[0], self.noise_dim, device=dev)
         fused_ok = do_d and hasattr(D, "critic_terms") and (self.gp_lambda == 0 or getattr(D, "piecewise_linear", False))
         share = D.shared_coefficients() if (do_d and hasattr(D, "shared_coefficients")) else contextlib.nullcontext()
