@@ -42,6 +42,7 @@ SIGNATURES = {
     "bg_seg_softmax_bwd_f32": [_p, _p, _p, _f, _p, _i64, _p],
     "bg_seg_argmax_f32": [_p, _p, _p, _i64, _p],
     "bg_story_project_f32": [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _i64, _p],
+    "bg_gather_story_f32": [_p, _i64, _p, _p, _p, _int, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _i64, _p],
     "bg_attention_fwd_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _f,
                              _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "bg_mask_gumbel_f32": [_p, _i64, _p, _p, _p, _i64, _p],

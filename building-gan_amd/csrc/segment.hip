@@ -29,12 +29,11 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nb) {
 
 // LPR lanes own one output row (one float4 each); a wave owns 64/LPR rows.
 template <int LPR, bool GENERAL>
-__global__ __launch_bounds__(256) void k_spmm_vec(SpmmArgs a) {
+__device__ __forceinline__ void spmm_vec_body(const SpmmArgs& a, int64_t blk) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int sub = lane % LPR;
-    const int64_t blk = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t row = (blk * 4 + wave) * RPW + lane / LPR;
     if (row >= a.n_rows || sub >= a.H4) return;
     const int32_t b = a.rowptr[row], e = a.rowptr[row + 1];
@@ -69,6 +68,11 @@ __global__ __launch_bounds__(256) void k_spmm_vec(SpmmArgs a) {
     if (a.add1) acc = bg_add4(acc, bg_ld4(a.add1 + row * a.ld1 + 4 * sub));
     if (a.add2) acc = bg_add4(acc, bg_ld4(a.add2 + row * a.ld2 + 4 * sub));
     bg_st4(a.out + row * a.ldo + 4 * sub, acc);
+}
+
+template <int LPR, bool GENERAL>
+__global__ __launch_bounds__(256) void k_spmm_vec(SpmmArgs a) {
+    spmm_vec_body<LPR, GENERAL>(a, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // scalar path: one thread per (row, channel)
@@ -380,14 +384,13 @@ __global__ void k_sddmm_scalar(const float* __restrict__ A, int64_t lda, const f
 // weight held as W[o, 0:H] (first H' outputs) and W[o, H:2H] (second H' outputs) of a row-major
 // [H', 2H] matrix -- i.e. out[s] = [ mean W[:, :H]^T | mean W[:, H:]^T ]: the story's own term and its
 // contribution to the building term, without the [S, H] mean ever going back to memory.
-__global__ __launch_bounds__(256) void k_story_project(const float* __restrict__ x, int64_t ldx,
-                                                       const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                       const float* __restrict__ count,
-                                                       const float* __restrict__ W, int64_t ldw, int Hout,
-                                                       float* __restrict__ out, int64_t ldo, int H) {
+__device__ __forceinline__ void story_project_body(const float* __restrict__ x, int64_t ldx,
+                                                   const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                   const float* __restrict__ count,
+                                                   const float* __restrict__ W, int64_t ldw, int Hout,
+                                                   float* __restrict__ out, int64_t ldo, int H, int64_t row) {
     __shared__ float4 part[256];
     __shared__ float mean[256];
-    const int64_t row = blockIdx.x;
     const int H4 = H / 4;                       // <= 64 lanes per slot row
     int lpr = 1;
     while (lpr < H4) lpr <<= 1;
@@ -425,6 +428,32 @@ __global__ __launch_bounds__(256) void k_story_project(const float* __restrict__
         }
         out[row * ldo + o] = d;
     }
+}
+
+__global__ __launch_bounds__(256) void k_story_project(const float* __restrict__ x, int64_t ldx,
+                                                       const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                       const float* __restrict__ count,
+                                                       const float* __restrict__ W, int64_t ldw, int Hout,
+                                                       float* __restrict__ out, int64_t ldo, int H) {
+    story_project_body(x, ldx, rowptr, col, count, W, ldw, Hout, out, ldo, H, blockIdx.x);
+}
+
+// Both reductions that a generator block takes of the SAME voxel features, in one launch (they are
+// independent: the story workgroups -- the long pole -- are dealt first, the gather-mean rows fill the chip
+// beside them).  n_story_blocks is padded to a multiple of 8 so the gather-mean's XCD-aware row order holds.
+struct StoryArgs {
+    const int32_t* rowptr; const int32_t* col; const float* count;
+    const float* W; int64_t ldw; int Hout; float* out; int64_t ldo; int n_story; int n_story_blocks;
+};
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_gather_story(SpmmArgs a, StoryArgs st, int H) {
+    if ((int)blockIdx.x < st.n_story_blocks) {
+        if ((int)blockIdx.x < st.n_story)
+            story_project_body(a.x, a.ldx, st.rowptr, st.col, st.count, st.W, st.ldw, st.Hout, st.out, st.ldo, H, blockIdx.x);
+        return;
+    }
+    spmm_vec_body<LPR, false>(a, xcd_remap(blockIdx.x - st.n_story_blocks, gridDim.x - st.n_story_blocks));
 }
 
 
@@ -826,6 +855,41 @@ int bg_story_project_f32(const float* x, int64_t ldx, const int32_t* rowptr, con
     if (!bg_aligned16(x) || !bg_aligned16(W) || ldx % 4 != 0 || ldw % 4 != 0) return BG_ERR_ALIGN;
     k_story_project<<<(unsigned)n_rows, 256, 0, (hipStream_t)stream>>>(x, ldx, rowptr, col, count, W, ldw, (int)Hout,
                                                                       out, ldo, (int)H);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_gather_story_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                        const float* row_scale, int row_mode, float* gm, int64_t ldg, int64_t n_rows,
+                        const int32_t* s_rowptr, const int32_t* s_col, const float* s_count,
+                        const float* W, int64_t ldw, int64_t Hout, float* pq, int64_t ldq, int64_t n_story,
+                        int64_t H, bgStream stream) {
+    if (n_rows < 0 || n_story < 0 || H <= 0 || Hout <= 0) return BG_ERR_ARG;
+    if (n_rows == 0 && n_story == 0) return BG_OK;
+    if (!x || !rowptr || !col || !gm || !s_rowptr || !s_count || !W || !pq) return BG_ERR_ARG;
+    if (ldx < H || ldg < H || ldw < 2 * H || ldq < 2 * Hout || (row_mode && !row_scale)) return BG_ERR_ARG;
+    if (H % 4 != 0 || H > 256 || n_story > (1 << 24)) return BG_ERR_SHAPE;
+    if (!bg_aligned16(x) || !bg_aligned16(gm) || !bg_aligned16(W) || ldx % 4 != 0 || ldg % 4 != 0 || ldw % 4 != 0)
+        return BG_ERR_ALIGN;
+    SpmmArgs a{x, ldx, rowptr, col, nullptr, nullptr, row_scale, row_mode, nullptr, 0, gm, ldg, n_rows, (int)(H / 4),
+               nullptr, 0, nullptr, 0};
+    int lpr = 1;
+    while (lpr < a.H4) lpr <<= 1;
+    const int rpb = 4 * (64 / lpr);
+    const int n_story_blocks = (int)((n_story + 7) / 8 * 8);
+    StoryArgs st{s_rowptr, s_col, s_count, W, ldw, (int)Hout, pq, ldq, (int)n_story, n_story_blocks};
+    const int64_t grid = (int64_t)n_story_blocks + (n_rows + rpb - 1) / rpb;
+    if (grid > 0x7fffffff) return BG_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    switch (lpr) {
+        case 1: k_gather_story<1><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
+        case 2: k_gather_story<2><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
+        case 4: k_gather_story<4><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
+        case 8: k_gather_story<8><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
+        case 16: k_gather_story<16><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
+        case 32: k_gather_story<32><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
+        default: k_gather_story<64><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
+    }
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

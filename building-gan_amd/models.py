@@ -266,18 +266,18 @@ class VoxelBlock(nn.Module):
     def forward_composed(self, voxel_feature, plan, pdm4, composed):
         """v + block(v) with the collapsed weights (valid when plan.vox_all_has)."""
         Wc, bc, Wsb = composed
-        gm = SpMM.apply(voxel_feature, plan.vox_mean)
-        if not self.if_agg_story_in_update:
-            return linear([voxel_feature, gm, pdm4], Wc, bc, residual=voxel_feature)
         H = voxel_feature.shape[1]
-        if (FUSE_STORY_TERM and not torch.is_grad_enabled() and "story_building_mean" in plan.ops
-                and H % 4 == 0 and H <= 256):
-            # graph-free pass: story mean and both of its projections in one launch, then
+        if (self.if_agg_story_in_update and FUSE_STORY_TERM and not torch.is_grad_enabled()
+                and "story_building_mean" in plan.ops and H % 4 == 0 and H <= 256):
+            # graph-free pass: the gather-mean, the story mean and both of its projections in one launch, then
             # term[s] = P[s] + mean over the stories of s's graph of Q  (P, Q = the two halves)
-            pq = ops.story_project_raw(plan.story_seg, voxel_feature, Wsb)
+            gm, pq = ops.gather_story_raw(plan.vox_mean, plan.story_seg, voxel_feature, Wsb)
             term = ops.spmm_add_raw(plan.story_building_mean, pq[:, H:], pq[:, :H])
             return linear([voxel_feature, gm, pdm4], Wc, bc, ACT_LEAKY, 0.01, pre_add=term,
                           pre_gather=plan.story_gather, residual=voxel_feature)
+        gm = SpMM.apply(voxel_feature, plan.vox_mean)
+        if not self.if_agg_story_in_update:
+            return linear([voxel_feature, gm, pdm4], Wc, bc, residual=voxel_feature)
         story = SpMM.apply(voxel_feature, plan.story_mean)                      # [S, H]
         building = SpMM.apply(SpMM.apply(story, plan.graph_of_story_mean), plan.story_graph_gather)   # [S, H]
         # (Wu3 - Wu4) story + Wu4 building, evaluated per STORY; the product's epilogue gathers it to the voxels

@@ -758,6 +758,25 @@ def story_project_raw(c: Csr, x: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gather_story_raw(op: LinOp, c: Csr, x: torch.Tensor, W: torch.Tensor):
+    """(op(x), story_project_raw(c, x, W)) in one launch; ``op`` must be an unweighted row-scaled operator with
+    explicit columns (the voxel gather-mean)."""
+    lib = _lib.load()
+    _lib.require_device(x, "gather_story")
+    x2, W2 = _f32c(x), _f32c(W)
+    H, Hout = x2.shape[1], W2.shape[0]
+    oc = op.csr
+    if (oc.col is None or op.col_mode != SCALE_NONE or x2.shape[0] != oc.n_cols or x2.shape[0] != c.n_cols
+            or W2.shape[1] != 2 * H or c.count is None):
+        raise _lib.BganError("gather_story: operator / segments / weight do not fit the operand")
+    gm = torch.empty(oc.n_rows, H, dtype=torch.float32, device=x.device)
+    pq = torch.empty(c.n_rows, 2 * Hout, dtype=torch.float32, device=x.device)
+    check(lib.bg_gather_story_f32(ptr(x2), _ld(x2), ptr(oc.rowptr), ptr(oc.col), ptr(op.row_scale), op.row_mode,
+                                  ptr(gm), H, oc.n_rows, ptr(c.rowptr), ptr(c.col), ptr(c.count), ptr(W2), _ld(W2), Hout,
+                                  ptr(pq), 2 * Hout, c.n_rows, H, stream()), "bg_gather_story_f32")
+    return gm, pq
+
+
 def attention_forward_raw(a, logits, b, x, v, theta, plan, exp_mask, exp_att, tau: float):
     """One Attention call without an autograd graph (see bg_attention_fwd_f32).
     Returns (soft0 [Nv,1], hard0 [Nv,1], soft [Ec], hard [Ec], new voxel features [Nv,H])."""

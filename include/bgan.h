@@ -134,6 +134,17 @@ int bg_story_project_f32(const float* x, int64_t ldx, const int32_t* rowptr, con
                          const float* count, const float* W, int64_t ldw, int64_t Hout,
                          float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream);
 
+/* bg_spmm_f32 (no edge weights, no column scale: gm = rs * P x over n_rows rows) and bg_story_project_f32
+ * (pq over n_story segments) of the SAME x in ONE launch -- a generator block needs both of its input and
+ * they are independent.  H % 4 == 0, H <= 256, 16-byte aligned operands.
+ * replaces: the propagate() gather + scatter-mean and the avg_pool_x over stories of one VoxelBlock call,
+ * Model/models.py:158,166, when nothing is differentiated.                                      */
+int bg_gather_story_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                        const float* row_scale, int row_mode, float* gm, int64_t ldg, int64_t n_rows,
+                        const int32_t* s_rowptr, const int32_t* s_col, const float* s_count,
+                        const float* W, int64_t ldw, int64_t Hout, float* pq, int64_t ldq, int64_t n_story,
+                        int64_t H, bgStream stream);
+
 /* Segment max with arg: out[s,h] = max_{k in seg s} x[c_k,h], arg[s,h] = c_k of the FIRST maximum
  * (slot order); an empty segment gives 0 and arg = -1.  Two phases as above;
  * partial_val / partial_arg: [n_chunks_ub, H]; chunk_ptr == NULL: one launch, a workgroup per row.

@@ -576,3 +576,16 @@ def test_critic_loss_node(cuda):
     loss2, _ = ops.CriticLoss.apply(hb.detach(), hs.detach(), None, wb.to(cuda), ws.to(cuda), 0.0)
     np.testing.assert_allclose(float(loss2), float(torch.dot(vb.view(-1), wb.double()) + torch.dot(vs.view(-1), ws.double())),
                                rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("preset,ragged,H", [("small", True, 128), ("dataset", False, 128), ("tiny", False, 64)])
+def test_gather_story_one_launch_equals_two(cuda, preset, ragged, H):
+    """bg_gather_story_f32 against bg_spmm_f32 + bg_story_project_f32 on the same operand: identical bits."""
+    from building_gan_amd import ops
+    g, p = _plan(_batch(preset, 7, ragged), cuda)
+    gen = torch.Generator().manual_seed(13)
+    x = (torch.rand(p.Nv, H, generator=gen) * 2 - 1).to(cuda)
+    W = (torch.rand(H, 2 * H, generator=gen) * 2 - 1).to(cuda)
+    gm, pq = ops.gather_story_raw(p.vox_mean, p.story_seg, x, W)
+    assert torch.equal(gm, ops.spmm_raw(p.vox_mean, x))
+    assert torch.equal(pq, ops.story_project_raw(p.story_seg, x, W))
