@@ -190,16 +190,35 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
                                                        float tau,
                                                        float* __restrict__ soft0, float* __restrict__ hard0,   // [Nv]
                                                        float* __restrict__ soft, float* __restrict__ hard,     // [Ec]
-                                                       float* __restrict__ out, int64_t ldo, int64_t n_vox) {
+                                                       float* __restrict__ out, int64_t ldo, int64_t n_vox,
+                                                       const float* __restrict__ Wd, int64_t ldwd,      // optional [2, H]: logits = V Wd^T + bd
+                                                       const float* __restrict__ bd) {
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
-    float th[CPL];
+    float th[CPL], wd0[CPL], wd1[CPL];
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) th[j] = theta[lane + 64 * j];
+    for (int j = 0; j < CPL; ++j) {
+        th[j] = theta[lane + 64 * j];
+        wd0[j] = Wd ? Wd[lane + 64 * j] : 0.f;
+        wd1[j] = Wd ? Wd[ldwd + lane + 64 * j] : 0.f;
+    }
     for (int64_t v = wave_id; v < n_vox; v += n_waves) {
+        float vv[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) vv[j] = V[v * ldv + lane + 64 * j];
+        // ---- mask logits: given, or the composed two-row decoder applied to the voxel's features here
+        float l0, l1;
+        if (Wd) {
+            float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) { d0 = fmaf(vv[j], wd0[j], d0); d1 = fmaf(vv[j], wd1[j], d1); }
+            l0 = bg_wave_sum(d0) + bd[0]; l1 = bg_wave_sum(d1) + bd[1];
+        } else {
+            l0 = logits[v * ldl]; l1 = logits[v * ldl + 1];
+        }
         // ---- two-way mask (k_mask_gumbel)
-        const float z0 = logits[v * ldl] - logf(exp_mask[2 * v]), z1 = logits[v * ldl + 1] - logf(exp_mask[2 * v + 1]);
+        const float z0 = l0 - logf(exp_mask[2 * v]), z1 = l1 - logf(exp_mask[2 * v + 1]);
         const float zm = fmaxf(z0, z1);
         const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
         const float esum = e0 + e1;
@@ -249,7 +268,7 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
             for (int j = 0; j < CPL; ++j) g[j] += w * xp[lane + 64 * j];
         }
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) out[v * ldo + lane + 64 * j] = V[v * ldv + lane + 64 * j] + s0 * g[j];
+        for (int j = 0; j < CPL; ++j) out[v * ldo + lane + 64 * j] = vv[j] + s0 * g[j];
     }
 }
 
@@ -353,19 +372,22 @@ int bg_attention_fwd_f32(const float* a, int64_t lda, const float* logits, int64
                          const int32_t* rowptr, const int32_t* col,
                          const float* exp_mask, const float* exp_att, float tau,
                          float* soft0, float* hard0, float* soft, float* hard,
-                         float* out, int64_t ldo, int64_t n_vox, int64_t H, bgStream stream) {
+                         float* out, int64_t ldo, int64_t n_vox, int64_t H,
+                         const float* wd, int64_t ldwd, const float* bd, bgStream stream) {
     if (n_vox < 0 || H <= 0 || tau == 0.f) return BG_ERR_ARG;
     if (n_vox == 0) return BG_OK;
-    if (!a || !logits || !b || !x || !v || !theta || !rowptr || !col || !exp_mask || !exp_att || !soft0 || !hard0 ||
-        !soft || !hard || !out || lda < H || ldb < H || ldx < H || ldv < H || ldo < H || ldl < 2)
+    if (!a || !b || !x || !v || !theta || !rowptr || !col || !exp_mask || !exp_att || !soft0 || !hard0 ||
+        !soft || !hard || !out || lda < H || ldb < H || ldx < H || ldv < H || ldo < H)
         return BG_ERR_ARG;
+    if (wd ? (!bd || ldwd < H) : (!logits || ldl < 2)) return BG_ERR_ARG;   // logits given, or the decoder to apply
     if (H % 64 != 0 || H > 64 * kMaxCPL) return BG_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     int grid = bg_grid_for(n_vox, 4, 256 * 16);
 #define BG_ATT_CASE(C)                                                                                          \
     case C:                                                                                                     \
         k_attention_fwd<C><<<grid, 256, 0, s>>>(a, lda, logits, ldl, b, ldb, x, ldx, v, ldv, theta, rowptr, col, \
-                                                exp_mask, exp_att, tau, soft0, hard0, soft, hard, out, ldo, n_vox); \
+                                                exp_mask, exp_att, tau, soft0, hard0, soft, hard, out, ldo, n_vox, \
+                                                wd, ldwd, bd);                                                  \
         break;
     switch ((int)(H / 64)) {
         BG_ATT_CASE(1) BG_ATT_CASE(2) BG_ATT_CASE(3) BG_ATT_CASE(4)

@@ -155,6 +155,47 @@ __global__ void k_critic_loss_bwd(const float* __restrict__ go, const float* __r
     }
 }
 
+// Mean position difference of every voxel to its in-neighbours, zero-padded to 4 columns:
+//   out[v, 0:3] = has(v) * pos[v] - (sum_{j -> v} pos[j]) / max(deg(v), 1) ,  out[v, 3] = 0
+// (the mean over in-edges of pos_i - pos_j, reference Model/models.py:160-161, constant per batch);
+// slot order, IEEE division, products and differences rounded separately.
+__global__ void k_pos_terms(const float* __restrict__ pos, int64_t ldp, const int32_t* __restrict__ rowptr,
+                            const int32_t* __restrict__ col, float* __restrict__ out, int64_t n) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const int32_t kb = rowptr[v], ke = rowptr[v + 1];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int32_t k = kb; k < ke; ++k) {
+        const float* pj = pos + (int64_t)col[k] * ldp;
+        sx = __fadd_rn(sx, pj[0]); sy = __fadd_rn(sy, pj[1]); sz = __fadd_rn(sz, pj[2]);
+    }
+    const float cnt = (float)(ke - kb > 1 ? ke - kb : 1);
+    const float has = ke > kb ? 1.f : 0.f;
+    const float* pv = pos + v * ldp;
+    float4 o;
+    o.x = __fsub_rn(__fmul_rn(has, pv[0]), __fdiv_rn(sx, cnt));
+    o.y = __fsub_rn(__fmul_rn(has, pv[1]), __fdiv_rn(sy, cnt));
+    o.z = __fsub_rn(__fmul_rn(has, pv[2]), __fdiv_rn(sz, cnt));
+    o.w = 0.f;
+    *reinterpret_cast<float4*>(out + v * 4) = o;
+}
+
+// Label-free input columns of the collapsed discriminator (models.VoxelGNN_D._static_powers), one row per voxel:
+//   [ feat (nf) | onehot(level) (ML) | pdm4 (4) | 1 | 0 .. ]   (ds columns)
+__global__ void k_d_static_cols(const float* __restrict__ feat, int64_t ldf, int nf, const int32_t* __restrict__ level,
+                                int ML, const float* __restrict__ pdm4, float* __restrict__ out, int64_t ldo, int ds,
+                                int64_t n) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * ds) return;
+    const int64_t v = t / ds; const int c = (int)(t % ds);
+    float val = 0.f;
+    if (c < nf) val = feat[v * ldf + c];
+    else if (c < nf + ML) val = (level[v] == c - nf) ? 1.f : 0.f;
+    else if (c < nf + ML + 4) val = pdm4[v * 4 + (c - nf - ML)];
+    else if (c == nf + ML + 4) val = 1.f;
+    out[v * ldo + c] = val;
+}
+
 }  // namespace
 
 extern "C" {
@@ -223,6 +264,28 @@ int bg_critic_loss_bwd_f32(const float* go, const float* wb, int64_t nb, const f
     if (work == 0) return BG_OK;
     k_critic_loss_bwd<<<bg_grid_for(work, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(go, wb, nb, ws, ns, grads, ldg, n_rows, (int)W,
                                                                                           coef, d_val_b, d_val_s, d_grads);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_pos_terms_f32(const float* pos, int64_t ldp, const int32_t* rowptr, const int32_t* col, float* out, int64_t n,
+                     bgStream stream) {
+    if (n < 0) return BG_ERR_ARG;
+    if (n == 0) return BG_OK;
+    if (!pos || !rowptr || !col || !out || ldp < 3) return BG_ERR_ARG;
+    if (!bg_aligned16(out)) return BG_ERR_ALIGN;
+    k_pos_terms<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(pos, ldp, rowptr, col, out, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_d_static_cols_f32(const float* feat, int64_t ldf, int64_t nf, const int32_t* level, int64_t ML, const float* pdm4,
+                         float* out, int64_t ldo, int64_t ds, int64_t n, bgStream stream) {
+    if (n < 0 || nf < 0 || ML < 0 || ds < nf + ML + 5 || ldo < ds) return BG_ERR_ARG;
+    if (n == 0) return BG_OK;
+    if (!feat || !level || !pdm4 || !out || ldf < nf) return BG_ERR_ARG;
+    k_d_static_cols<<<bg_grid_for(n * ds, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(feat, ldf, (int)nf, level, (int)ML, pdm4,
+                                                                                         out, ldo, (int)ds, n);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -93,8 +93,7 @@ def _pos_terms(plan, pos):
     """Per-node mean of (pos_i - pos_j) over in-edges, zero-padded to 4 columns (cached per plan)."""
     cached = plan.ops.get("pdm4")
     if cached is None:
-        pos4 = F.pad(pos.detach().float(), (0, 1)).contiguous()
-        cached = plan.vox_has * pos4 - ops.spmm_raw(plan.vox_mean, pos4)
+        cached = ops.pos_terms_raw(plan.vox_mean, pos.detach())       # one launch, straight off the feature columns
         plan.ops["pdm4"] = cached
     return cached
 
@@ -168,7 +167,7 @@ class Attention(nn.Module):
         a = math.sqrt(6.0 / (1 + hidden_dim))          # torch_geometric inits.glorot
         nn.init.uniform_(self.theta, -a, a)
 
-    def shared_terms(self, program_graph_feature):
+    def shared_terms(self, program_graph_feature, stacked=None):
         """What the calls of one generator forward have in common (the module and the program features are
         the same in all of them, reference models.py:194,201):
           * NN_p(program features), evaluated once instead of once per call;
@@ -176,20 +175,40 @@ class Attention(nn.Module):
             (models.py:98), so its two Linears are the [2, H] map W2 W1 with bias W2 b1 + b2, stacked under
             NN_v's [H, H] (rows padded to a multiple of 4).  A call then runs one GEMM instead of three."""
         b = linear(program_graph_feature, self.NN_p.weight, self.NN_p.bias)
+        Wcat, bcat = stacked if stacked is not None else self.stacked_weights()
+        return b, Wcat, bcat
+
+    def stacked_weights(self):
+        """(Wcat [H + 4, H], bcat): NN_v with the composed mask decoder stacked under it -- a function of the
+        parameters alone (None, None when the decoder is not two plain Linears)."""
         mods = [m for m in self.dec if isinstance(m, nn.Linear)]
         if len(mods) != len(self.dec) or len(mods) != 2:
-            return b, None, None
+            return None, None
         W1, b1, W2, b2 = mods[0].weight, mods[0].bias, mods[1].weight, mods[1].bias
         Wd = ops.MatMul.apply(W2, W1, False, False)                                    # [2, H]
         bd = torch.addmv(b2, W2, b1)
-        H = self.NN_v.weight.shape[0]
         Wcat = torch.cat([self.NN_v.weight, Wd, ops.zeros_view(2, W1.shape[1], device=Wd.device)], dim=0)  # [H + 4, H]
         bcat = torch.cat([self.NN_v.bias, bd, ops.zeros_view(2, device=bd.device)])
-        return b, Wcat, bcat
+        return Wcat, bcat
 
     def forward(self, program_graph_feature, voxel_feature, plan, noise=None, shared=None):
         exp_mask, exp_att = (None, None) if noise is None else noise
         b, Wcat, bcat = shared if shared is not None else self.shared_terms(program_graph_feature)
+        H = self.NN_v.weight.shape[0]
+        if (Wcat is not None and FUSE_ATTENTION and not torch.is_grad_enabled() and 0 < plan.cross_v.max_len <= 64
+                and H % 64 == 0):
+            # nothing will be differentiated: NN_v as one [Nv,H] x [H,H] product (no ragged 4-column tile), then
+            # ONE launch for the rest of the call, the two-row composed mask decoder included
+            a = linear(voxel_feature, Wcat[:H], bcat[:H])
+            if exp_mask is None:
+                exp_mask = torch.empty(voxel_feature.shape[0], 2, dtype=a.dtype, device=a.device).exponential_()
+            if exp_att is None:
+                exp_att = torch.empty(plan.Ec, dtype=a.dtype, device=a.device).exponential_()
+            soft0, hard0, soft_att, hard_att, new_voxel_feature = ops.attention_forward_raw(
+                a, None, b, program_graph_feature, voxel_feature, self.theta, plan, exp_mask, exp_att, -1.0,
+                wd=Wcat[H:H + 2], bd=bcat[H:H + 2])
+            return ({"hard": hard0, "soft": soft0}, {"hard": hard_att.view(-1, 1), "soft": soft_att.view(-1, 1)},
+                    new_voxel_feature)
         if Wcat is not None:
             H = self.NN_v.weight.shape[0]
             a, logits, _ = linear(voxel_feature, Wcat, bcat).split([H, 2, 2], dim=1)
@@ -308,7 +327,15 @@ class VoxelGNN_G(nn.Module):
         self.block = VoxelBlock(hidden_dim, if_agg_story_in_update=True)
         self.attention = Attention(hidden_dim)
 
-    def forward(self, x, v, z, plan, noise: Optional[Sequence] = None):
+    def derived_weights(self):
+        """What every forward derives from the parameters alone: the composed block weights (Wc, bc, Wsb) and
+        the attention's stacked weight (Wcat, bcat).  A caller that knows the parameters have not changed
+        (train.Trainer between two generator updates) may keep them and pass them back as ``derived``."""
+        Wc, bc, Wsb = self.block.compose()
+        Wcat, bcat = self.attention.stacked_weights()
+        return [Wc, bc, Wsb, Wcat, bcat]
+
+    def forward(self, x, v, z, plan, noise: Optional[Sequence] = None, derived=None):
         n_calls = 1 + sum(1 for i in range(self.layer_num) if i % 2 == 0 and i != 0)
         if noise is None:
             # all Exp(1) draws of this forward (mask [Nv, 2] + attention [Ec] per call) in ONE launch
@@ -319,12 +346,16 @@ class VoxelGNN_G(nn.Module):
         draws = iter(noise)
         pos, v = extract_pos(v)
         pdm4 = _pos_terms(plan, pos)
-        v = run_mlp(self.enc, torch.cat((v, z), dim=-1) if self.noise_dim != 0 else v)
-        v = v + ops.spmm_raw(_level_op(plan, self.pe.shape[0]), self.pe)
-        shared = self.attention.shared_terms(x)
+        enc = self.enc[0]                       # pe[level] rides in the encoder product's epilogue (gathered addend)
+        v = linear(torch.cat((v, z), dim=-1) if self.noise_dim != 0 else v, enc.weight, enc.bias,
+                   pre_add=self.pe, pre_gather=_level_op(plan, self.pe.shape[0]))
+        use = derived is not None and derived[3] is not None
+        shared = self.attention.shared_terms(x, (derived[3], derived[4]) if use else None)
         _, _, v = self.attention(x, v, plan, next(draws), shared)
         out_mask = out_att = None
-        composed = self.block.compose() if (COMPOSE_BLOCKS and plan.vox_all_has) else None
+        composed = None
+        if COMPOSE_BLOCKS and plan.vox_all_has:
+            composed = tuple(derived[:3]) if derived is not None else self.block.compose()
         for i in range(self.layer_num):
             if composed is not None:
                 v = self.block.forward_composed(v, plan, pdm4, composed)
@@ -363,12 +394,12 @@ class VoxelGNN_D(nn.Module):
         Z = plan.ops.get(key)
         if Z is None:
             ML = self.pe.shape[0]
-            onehot = ops.spmm_raw(_level_op(plan, ML), torch.eye(ML, device=feat.device))
-            cols = [feat.detach().float(), onehot, pdm4, torch.ones(feat.shape[0], 1, device=feat.device)]
-            width = sum(c.shape[1] for c in cols)
+            _level_op(plan, ML)                                       # raises when a building has more stories than pe rows
+            width = feat.shape[1] + ML + 4 + 1
             ds = (width + 3) // 4 * 4
-            Z = torch.zeros(feat.shape[0], (self.layer_num + 1) * ds, device=feat.device)
-            Z[:, :width] = torch.cat(cols, dim=1)
+            # column group 0 in one launch; the chain of operator powers writes groups 1..L
+            Z = torch.empty(feat.shape[0], (self.layer_num + 1) * ds, device=feat.device)
+            ops.d_static_cols_raw(feat.detach(), plan.level, ML, pdm4, Z, ds)
             ops.power_chain_raw(plan.vox_mean, Z, self.layer_num, ds, plan.vox_blocks)
             plan.ops[key] = Z
         return Z
@@ -463,11 +494,11 @@ class Generator(nn.Module):
         self.programGNN = ProgramGNN(program_input_dim, hidden_dim, noise_dim, program_layer)
         self.voxelGNN = VoxelGNN_G(voxel_input_dim, hidden_dim, 0, voxel_layer, max_len)
 
-    def forward(self, graph, program_z, voxel_z, noise: Optional[Sequence] = None):
+    def forward(self, graph, program_z, voxel_z, noise: Optional[Sequence] = None, derived=None):
         plan = build_plan(graph)
         x = self.programGNN(graph.program_class_feature, graph.story_level_feature, graph.program_target_ratio,
                             program_z, plan)
-        mask, att, _ = self.voxelGNN(x, graph.voxel_feature, voxel_z, plan, noise)
+        mask, att, _ = self.voxelGNN(x, graph.voxel_feature, voxel_z, plan, noise, derived)
         out, soft_out, idx = Attention.construct_output(graph.program_class_feature, graph.voxel_feature.shape[0],
                                                         att, mask, plan, graph.cross_edge_program_index_select)
         return out, soft_out, mask, att, idx

@@ -777,13 +777,17 @@ def gather_story_raw(op: LinOp, c: Csr, x: torch.Tensor, W: torch.Tensor):
     return gm, pq
 
 
-def attention_forward_raw(a, logits, b, x, v, theta, plan, exp_mask, exp_att, tau: float):
-    """One Attention call without an autograd graph (see bg_attention_fwd_f32).
+def attention_forward_raw(a, logits, b, x, v, theta, plan, exp_mask, exp_att, tau: float, wd=None, bd=None):
+    """One Attention call without an autograd graph (see bg_attention_fwd_f32).  ``logits`` [Nv,2], or None with
+    the composed decoder (wd [2,H], bd [2]) to apply in the kernel.
     Returns (soft0 [Nv,1], hard0 [Nv,1], soft [Ec], hard [Ec], new voxel features [Nv,H])."""
     lib = _lib.load()
     _lib.require_device(v, "attention_forward")
     cv = plan.cross_v
-    a2, l2, b2, x2, v2 = _f32c(a), _f32c(logits), _f32c(b), _f32c(x), _f32c(v)
+    a2, b2, x2, v2 = _f32c(a), _f32c(b), _f32c(x), _f32c(v)
+    l2 = _f32c(logits) if logits is not None else None
+    wd2 = _f32c(wd) if wd is not None else None
+    bd2 = _f32c(bd).contiguous() if bd is not None else None
     th, em, ea = _f32c(theta.reshape(-1)), _f32c(exp_mask).contiguous(), _f32c(exp_att.reshape(-1))
     n, H = v2.shape
     dev = v.device
@@ -792,9 +796,11 @@ def attention_forward_raw(a, logits, b, x, v, theta, plan, exp_mask, exp_att, ta
     soft = torch.empty(cv.nnz, dtype=torch.float32, device=dev)
     hard = torch.empty(cv.nnz, dtype=torch.float32, device=dev)
     out = torch.empty(n, H, dtype=torch.float32, device=dev)
-    check(lib.bg_attention_fwd_f32(ptr(a2), _ld(a2), ptr(l2), _ld(l2), ptr(b2), _ld(b2), ptr(x2), _ld(x2), ptr(v2), _ld(v2),
+    check(lib.bg_attention_fwd_f32(ptr(a2), _ld(a2), ptr(l2), _ld(l2) if l2 is not None else 0, ptr(b2), _ld(b2),
+                                   ptr(x2), _ld(x2), ptr(v2), _ld(v2),
                                    ptr(th), ptr(cv.rowptr), ptr(cv.col), ptr(em), ptr(ea), tau, ptr(soft0), ptr(hard0),
-                                   ptr(soft), ptr(hard), ptr(out), _ld(out), n, H, stream()), "bg_attention_fwd_f32")
+                                   ptr(soft), ptr(hard), ptr(out), _ld(out), n, H,
+                                   ptr(wd2), _ld(wd2) if wd2 is not None else 0, ptr(bd2), stream()), "bg_attention_fwd_f32")
     return soft0, hard0, soft, hard, out
 
 
@@ -851,6 +857,28 @@ def construct_output_raw(mask_hard, att_hard, att_soft, plan, cls):
     check(lib.bg_construct_output_f32(ptr(mh), ptr(ah), ptr(asf), ptr(cv.rowptr), ptr(cv.col), ptr(c2), _ld(c2), Cn,
                                       ptr(out), ptr(soft), ptr(idx), n, stream()), "bg_construct_output_f32")
     return out, soft, idx
+
+
+def pos_terms_raw(op: LinOp, pos: torch.Tensor) -> torch.Tensor:
+    """[N, 4]: has * pos - mean over in-neighbours of pos, zero 4th column (``pos`` may be a column slice)."""
+    lib = _lib.load()
+    _lib.require_device(pos, "pos_terms")
+    c = op.csr
+    p2 = pos if (pos.dtype == torch.float32 and pos.stride(-1) == 1) else pos.float().contiguous()
+    if p2.shape[1] != 3 or p2.shape[0] != c.n_rows or c.n_rows != c.n_cols or c.col is None:
+        raise _lib.BganError("pos_terms: pos must be [N, 3] over a square CSR with explicit columns")
+    out = torch.empty(c.n_rows, 4, dtype=torch.float32, device=pos.device)
+    check(lib.bg_pos_terms_f32(ptr(p2), p2.stride(0), ptr(c.rowptr), ptr(c.col), ptr(out), c.n_rows, stream()),
+          "bg_pos_terms_f32")
+    return out
+
+
+def d_static_cols_raw(feat, level, ML: int, pdm4, out, ds: int) -> None:
+    lib = _lib.load()
+    f2, p4 = _f32c(feat), _f32c(pdm4).contiguous()
+    n, nf = f2.shape
+    check(lib.bg_d_static_cols_f32(ptr(f2), _ld(f2), nf, ptr(level), ML, ptr(p4), ptr(out), out.stride(0), ds, n, stream()),
+          "bg_d_static_cols_f32")
 
 
 class CriticLoss(torch.autograd.Function):

@@ -120,12 +120,39 @@ class Trainer:
         self.group = group
         self._graphs = None
         self._cw_cache = None
+        # composed generator weights (functions of the parameters alone) kept between generator updates for the
+        # graph-free forwards of critic-only iterations; refreshed IN PLACE (captured graphs hold the buffers)
+        # after every change of the generator's parameters that goes through this class or load_state_dict
+        self._g_derived = None
+        if hasattr(self.generator, "register_load_state_dict_post_hook"):
+            self.generator.register_load_state_dict_post_hook(lambda _m, _k: self.refresh_derived())
         self._overlap_stream = None    # set while capture() records the iteration
 
     def broadcast_parameters(self, src: int = 0):
         if _world(self.group) > 1:
             dist.broadcast(self.opt_g.flat, src, group=self.group)
             dist.broadcast(self.opt_d.flat, src, group=self.group)
+            self.refresh_derived()
+
+    def _derived(self):
+        """The generator's parameter-only tensors for a graph-free forward (built on first use)."""
+        gnn = getattr(self.generator, "voxelGNN", None)
+        if not hasattr(gnn, "derived_weights"):
+            return None
+        if self._g_derived is None:
+            with torch.no_grad():
+                self._g_derived = [None if t is None else t.clone() for t in gnn.derived_weights()]
+        return self._g_derived
+
+    def refresh_derived(self):
+        """Recompute the kept tensors after the generator's parameters changed (optimizer step, broadcast,
+        load_state_dict, restore).  Call it after changing the parameters in any other way."""
+        if self._g_derived is None:
+            return
+        with torch.no_grad():
+            for buf, t in zip(self._g_derived, self.generator.voxelGNN.derived_weights()):
+                if buf is not None:
+                    buf.copy_(t)
 
     # ------------------------------------------------------------------ objectives
     # reference losses.py:14-35 / 52-61 with every mean written as (local sum) / (global count), so that the
@@ -214,8 +241,13 @@ class Trainer:
                 with torch.cuda.stream(side):
                     D.prepare(batch)
             # the generator's autograd graph is only needed when its own update follows (train.py:106-113)
-            with contextlib.nullcontext() if g_update else torch.no_grad():
+            if g_update:
                 gen = G(batch, program_z, voxel_z, noise)
+            else:
+                with torch.no_grad():
+                    derived = self._derived()
+                    gen = G(batch, program_z, voxel_z, noise, derived) if derived is not None else \
+                        G(batch, program_z, voxel_z, noise)
             if side is not None:
                 cur.wait_stream(side)
             out, soft_out = gen[0], gen[1]
@@ -285,6 +317,7 @@ class Trainer:
             stats.update(self._phase_g(batch, counts, gen))
             self.opt_g.all_reduce(self.group)
             self.opt_g.step()
+            self.refresh_derived()
         else:
             for p in self.opt_d.params:
                 p.requires_grad = False
@@ -328,7 +361,12 @@ class Trainer:
             self.opt_d.step()
             return self._phase_g(batch, counts, gen)
         gB, statsB = cap(seg_b)
-        gC, _ = cap(lambda: self.opt_g.step())
+        self._derived()                       # the buffers must exist before the graphs that read / refresh them
+
+        def seg_c():
+            self.opt_g.step()
+            self.refresh_derived()
+        gC, _ = cap(seg_c)
         graphs["with_g"] = (gA, gB, gC, {**statsA, **statsB})
         # iteration WITHOUT generator update
         gA2, (gen2, statsA2) = cap(lambda: self._phase_d(batch, counts, True, g_update=False))
@@ -339,6 +377,7 @@ class Trainer:
         self._overlap_stream = None    # eager iterations stay on one stream
         self.opt_g.restore(saved[0])
         self.opt_d.restore(saved[1])
+        self.refresh_derived()
         torch.cuda.synchronize()
 
     def train_iteration_graphed(self, i: int):

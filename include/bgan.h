@@ -218,7 +218,9 @@ int bg_mask_gumbel_bwd_f32(const float* soft0, const float* g_soft, const float*
 /* One whole Attention call, forward only (no autograd graph: inference, critic-only iterations): the
  * two-way mask, the tanh cross logits, the segment Gumbel-softmax pointer, the soft-weighted gather of
  * program features and  out = v + soft_mask * gathered  in one launch (one wave per voxel; every voxel
- * must have between 1 and 64 cross edges).  a = NN_v(v), b = NN_p(x) as for bg_cross_logits_f32.
+ * must have between 1 and 64 cross edges).  a = NN_v(v), b = NN_p(x) as for bg_cross_logits_f32.  The mask
+ * logits are either given (logits [n,2], wd == NULL) or computed here as v wd^T + bd from the composed
+ * two-row decoder wd [2,H] (pitch ldwd), bd [2] (logits may then be NULL).
  * replaces: Model/models.py:109-126 (Attention.forward) when nothing is differentiated.      */
 int bg_attention_fwd_f32(const float* a, int64_t lda, const float* logits, int64_t ldl,
                          const float* b, int64_t ldb, const float* x, int64_t ldx,
@@ -226,7 +228,8 @@ int bg_attention_fwd_f32(const float* a, int64_t lda, const float* logits, int64
                          const int32_t* rowptr, const int32_t* col,
                          const float* exp_mask, const float* exp_att, float tau,
                          float* soft0, float* hard0, float* soft, float* hard,
-                         float* out, int64_t ldo, int64_t n_vox, int64_t H, bgStream stream);
+                         float* out, int64_t ldo, int64_t n_vox, int64_t H,
+                         const float* wd, int64_t ldwd, const float* bd, bgStream stream);
 
 /* ------------------------------------------------------------------ critic update ------ */
 
@@ -252,6 +255,20 @@ int bg_pack_columns_f32(const float* const* src, const int64_t* ld, int n_src, i
 int bg_construct_output_f32(const float* mask_hard, const float* att_hard, const float* att_soft,
                             const int32_t* rowptr, const int32_t* col, const float* cls, int64_t ldc, int64_t C,
                             float* out, float* soft_out, int64_t* idx, int64_t n_vox, bgStream stream);
+
+/* out[v, 0:3] = has(v) * pos[v] - mean over v's in-neighbours j of pos[j], out[v, 3] = 0 (out [n, 4]
+ * contiguous; pos[v] = 3 floats at pos + v*ldp; CSR by target): the per-voxel mean of pos_i - pos_j.
+ * replaces: the pos_i - pos_j columns of the message and their scatter-mean, Model/models.py:158-161
+ * (constant over the layers of a pass: evaluated once).                                          */
+int bg_pos_terms_f32(const float* pos, int64_t ldp, const int32_t* rowptr, const int32_t* col, float* out, int64_t n,
+                     bgStream stream);
+
+/* out[v, 0:ds] = [ feat[v, 0:nf] | onehot(level[v]) (ML) | pdm4[v, 0:4] | 1 | 0 .. ]: the label-free input
+ * columns of the discriminator's collapsed voxel GNN (ds >= nf + ML + 5).
+ * replaces: the inputs of feature_enc and pe[level], Model/models.py:221-222, as columns the operator
+ * powers act on.                                                                                 */
+int bg_d_static_cols_f32(const float* feat, int64_t ldf, int64_t nf, const int32_t* level, int64_t ML, const float* pdm4,
+                         float* out, int64_t ldo, int64_t ds, int64_t n, bgStream stream);
 
 /* WGAN-GP critic objective in two launches:
  *   loss[0] = <val_b, wb> + <val_s, ws> + coef * sum_r (||grads[r, 0:W]|| - 1)^2 ,  r < n_rows

@@ -589,3 +589,28 @@ def test_gather_story_one_launch_equals_two(cuda, preset, ragged, H):
     gm, pq = ops.gather_story_raw(p.vox_mean, p.story_seg, x, W)
     assert torch.equal(gm, ops.spmm_raw(p.vox_mean, x))
     assert torch.equal(pq, ops.story_project_raw(p.story_seg, x, W))
+
+
+def test_pos_terms_and_static_columns(cuda):
+    """bg_pos_terms_f32 against the scatter-mean statement (has * pos - mean_j pos_j: bit-exact, including an
+    isolated voxel) and bg_d_static_cols_f32 against the concatenation it replaces."""
+    from building_gan_amd import ops
+    from oracle.scatter import scatter_mean
+    cpu = _batch("small", 8, True)
+    cpu.voxel_edge = cpu.voxel_edge[:, cpu.voxel_edge[1] != 3]          # voxel 3 loses its in-edges
+    import copy
+    g, p = _plan(copy.deepcopy(cpu), cuda)
+    pos = cpu.voxel_feature[:, 3:6]
+    ve = cpu.voxel_edge
+    has = torch.zeros(p.Nv, 1).index_fill_(0, ve[1], 1.0)
+    ref = has * pos - scatter_mean(pos[ve[0]], ve[1], p.Nv)
+    got = ops.pos_terms_raw(p.vox_mean, g.voxel_feature[:, 3:6])
+    assert torch.equal(got[:, :3].cpu(), ref) and bool((got[:, 3] == 0).all())
+    assert float(got[3].abs().max()) == 0.0
+    feat = torch.cat([cpu.voxel_feature[:, 0:3], cpu.voxel_feature[:, 6:]], dim=1)
+    ML, ds = 20, 32
+    Z = torch.full((p.Nv, 3 * ds), -7.0, device=cuda)
+    ops.d_static_cols_raw(feat.to(cuda), p.level, ML, got, Z, ds)
+    onehot = torch.nn.functional.one_hot(p.level.cpu().long(), ML).float()
+    expect = torch.cat([feat, onehot, got.cpu(), torch.ones(p.Nv, 1), torch.zeros(p.Nv, ds - 4 - ML - 5)], dim=1)
+    assert torch.equal(Z[:, :ds].cpu(), expect) and bool((Z[:, ds:] == -7.0).all())

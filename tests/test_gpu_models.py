@@ -183,9 +183,25 @@ def test_graph_capture_replays_and_restores_state(cuda):
     assert int(tr.opt_d.t.item()) == 6 and int(tr.opt_g.t.item()) == 2
     assert torch.isfinite(stats["d_loss"]).all() and torch.isfinite(tr.opt_d.flat).all()
     assert not torch.equal(tr.opt_g.flat, before_g) and not torch.equal(tr.opt_d.flat, before_d)
+    # the composed generator weights kept for critic-only iterations follow every generator update
+    with torch.no_grad():
+        fresh = tr.generator.voxelGNN.derived_weights()
+    assert tr._g_derived is not None
+    for kept, now in zip(tr._g_derived, fresh):
+        assert torch.equal(kept, now)
     # an eager iteration on the same trainer still works after replays
     s2 = tr.train_iteration(batch, 7)
     assert torch.isfinite(s2["d_loss"]).all()
+    tr.train_iteration(batch, 10)                                   # eager generator update: refreshed in place
+    with torch.no_grad():
+        fresh = tr.generator.voxelGNN.derived_weights()
+    for kept, now in zip(tr._g_derived, fresh):
+        assert torch.equal(kept, now)
+    tr.generator.load_state_dict({k: v * 0.5 for k, v in tr.generator.state_dict().items()})
+    with torch.no_grad():
+        fresh = tr.generator.voxelGNN.derived_weights()
+    for kept, now in zip(tr._g_derived, fresh):
+        assert torch.equal(kept, now)
 
 
 def test_isolated_voxel_falls_back_to_two_linear_path(cuda):
