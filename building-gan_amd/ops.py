@@ -19,6 +19,7 @@ from .plan import Csr, LinOp, SCALE_NONE
 ACT_NONE, ACT_LEAKY = 0, 1
 
 _INPUT_GRADS_ONLY = False
+_NO_GRAD_CALL = False      # set by linear(): the call was made under torch.no_grad()
 
 
 @contextlib.contextmanager
@@ -500,7 +501,7 @@ class LinearCat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, W, b, act, slope, row_scale, residual, pre_add, *xs):
         # the residual can ride in the epilogue unless a backward will need the activation's own sign
-        no_backward = not any(ctx.needs_input_grad)
+        no_backward = _NO_GRAD_CALL or not any(ctx.needs_input_grad)
         fuse_res = residual if (act != ACT_LEAKY or no_backward) else None
         w_t = isinstance(act, tuple)            # (act, "t"): W is stored [K, out] instead of [out, K]
         if w_t:
@@ -569,6 +570,8 @@ def linear(xs, W, b=None, act=ACT_NONE, slope=0.01, row_scale=None, residual=Non
     """``w_t``: W is given as [K, out] (y = cat(xs) @ W) instead of the nn.Linear layout [out, K].
     ``pre_gather``: a pure gather LinOp (one source row per output row, no scaling); ``pre_add`` then holds
     one row per SOURCE and the gather is fused into the product's epilogue."""
+    global _NO_GRAD_CALL
+    _NO_GRAD_CALL = not torch.is_grad_enabled()       # Function.forward itself always runs with grad mode off
     if torch.is_tensor(xs):
         xs = [xs]
     if pre_gather is not None:
