@@ -98,7 +98,16 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream() -> int:
+    """Raw handle of torch's current HIP stream on the current device.  Called once per kernel launch: the
+    C-level getters cost ~0.3 us against ~4 us for torch.cuda.current_stream().cuda_stream (a Stream object per
+    call), which was 1.2 ms of an eager training iteration."""
+    if _raw_stream is not None and _get_device is not None:
+        return _raw_stream(_get_device())
     return torch.cuda.current_stream().cuda_stream
 
 
