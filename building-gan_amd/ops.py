@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import threading
 from typing import List, Optional, Sequence
 
 import torch
@@ -254,6 +255,18 @@ _PtrArr4 = C.c_void_p * 4
 _I64Arr4 = C.c_int64 * 4
 
 
+_GEMM_TLS = threading.local()
+
+
+def _gemm_arrays():
+    """Per-thread ctypes argument arrays of bg_gemm_f32 (the autograd engine calls backward functions from its
+    own thread); building three arrays per call cost more than the launch itself."""
+    t = _GEMM_TLS
+    if not hasattr(t, "pa"):
+        t.pa, t.la, t.ka = _PtrArr4(), _I64Arr4(), _I64Arr4()
+    return t.pa, t.la, t.ka
+
+
 def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: bool,
              bias: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
              act: int = ACT_NONE, slope: float = 0.01, residual: Optional[torch.Tensor] = None,
@@ -261,17 +274,29 @@ def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: b
              pre_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C = epilogue(cat(A, -1 (or 0 when transA)) (x) B); see bg_gemm_f32."""
     lib = _lib.load()
-    if len(A) < 1 or len(A) > 4:
+    n_seg = len(A)
+    if n_seg < 1 or n_seg > 4:
         raise _lib.BganError("gemm: 1..4 A segments")
-    As = [_f32c(a) for a in A]
     B2 = _f32c(B)
     _lib.require_device(B2, "gemm")
-    M = As[0].shape[1] if transA else As[0].shape[0]
-    Ks = [a.shape[0] if transA else a.shape[1] for a in As]
-    for a in As:
-        if (a.shape[1] if transA else a.shape[0]) != M:
-            raise _lib.BganError("gemm: A segments disagree on M")
-    Ktot = sum(Ks)
+    pa, la, ka = _gemm_arrays()
+    M = -1
+    Ktot = 0
+    keep = []                                   # converted operands must outlive the launch call
+    for i in range(4):
+        if i < n_seg:
+            a = _f32c(A[i])
+            keep.append(a)
+            r, c = a.shape
+            m, k = (c, r) if transA else (r, c)
+            if M < 0:
+                M = m
+            elif m != M:
+                raise _lib.BganError("gemm: A segments disagree on M")
+            pa[i], la[i], ka[i] = a.data_ptr(), (a.stride(0) if r > 1 else max(c, 1)), k
+            Ktot += k
+        else:
+            pa[i], la[i], ka[i] = None, 0, 0
     N = B2.shape[0] if transB else B2.shape[1]
     if (B2.shape[1] if transB else B2.shape[0]) != Ktot:
         raise _lib.BganError(f"gemm: reduction sizes differ ({Ktot} vs {tuple(B2.shape)}, transB={transB})")
@@ -281,23 +306,22 @@ def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: b
         raise _lib.BganError("gemm: `out` must be an fp32 [M, N] matrix with unit inner stride")
     if M == 0 or N == 0:
         return out
-    pa = _PtrArr4(*([a.data_ptr() for a in As] + [None] * (4 - len(As))))
-    la = _I64Arr4(*([_ld(a) for a in As] + [0] * (4 - len(As))))
-    ka = _I64Arr4(*(Ks + [0] * (4 - len(As))))
     if bias is not None:
         bias = _f32c(bias)
     if row_scale is not None:
         row_scale = _f32c(row_scale.reshape(-1))
+    ldr = ldp = 0
     if residual is not None:
         residual = _f32c(residual)
+        ldr = _ld(residual)
     if pre_add is not None:
         pre_add = _f32c(pre_add)
+        ldp = _ld(pre_add)
         if pre_rows is not None and (pre_rows.dtype != torch.int32 or pre_rows.numel() != M):
             raise _lib.BganError("gemm: pre_rows must hold one int32 row index per output row")
-    check(lib.bg_gemm_f32(int(transA), int(transB), M, N, len(As), pa, la, ka, ptr(B2), _ld(B2), ptr(out), _ld(out),
-                          ptr(bias), ptr(row_scale), act, slope, ptr(residual),
-                          _ld(residual) if residual is not None else 0, ptr(pre_add),
-                          _ld(pre_add) if pre_add is not None else 0, ptr(pre_rows), stream()), "bg_gemm_f32")
+    check(lib.bg_gemm_f32(int(transA), int(transB), M, N, n_seg, pa, la, ka, ptr(B2), _ld(B2), ptr(out), _ld(out),
+                          ptr(bias), ptr(row_scale), act, slope, ptr(residual), ldr, ptr(pre_add), ldp,
+                          ptr(pre_rows), stream()), "bg_gemm_f32")
     return out
 
 
