@@ -225,20 +225,37 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
         const float s0 = e0 / esum, s1 = e1 / esum;
         const float one0 = s0 >= s1 ? 1.f : 0.f;
         if (lane == 0) { soft0[v] = s0; hard0[v] = (one0 - s0) + s0; }
-        // ---- logits of the voxel's cross edges (k_cross_logits); lane j keeps edge j's y = (att + gumbel) / tau
+        // ---- logits of the voxel's cross edges (k_cross_logits); lane j keeps edge j's y = (att + gumbel) / tau.
+        // Lane j first fetches edge j's program node and noise (one coalesced load each); the program rows of
+        // four edges are then requested together, so a voxel pays one memory round trip per four edges
+        // instead of two dependent ones (index, then row) per edge.  Same arithmetic in the same order.
         float av[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) av[j] = A[v * lda + lane + 64 * j];
         const int32_t b = rowptr[v], e = rowptr[v + 1];
         const int deg = e - b;
+        const int32_t my_col = lane < deg ? col[b + lane] : 0;
+        const float my_exp = lane < deg ? exp_att[b + lane] : 1.f;
         float y = -3.402823466e+38f;
-        for (int32_t k = b; k < e; ++k) {
-            const float* bp = B + (int64_t)col[k] * ldb;
-            float acc = 0.f;
+        for (int k0 = 0; k0 < deg; k0 += 4) {
+            float bv[4][CPL];
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) acc = fmaf(th[j], tanhf(av[j] + bp[lane + 64 * j]), acc);
-            acc = bg_wave_sum(acc);
-            if (lane == k - b) y = (acc + (-logf(exp_att[k]))) / tau;
+            for (int i = 0; i < 4; ++i) {
+                const int32_t c = __shfl(my_col, k0 + i < deg ? k0 + i : k0, 64);
+                const float* bp = B + (int64_t)c * ldb;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) bv[i][j] = bp[lane + 64 * j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (k0 + i < deg) {                                  // wave-uniform
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) acc = fmaf(th[j], tanhf(av[j] + bv[i][j]), acc);
+                    acc = bg_wave_sum(acc);
+                    if (lane == k0 + i) y = (acc + (-logf(my_exp))) / tau;
+                }
+            }
         }
         // ---- segment Gumbel-softmax (k_seg_gumbel_softmax): max, then exp / sum in slot order
         float m = y;
@@ -261,11 +278,23 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
         float g[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) g[j] = 0.f;
-        for (int jk = 0; jk < deg; ++jk) {
-            const float w = __shfl(o, jk, 64);
-            const float* xp = X + (int64_t)col[b + jk] * ldx;
+        for (int k0 = 0; k0 < deg; k0 += 4) {
+            float xv[4][CPL];
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) g[j] += w * xp[lane + 64 * j];
+            for (int i = 0; i < 4; ++i) {
+                const int32_t c = __shfl(my_col, k0 + i < deg ? k0 + i : k0, 64);
+                const float* xp = X + (int64_t)c * ldx;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) xv[i][j] = xp[lane + 64 * j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (k0 + i < deg) {
+                    const float w = __shfl(o, k0 + i, 64);
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) g[j] += w * xv[i][j];
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < CPL; ++j) out[v * ldo + lane + 64 * j] = vv[j] + s0 * g[j];
