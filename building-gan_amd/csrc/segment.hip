@@ -34,7 +34,7 @@ __device__ __forceinline__ void spmm_vec_body(const SpmmArgs& a, int64_t blk) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int sub = lane % LPR;
-    const int64_t row = (blk * 4 + wave) * RPW + lane / LPR;
+    const int64_t row = (blk * (blockDim.x >> 6) + wave) * RPW + lane / LPR;
     if (row >= a.n_rows || sub >= a.H4) return;
     const int32_t b = a.rowptr[row], e = a.rowptr[row + 1];
     const float* xb = a.x + 4 * sub;
@@ -389,12 +389,13 @@ __device__ __forceinline__ void story_project_body(const float* __restrict__ x, 
                                                    const float* __restrict__ count,
                                                    const float* __restrict__ W, int64_t ldw, int Hout,
                                                    float* __restrict__ out, int64_t ldo, int H, int64_t row) {
-    __shared__ float4 part[256];
+    __shared__ float4 part[1024];
     __shared__ float mean[256];
+    const int nt = blockDim.x;                  // 256 or 1024 threads (a power of two)
     const int H4 = H / 4;                       // <= 64 lanes per slot row
     int lpr = 1;
     while (lpr < H4) lpr <<= 1;
-    const int spb = 256 / lpr, sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
+    const int spb = nt / lpr, sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
     const int32_t k0 = rowptr[row], k1 = rowptr[row + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (sub < H4) {
@@ -409,16 +410,39 @@ __device__ __forceinline__ void story_project_body(const float* __restrict__ x, 
         }
         for (; k < k1; k += spb) acc = bg_add4(acc, bg_ld4(xb + (int64_t)(col ? col[k] : k) * ldx));
     }
+    // the lane groups' partial sums, combined by a fixed binary tree (deterministic)
     part[threadIdx.x] = acc;
     __syncthreads();
+    for (int stride = spb >> 1; stride > 0; stride >>= 1) {
+        if (grp < stride) {
+            acc = bg_add4(acc, part[(grp + stride) * lpr + sub]);
+            part[threadIdx.x] = acc;
+        }
+        __syncthreads();
+    }
     if (grp == 0 && sub < H4) {
-        for (int g = 1; g < spb; ++g) acc = bg_add4(acc, part[g * lpr + sub]);
         const float c = count[row];
         mean[4 * sub + 0] = acc.x / c; mean[4 * sub + 1] = acc.y / c;
         mean[4 * sub + 2] = acc.z / c; mean[4 * sub + 3] = acc.w / c;
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < 2 * Hout; o += 256) {
+    // projection: P = nt / (2 Hout) adjacent lanes share one output, each over a contiguous quarter (..) of H
+    int P = nt / (2 * Hout);
+    if (P >= 2 && (P & (P - 1)) == 0 && P <= 8 && P * 2 * Hout == nt && H % (4 * P) == 0) {
+        const int o = threadIdx.x / P, pp = threadIdx.x % P, hs = H / P;
+        const float* w = W + (int64_t)(o < Hout ? o : o - Hout) * ldw + (o < Hout ? 0 : H) + pp * hs;
+        const float* mv = mean + pp * hs;
+        float d = 0.f;
+        for (int h = 0; h < hs; h += 4) {
+            const float4 wv = bg_ld4(w + h);
+            d = fmaf(wv.x, mv[h], d); d = fmaf(wv.y, mv[h + 1], d);
+            d = fmaf(wv.z, mv[h + 2], d); d = fmaf(wv.w, mv[h + 3], d);
+        }
+        for (int off = 1; off < P; off <<= 1) d += __shfl_xor(d, off, 64);
+        if (pp == 0) out[row * ldo + o] = d;
+        return;
+    }
+    for (int o = threadIdx.x; o < 2 * Hout; o += nt) {
         const float* w = W + (int64_t)(o < Hout ? o : o - Hout) * ldw + (o < Hout ? 0 : H);
         float d = 0.f;
         for (int h = 0; h < H; h += 4) {
@@ -430,7 +454,7 @@ __device__ __forceinline__ void story_project_body(const float* __restrict__ x, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_story_project(const float* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(1024) void k_story_project(const float* __restrict__ x, int64_t ldx,
                                                        const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                        const float* __restrict__ count,
                                                        const float* __restrict__ W, int64_t ldw, int Hout,
@@ -447,7 +471,7 @@ struct StoryArgs {
 };
 
 template <int LPR>
-__global__ __launch_bounds__(256) void k_gather_story(SpmmArgs a, StoryArgs st, int H) {
+__global__ __launch_bounds__(1024) void k_gather_story(SpmmArgs a, StoryArgs st, int H) {
     if ((int)blockIdx.x < st.n_story_blocks) {
         if ((int)blockIdx.x < st.n_story)
             story_project_body(a.x, a.ldx, st.rowptr, st.col, st.count, st.W, st.ldw, st.Hout, st.out, st.ldo, H, blockIdx.x);
@@ -853,7 +877,7 @@ int bg_story_project_f32(const float* x, int64_t ldx, const int32_t* rowptr, con
     if (!x || !rowptr || !count || !W || !out || ldx < H || ldw < 2 * H || ldo < 2 * Hout) return BG_ERR_ARG;
     if (H % 4 != 0 || H > 256) return BG_ERR_SHAPE;
     if (!bg_aligned16(x) || !bg_aligned16(W) || ldx % 4 != 0 || ldw % 4 != 0) return BG_ERR_ALIGN;
-    k_story_project<<<(unsigned)n_rows, 256, 0, (hipStream_t)stream>>>(x, ldx, rowptr, col, count, W, ldw, (int)Hout,
+    k_story_project<<<(unsigned)n_rows, 1024, 0, (hipStream_t)stream>>>(x, ldx, rowptr, col, count, W, ldw, (int)Hout,
                                                                       out, ldo, (int)H);
     BG_LAUNCH_CHECK();
     return BG_OK;
@@ -875,20 +899,20 @@ int bg_gather_story_f32(const float* x, int64_t ldx, const int32_t* rowptr, cons
                nullptr, 0, nullptr, 0};
     int lpr = 1;
     while (lpr < a.H4) lpr <<= 1;
-    const int rpb = 4 * (64 / lpr);
+    const int rpb = 16 * (64 / lpr);                   // 1024 threads per workgroup: 16 waves of gather-mean rows
     const int n_story_blocks = (int)((n_story + 7) / 8 * 8);
     StoryArgs st{s_rowptr, s_col, s_count, W, ldw, (int)Hout, pq, ldq, (int)n_story, n_story_blocks};
     const int64_t grid = (int64_t)n_story_blocks + (n_rows + rpb - 1) / rpb;
     if (grid > 0x7fffffff) return BG_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     switch (lpr) {
-        case 1: k_gather_story<1><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
-        case 2: k_gather_story<2><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
-        case 4: k_gather_story<4><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
-        case 8: k_gather_story<8><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
-        case 16: k_gather_story<16><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
-        case 32: k_gather_story<32><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
-        default: k_gather_story<64><<<(unsigned)grid, 256, 0, s>>>(a, st, (int)H); break;
+        case 1: k_gather_story<1><<<(unsigned)grid, 1024, 0, s>>>(a, st, (int)H); break;
+        case 2: k_gather_story<2><<<(unsigned)grid, 1024, 0, s>>>(a, st, (int)H); break;
+        case 4: k_gather_story<4><<<(unsigned)grid, 1024, 0, s>>>(a, st, (int)H); break;
+        case 8: k_gather_story<8><<<(unsigned)grid, 1024, 0, s>>>(a, st, (int)H); break;
+        case 16: k_gather_story<16><<<(unsigned)grid, 1024, 0, s>>>(a, st, (int)H); break;
+        case 32: k_gather_story<32><<<(unsigned)grid, 1024, 0, s>>>(a, st, (int)H); break;
+        default: k_gather_story<64><<<(unsigned)grid, 1024, 0, s>>>(a, st, (int)H); break;
     }
     BG_LAUNCH_CHECK();
     return BG_OK;
