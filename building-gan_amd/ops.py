@@ -525,7 +525,9 @@ class LinearCat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, W, b, act, slope, row_scale, residual, pre_add, *xs):
         # the residual can ride in the epilogue unless a backward will need the activation's own sign
+        global _NO_GRAD_CALL
         no_backward = _NO_GRAD_CALL or not any(ctx.needs_input_grad)
+        _NO_GRAD_CALL = False                   # one-shot: a direct LinearCat.apply never inherits it
         fuse_res = residual if (act != ACT_LEAKY or no_backward) else None
         w_t = isinstance(act, tuple)            # (act, "t"): W is stored [K, out] instead of [out, K]
         if w_t:
