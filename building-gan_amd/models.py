@@ -30,6 +30,7 @@ COMPOSE_BLOCKS = True  # collapse messageMLP into updateMLP where legal (VoxelBl
 COMPOSE_STACK = True   # run the discriminator's 12 composed layers as one autograd node (ops.AffineStack)
 FUSE_STORY_TERM = True  # generator block: story mean + its projections in one launch when no graph is built
 FUSE_PROGRAM_BLOCK = True   # ProgramBlock: one launch for both aggregations, residual in the epilogue (no-grad passes)
+FUSE_GATHER_STORY_MAX_ROWS = 1 << 16   # gather-mean + story projection share a launch up to this many voxels
 FUSE_OUTPUT = True     # construct_output as one launch when no autograd graph is being built
 FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is being built
 COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
@@ -290,7 +291,11 @@ class VoxelBlock(nn.Module):
                 and "story_building_mean" in plan.ops and H % 4 == 0 and H <= 256):
             # graph-free pass: the gather-mean, the story mean and both of its projections in one launch, then
             # term[s] = P[s] + mean over the stories of s's graph of Q  (P, Q = the two halves)
-            gm, pq = ops.gather_story_raw(plan.vox_mean, plan.story_seg, voxel_feature, Wsb)
+            if plan.Nv <= FUSE_GATHER_STORY_MAX_ROWS:
+                gm, pq = ops.gather_story_raw(plan.vox_mean, plan.story_seg, voxel_feature, Wsb)
+            else:       # large batches fill the chip on their own (10^6 voxels: 417 + 96 us as two launches, 632 us as one)
+                gm = ops.spmm_raw(plan.vox_mean, voxel_feature)
+                pq = ops.story_project_raw(plan.story_seg, voxel_feature, Wsb)
             term = ops.spmm_add_raw(plan.story_building_mean, pq[:, H:], pq[:, :H])
             return linear([voxel_feature, gm, pdm4], Wc, bc, ACT_LEAKY, 0.01, pre_add=term,
                           pre_gather=plan.story_gather, residual=voxel_feature)
