@@ -2,6 +2,7 @@
 // segment max with arg, arg gather / scatter, sampled dot products.  HBM-bound: 16-byte gathers,
 // one float4 per lane, rows owned by lane groups (no atomics), slot order = COO order.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -15,6 +16,7 @@ struct SpmmArgs {
     int64_t n_rows; int H4;   // H4 = H / 4 float4 columns (<= 64 per launch)
     const float* add1; int64_t ld1;   // optional addends: out = rs * sum + add1 + add2
     const float* add2; int64_t ld2;
+    int nt_store;                     // write the result with non-temporal stores (set by spmm_dispatch for big outputs)
 };
 
 __device__ __forceinline__ float apply_scale(float v, float s, int mode) {
@@ -67,7 +69,14 @@ __device__ __forceinline__ void spmm_vec_body(const SpmmArgs& a, int64_t blk) {
     }
     if (a.add1) acc = bg_add4(acc, bg_ld4(a.add1 + row * a.ld1 + 4 * sub));
     if (a.add2) acc = bg_add4(acc, bg_ld4(a.add2 + row * a.ld2 + 4 * sub));
-    bg_st4(a.out + row * a.ldo + 4 * sub, acc);
+    if (a.nt_store) {
+        // a result far larger than the caches streams past them: the gathered rows keep the L2 / Infinity Cache
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f o = {acc.x, acc.y, acc.z, acc.w};
+        __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(a.out + row * a.ldo + 4 * sub));
+    } else {
+        bg_st4(a.out + row * a.ldo + 4 * sub, acc);
+    }
 }
 
 template <int LPR, bool GENERAL>
@@ -123,6 +132,10 @@ int spmm_dispatch(SpmmArgs a, int64_t H, hipStream_t s) {
         return BG_OK;
     }
     const bool general = !a.col || a.edge_w || a.col_mode;
+    {
+        static const int64_t nt_bytes = [] { const char* e = getenv("BG_SPMM_NT_MB"); return (int64_t)(e ? atoi(e) : 128) << 20; }();
+        a.nt_store = nt_bytes > 0 && a.n_rows * H * 4 >= nt_bytes;
+    }
     for (int64_t h0 = 0; h0 < H; h0 += 256) {   // panels of 64 float4 columns
         SpmmArgs p = a;
         p.x = a.x + h0; p.out = a.out + h0;

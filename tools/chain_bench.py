@@ -26,3 +26,12 @@ for W in (32, 24, 16):
         t1 = timeit(lambda: ops.power_chain_raw(p.vox_mean, Z, L, W, blk))
         t2 = timeit(lambda: ops.horner_chain_raw(p.vox_mean.T, Y, L, W, blk))
         print("W=%2d %-10s powers %7.1f us   horner(A^T) %7.1f us" % (W, name, t1, t2), flush=True)
+# where a step's time goes: the same chain keeping only the last step (no per-step global store), and 1 step
+W = 32
+Z = torch.rand(p.Nv, (L + 1) * W, device=dev)
+out = torch.empty(p.Nv, W, device=dev)
+for steps in (12, 1):
+    t = timeit(lambda: ops._chain_launch(p.vox_mean, b, Z.data_ptr(), Z.stride(0), None, 0, 0, out.data_ptr(), W, 0, steps, W))
+    print("W=32 powers, only the last step stored, %2d steps: %7.1f us" % (steps, t), flush=True)
+    t = timeit(lambda: ops._chain_launch(p.vox_mean, b, Z.data_ptr(), Z.stride(0), None, 0, 0, Z.data_ptr() + 4 * W, Z.stride(0), W, steps, W))
+    print("W=32 powers, every step stored,         %2d steps: %7.1f us" % (steps, t), flush=True)
