@@ -150,7 +150,8 @@ def test_segmax_empty_segment(cuda):
                                    (20000, 128, [128, 128, 4]),
                                    # narrow last segments: unaligned widths, a skinny-kernel shape, the 128x128-tile shape
                                    (400, 96, [64, 36, 3]), (500, 128, [128, 2]), (90, 64, [128, 128, 4]),
-                                   (70000, 256, [256, 256, 4]), (3000, 128, [128, 1])])
+                                   (70000, 256, [256, 256, 4]), (3000, 128, [128, 1]),
+                                   (70000, 128, [128, 128, 4])])      # narrow output, many rows: 128x64 tiles
 def test_gemm_linear_cat(cuda, shape):
     from building_gan_amd import ops
     M, N, Ks = shape
