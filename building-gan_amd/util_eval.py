@@ -39,13 +39,20 @@ def check_connectivity(g, max_out_program_index, mask):
     return edges(flat & gt), edges(gt & ~flat), edges(flat & ~gt)
 
 
-def draw_z(g, noise_dim: int, device, trunc: float = 1.0):
-    """z ~ U(0,1) drawn on the CPU generator and moved, as reference util_eval.py:81-87."""
+def draw_z(g, noise_dim: int, device, trunc: float = 1.0, generator=None):
+    """z ~ U(0,1) drawn on the CPU generator and moved, as reference util_eval.py:81-87.  When ``generator`` is
+    given and its voxel GNN takes no noise (reference models.py:239 builds it with noise_dim 0, so voxel_z is
+    never read) voxel_z is not drawn: for a 10^6-voxel batch the unused draw and its copy cost more than the
+    whole forward.  (The CPU generator's stream then differs from the reference's after this call.)"""
     program_z = torch.rand(g.program_class_feature.shape[0], noise_dim).to(device)
-    voxel_z = torch.rand(g.voxel_feature.shape[0], noise_dim).to(device)
+    if generator is not None and getattr(getattr(generator, "voxelGNN", None), "noise_dim", 1) == 0:
+        voxel_z = None
+    else:
+        voxel_z = torch.rand(g.voxel_feature.shape[0], noise_dim).to(device)
     if trunc < 1.0:
         program_z.clamp_(min=-trunc, max=trunc)
-        voxel_z.clamp_(min=-trunc, max=trunc)
+        if voxel_z is not None:
+            voxel_z.clamp_(min=-trunc, max=trunc)
     return program_z, voxel_z
 
 
@@ -62,7 +69,7 @@ def evaluate(data_loader, generator, raw_dir: Optional[str], output_dir: Optiona
             if i >= number_of_batches:
                 break
             g.to(device)
-            program_z, voxel_z = draw_z(g, generator.noise_dim, device, trunc)
+            program_z, voxel_z = draw_z(g, generator.noise_dim, device, trunc, generator)
             out, soft_out, mask, att, max_out_program_index = generator(g, program_z, voxel_z)
             inter_edges, missing_edges, gen_edges = check_connectivity(g, max_out_program_index, mask["hard"])
             total_inter += inter_edges.shape[1]
@@ -85,7 +92,7 @@ def generate_multiple_outputs_from_batch(batch, variation_num, generator, raw_di
     device = device_ids[0] if device_ids else next(generator.parameters()).device
     batch.to(device)
     with torch.no_grad():
-        program_z, voxel_z = draw_z(batch, generator.noise_dim, device, trunc)
+        program_z, voxel_z = draw_z(batch, generator.noise_dim, device, trunc, generator)
         out, soft_out, mask, att, max_out_program_index = generator(batch, program_z, voxel_z)
         class_w, program_w, far = get_program_ratio(batch, att["hard"], mask["hard"], area_index_in_voxel_feature=6)
         if writer is not None:
