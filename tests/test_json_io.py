@@ -87,3 +87,18 @@ def test_save_output_writes_labels_ratios_and_far(tmp_path):
         for a, b in zip(vg["voxel_node"], raw_v["voxel_node"]):
             assert a["type"] == b["type"] and a["type_id"] == b["type_id"]      # labels painted back unchanged
         assert all("region_far" in n for n in lg["node"])
+
+
+def test_draw_z_skips_the_noise_the_generator_never_reads():
+    """reference util_eval.py:81-87 draws voxel_z although Generator builds its voxel GNN with noise_dim 0
+    (models.py:239); the mirror draws it only for a generator that reads it."""
+    import types
+    import torch
+    from building_gan_amd.models import Generator
+    from building_gan_amd.util_eval import draw_z
+    g = types.SimpleNamespace(program_class_feature=torch.zeros(5, 6), voxel_feature=torch.zeros(9, 7))
+    G = Generator(7, 7, 16, 4, 1, 1)
+    pz, vz = draw_z(g, 4, torch.device("cpu"), 1.0, G)
+    assert tuple(pz.shape) == (5, 4) and vz is None
+    pz, vz = draw_z(g, 4, torch.device("cpu"))                 # no generator given: both, as the reference
+    assert tuple(pz.shape) == (5, 4) and tuple(vz.shape) == (9, 4)
