@@ -31,6 +31,7 @@ COMPOSE_STACK = True   # run the discriminator's 12 composed layers as one autog
 FUSE_STORY_TERM = True  # generator block: story mean + its projections in one launch when no graph is built
 FUSE_PROGRAM_BLOCK = True   # ProgramBlock: one launch for both aggregations, residual in the epilogue (no-grad passes)
 FUSE_GATHER_STORY_MAX_ROWS = 1 << 16   # gather-mean + story projection share a launch up to this many voxels
+FUSE_GBLOCK = True      # generator block with a graph: one autograd node with a hand-written backward
 FUSE_OUTPUT = True     # construct_output as one launch when no autograd graph is being built
 FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is being built
 COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
@@ -299,6 +300,10 @@ class VoxelBlock(nn.Module):
             term = ops.spmm_add_raw(plan.story_building_mean, pq[:, H:], pq[:, :H])
             return linear([voxel_feature, gm, pdm4], Wc, bc, ACT_LEAKY, 0.01, pre_add=term,
                           pre_gather=plan.story_gather, residual=voxel_feature)
+        if (self.if_agg_story_in_update and FUSE_GBLOCK and torch.is_grad_enabled() and "story_building_mean" in plan.ops
+                and H % 4 == 0 and H <= 256 and plan.Nv <= FUSE_GATHER_STORY_MAX_ROWS):
+            # a graph is being built (generator update): the whole block as one autograd node
+            return ops.GBlock.apply(voxel_feature, Wc, bc, Wsb, pdm4, plan, 0.01)
         gm = SpMM.apply(voxel_feature, plan.vox_mean)
         if not self.if_agg_story_in_update:
             return linear([voxel_feature, gm, pdm4], Wc, bc, residual=voxel_feature)

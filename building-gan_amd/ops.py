@@ -806,6 +806,56 @@ def gather_story_raw(op: LinOp, c: Csr, x: torch.Tensor, W: torch.Tensor):
     return gm, pq
 
 
+class GBlock(torch.autograd.Function):
+    """v + block(v) of the generator's composed VoxelBlock (models.VoxelBlock.compose) as ONE autograd node:
+
+        gm = A v;  story = mean_story(v);  term = story (Wu3 - Wu4)^T + building Wu4^T  (per story)
+        y = leaky([v | gm | p] Wc^T + bc + term[story of the voxel]);  out = v + y
+
+    Forward = the fused launches of the graph-free pass (gather-mean + story projection, building term,
+    product with the gathered term in its epilogue) plus the residual add: 4 launches for 7 of the op-by-op
+    path.  The hand-written backward needs 15 for its 21: one pass turns the incoming gradient into
+    g + gx_self + A^T gx_nbr, a second adds the story / building means' share.  First-order autograd only
+    (the generator is never differentiated twice)."""
+
+    @staticmethod
+    def forward(ctx, v, Wc, bc, Wsb, pdm4, plan, slope: float):
+        H = v.shape[1]
+        gm, pq = gather_story_raw(plan.vox_mean, plan.story_seg, v, Wsb)
+        term = spmm_add_raw(plan.story_building_mean, pq[:, H:], pq[:, :H])
+        y = gemm_raw([v, gm, pdm4], Wc, False, True, bias=bc, act=ACT_LEAKY, slope=slope, pre_add=term,
+                     pre_rows=plan.story_gather.csr.col)
+        ctx.plan, ctx.slope = plan, slope
+        ctx.save_for_backward(v, gm, y, Wc, Wsb, pdm4)
+        return v + y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        v, gm, y, Wc, Wsb, pdm4 = ctx.saved_tensors
+        plan = ctx.plan
+        H = v.shape[1]
+        g = _f32c(g)
+        gz = torch.ops.aten.leaky_relu_backward(g, y, ctx.slope, True)           # y = leaky(z) has the sign of z
+        gterm = spmm_raw(plan.story_gather.T, gz)                                 # [S, H]: sum over each story's voxels
+        gWc = gbc = gWsb = gv = None
+        if ctx.needs_input_grad[1]:
+            gWc = gemm_tn_raw(gz, [v, gm, pdm4])
+        if ctx.needs_input_grad[2]:
+            gbc = colsum_raw(gz)
+        sbm = plan.story_building_mean                                            # symmetric: its own transpose
+        if ctx.needs_input_grad[3]:
+            story = spmm_raw(plan.story_mean, v)
+            gWsb = gemm_tn_raw(gterm, [story, spmm_raw(sbm, story)])
+        if ctx.needs_input_grad[0]:
+            gx = gemm_raw([gz], Wc[:, :2 * H], False, False)                      # [N, 2H]: to v | to A v
+            gsb = gemm_raw([gterm], Wsb, False, False)                            # [S, 2H]: to story | to building
+            g_story = spmm_add_raw(sbm, gsb[:, H:], gsb[:, :H])
+            t1 = spmm_add_raw(plan.vox_mean.T, gx[:, H:], g, gx[:, :H])
+            gv = spmm_add_raw(plan.story_mean.T, g_story, t1)
+        return gv, gWc, gbc, gWsb, None, None, None
+
+
 def attention_forward_raw(a, logits, b, x, v, theta, plan, exp_mask, exp_att, tau: float, wd=None, bd=None):
     """One Attention call without an autograd graph (see bg_attention_fwd_f32).  ``logits`` [Nv,2], or None with
     the composed decoder (wd [2,H], bd [2]) to apply in the kernel.

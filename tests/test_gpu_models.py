@@ -381,3 +381,33 @@ def test_fused_attention_forward_equals_unfused(cuda):
     assert torch.equal(att_g["hard"].round(), att_r["hard"].round()) and torch.equal(mask_g["hard"].round(), mask_r["hard"].round())
     for a, b in ((out_g, out_r), (soft_g, soft_r), (mask_g["soft"], mask_r["soft"]), (att_g["soft"], att_r["soft"])):
         torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_generator_block_node_equals_op_by_op_path(cuda):
+    """ops.GBlock (one autograd node, hand-written backward) against the op-by-op composed block on identical
+    weights and inputs: output and every gradient (input, messageMLP, updateMLP) to fp32 rounding."""
+    from building_gan_amd import models as hm
+    from building_gan_amd.plan import build_plan
+    cpu, gpu, sz, *_ = _setup("small", 51, True, cuda)
+    plan = build_plan(gpu)
+    assert plan.vox_all_has
+    torch.manual_seed(51)
+    blk = hm.VoxelBlock(128, if_agg_story_in_update=True).to(cuda)
+    pdm4 = hm.position_terms(gpu)
+    v0 = (torch.rand(sz["Nv"], 128, device=cuda) * 2 - 1)
+    gout = torch.rand(sz["Nv"], 128, device=cuda) * 2 - 1
+    res = {}
+    for fused in (True, False):
+        hm.FUSE_GBLOCK = fused
+        try:
+            for p in blk.parameters():
+                p.grad = None
+            v = v0.clone().requires_grad_(True)
+            out = blk.forward_composed(v, plan, pdm4, blk.compose())
+            (out * gout).sum().backward()
+            res[fused] = [out.detach(), v.grad] + [p.grad.clone() for p in blk.parameters()]
+        finally:
+            hm.FUSE_GBLOCK = True
+    for a, b in zip(res[True], res[False]):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale
