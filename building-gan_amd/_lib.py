@@ -46,7 +46,7 @@ SIGNATURES = {
     "bg_attention_fwd_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _f,
                              _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _i64, _p, _p],
     "bg_mask_gumbel_f32": [_p, _i64, _p, _p, _p, _i64, _p],
-    "bg_mask_gumbel_bwd_f32": [_p, _p, _p, _p, _i64, _p],
+    "bg_mask_gumbel_bwd_f32": [_p, _p, _p, _p, _p, _i64, _i64, _p],
     "bg_gp_sample_f32": [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p],
     "bg_pack_columns_f32": [_p, _p, _int, _i64, _i64, _p, _i64, _i64, _p],
     "bg_construct_output_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _p],

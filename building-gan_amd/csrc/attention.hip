@@ -162,13 +162,15 @@ __global__ void k_mask_gumbel(const float* __restrict__ logits, int64_t ldl, con
 
 // d logits of  <g_soft, soft0> + <g_hard, hard0>  (the hard output passes its gradient straight through)
 __global__ void k_mask_gumbel_bwd(const float* __restrict__ soft0, const float* __restrict__ g_soft,
-                                  const float* __restrict__ g_hard, float* __restrict__ d_logits, int64_t n) {
+                                  const float* __restrict__ g_hard, const float* __restrict__ g_more,
+                                  float* __restrict__ d_logits, int64_t ldd, int64_t n) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
     const float s = soft0[v];
-    const float g = (g_soft ? g_soft[v] : 0.f) + (g_hard ? g_hard[v] : 0.f);
+    const float g = (g_soft ? g_soft[v] : 0.f) + (g_hard ? g_hard[v] : 0.f) + (g_more ? g_more[v] : 0.f);
     const float d = g * s * (1.f - s);
-    *reinterpret_cast<float2*>(d_logits + 2 * v) = make_float2(d, -d);
+    if (ldd == 2) *reinterpret_cast<float2*>(d_logits + 2 * v) = make_float2(d, -d);
+    else *reinterpret_cast<float4*>(d_logits + ldd * v) = make_float4(d, -d, 0.f, 0.f);   // a 4-column slot of a wider row
 }
 
 // Forward-only fusion of one Attention call (reference models.py:104-126) for passes that build no
@@ -384,13 +386,14 @@ int bg_mask_gumbel_f32(const float* logits, int64_t ldl, const float* expn, floa
     return BG_OK;
 }
 
-int bg_mask_gumbel_bwd_f32(const float* soft0, const float* g_soft, const float* g_hard, float* d_logits,
-                           int64_t n, bgStream stream) {
+int bg_mask_gumbel_bwd_f32(const float* soft0, const float* g_soft, const float* g_hard, const float* g_more,
+                           float* d_logits, int64_t ldd, int64_t n, bgStream stream) {
     if (n < 0) return BG_ERR_ARG;
     if (n == 0) return BG_OK;
-    if (!soft0 || !d_logits) return BG_ERR_ARG;
-    k_mask_gumbel_bwd<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(soft0, g_soft, g_hard,
-                                                                                         d_logits, n);
+    if (!soft0 || !d_logits || ldd < 2) return BG_ERR_ARG;
+    if (ldd != 2 && (ldd % 4 != 0 || !bg_aligned16(d_logits))) return BG_ERR_ALIGN;
+    k_mask_gumbel_bwd<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(soft0, g_soft, g_hard, g_more,
+                                                                                         d_logits, ldd, n);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

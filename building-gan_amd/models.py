@@ -31,6 +31,7 @@ COMPOSE_STACK = True   # run the discriminator's 12 composed layers as one autog
 FUSE_STORY_TERM = True  # generator block: story mean + its projections in one launch when no graph is built
 FUSE_PROGRAM_BLOCK = True   # ProgramBlock: one launch for both aggregations, residual in the epilogue (no-grad passes)
 FUSE_GATHER_STORY_MAX_ROWS = 1 << 16   # gather-mean + story projection share a launch up to this many voxels
+FUSE_ATTENTION_NODE = True   # Attention call with a graph: one autograd node with a hand-written backward
 FUSE_GBLOCK = True      # generator block with a graph: one autograd node with a hand-written backward
 FUSE_OUTPUT = True     # construct_output as one launch when no autograd graph is being built
 FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is being built
@@ -211,8 +212,18 @@ class Attention(nn.Module):
                 wd=Wcat[H:H + 2], bd=bcat[H:H + 2])
             return ({"hard": hard0, "soft": soft0}, {"hard": hard_att.view(-1, 1), "soft": soft_att.view(-1, 1)},
                     new_voxel_feature)
+        if (Wcat is not None and FUSE_ATTENTION_NODE and torch.is_grad_enabled() and 0 < plan.cross_v.max_len <= 64
+                and H % 64 == 0 and H % 4 == 0):
+            # a graph is being built (generator update): the whole call as one autograd node
+            if exp_mask is None:
+                exp_mask = torch.empty(voxel_feature.shape[0], 2, dtype=torch.float32, device=voxel_feature.device).exponential_()
+            if exp_att is None:
+                exp_att = torch.empty(plan.Ec, dtype=torch.float32, device=voxel_feature.device).exponential_()
+            soft0, hard0, soft_att, hard_att, new_voxel_feature = ops.AttentionNode.apply(
+                voxel_feature, program_graph_feature, b, Wcat, bcat, self.theta, exp_mask, exp_att, plan, -1.0)
+            return ({"hard": hard0, "soft": soft0}, {"hard": hard_att.view(-1, 1), "soft": soft_att.view(-1, 1)},
+                    new_voxel_feature)
         if Wcat is not None:
-            H = self.NN_v.weight.shape[0]
             a, logits, _ = linear(voxel_feature, Wcat, bcat).split([H, 2, 2], dim=1)
         else:
             logits = run_mlp(self.dec, voxel_feature)

@@ -770,7 +770,7 @@ class MaskGumbel(torch.autograd.Function):
         gs = _f32c(g_soft).contiguous() if g_soft is not None else None
         gh = _f32c(g_hard).contiguous() if g_hard is not None else None
         d = torch.empty(n, 2, dtype=torch.float32, device=soft0.device)
-        check(lib.bg_mask_gumbel_bwd_f32(ptr(soft0), ptr(gs), ptr(gh), ptr(d), n, stream()), "bg_mask_gumbel_bwd_f32")
+        check(lib.bg_mask_gumbel_bwd_f32(ptr(soft0), ptr(gs), ptr(gh), None, ptr(d), 2, n, stream()), "bg_mask_gumbel_bwd_f32")
         return d, None
 
 
@@ -804,6 +804,92 @@ def gather_story_raw(op: LinOp, c: Csr, x: torch.Tensor, W: torch.Tensor):
                                   ptr(gm), H, oc.n_rows, ptr(c.rowptr), ptr(c.col), ptr(c.count), ptr(W2), _ld(W2), Hout,
                                   ptr(pq), 2 * Hout, c.n_rows, H, stream()), "bg_gather_story_f32")
     return gm, pq
+
+
+def _identity_op(plan) -> LinOp:
+    """Row i <- row i (one slot per row, no column list): lets bg_sddmm_f32 take per-row dot products."""
+    op = plan.ops.get("vox_identity")
+    if op is None:
+        n = plan.Nv
+        op = LinOp(Csr(torch.arange(n + 1, dtype=torch.int32, device=plan.device), None, None, n, n, n))
+        plan.ops["vox_identity"] = op
+    return op
+
+
+class AttentionNode(torch.autograd.Function):
+    """One Attention call (reference models.py:104-126) as ONE autograd node: the forward is the fused pair of
+    the graph-free pass (NN_v product, then one launch for mask, cross logits, segment Gumbel-softmax pointer,
+    weighted gather and residual), the backward is written by hand over the existing backward kernels --
+    17-19 launches for the 29 of the op-by-op graph, 2 for 6 forward.  First-order autograd.
+
+    Inputs: v [Nv,H], x [Np,H] program features, b = NN_p(x) [Np,H], Wcat [H+4,H] / bcat [H+4] (NN_v with the
+    composed two-row mask decoder stacked under it), theta, Exp(1) noise.  Outputs (soft0 [Nv,1], hard0 [Nv,1],
+    soft [Ec], hard [Ec], new voxel features)."""
+
+    @staticmethod
+    def forward(ctx, v, x, b, Wcat, bcat, theta, exp_mask, exp_att, plan, tau: float):
+        H = v.shape[1]
+        a = gemm_raw([v], Wcat[:H], False, True, bias=bcat[:H])
+        soft0, hard0, soft, hard, out = attention_forward_raw(a, None, b, x, v, theta, plan, exp_mask, exp_att, tau,
+                                                              wd=Wcat[H:H + 2], bd=bcat[H:H + 2])
+        ctx.plan, ctx.tau = plan, float(tau)
+        ctx.theta_shape = theta.shape
+        ctx.save_for_backward(v, x, b, a, Wcat, theta, soft0, soft)
+        ctx.set_materialize_grads(False)
+        return soft0, hard0, soft, hard, out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_soft0, g_hard0, g_soft, g_hard, g_out):
+        lib = _lib.load()
+        v, x, b, a, Wcat, theta, soft0, soft = ctx.saved_tensors
+        plan = ctx.plan
+        cv = plan.cross_v
+        N, H = v.shape
+        dev = v.device
+        th = _f32c(theta.reshape(-1))
+        # ---- new_v = v + soft0 * gathered,  gathered = sum_e soft_e x[cep_e]
+        g_e = None
+        g_x = None
+        g_more = None
+        if g_out is not None:
+            g_out = _f32c(g_out)
+            gathered = spmm_raw(plan.cross_v_sum, x, soft)
+            g_more = sddmm_raw(_identity_op(plan), g_out, gathered)             # <g_out[v], gathered[v]>: to soft0
+            gg = g_out * soft0                                                  # to gathered
+            g_e = sddmm_raw(plan.cross_v_sum, gg, x)                            # to soft_e
+            if ctx.needs_input_grad[1]:
+                g_x = spmm_raw(plan.cross_v_sum.T, gg, soft)
+        for extra in (g_soft, g_hard):                                          # hard passes its gradient straight to soft
+            if extra is not None:
+                g_e = extra.reshape(-1) if g_e is None else g_e + extra.reshape(-1)
+        # ---- one [Nv, H+4] matrix of gradients at the stacked Linear's output: [d a | d logits | 0 0]
+        G_al = torch.empty(N, H + 4, dtype=torch.float32, device=dev)
+        db = dth = None
+        if g_e is not None:
+            d_att = torch.empty_like(soft)
+            check(lib.bg_seg_softmax_bwd_f32(ptr(soft), ptr(_f32c(g_e)), ptr(cv.rowptr), ctx.tau, ptr(d_att), cv.n_rows,
+                                             stream()), "bg_seg_softmax_bwd_f32")
+            nb = max(1, min(1024, (cv.n_rows + 3) // 4))
+            dpre = torch.empty(cv.nnz, H, dtype=torch.float32, device=dev)
+            dth_p = torch.empty(nb, H, dtype=torch.float32, device=dev)
+            check(lib.bg_cross_logits_bwd_f32(ptr(a), _ld(a), ptr(b), _ld(b), ptr(th), ptr(cv.rowptr), ptr(cv.col),
+                                              ptr(d_att), ptr(dpre), ptr(G_al), H + 4, ptr(dth_p), nb, cv.n_rows, H,
+                                              stream()), "bg_cross_logits_bwd_f32")
+            if ctx.needs_input_grad[2]:
+                db = spmm_raw(plan.edge_program_gather.T, dpre)
+            if ctx.needs_input_grad[5]:
+                dth = colsum_raw(dth_p).view(ctx.theta_shape)
+        else:
+            G_al[:, :H].zero_()
+        gs0 = _f32c(g_soft0).contiguous() if g_soft0 is not None else None
+        gh0 = _f32c(g_hard0).contiguous() if g_hard0 is not None else None
+        check(lib.bg_mask_gumbel_bwd_f32(ptr(soft0), ptr(gs0), ptr(gh0), ptr(g_more), G_al.data_ptr() + 4 * H, H + 4, N,
+                                         stream()), "bg_mask_gumbel_bwd_f32")
+        gW = gemm_tn_raw(G_al, [v]) if ctx.needs_input_grad[3] else None
+        gb = colsum_raw(G_al) if ctx.needs_input_grad[4] else None
+        gv = gemm_raw([G_al], Wcat, False, False, residual=g_out) if ctx.needs_input_grad[0] else None
+        return gv, g_x, db, gW, gb, dth, None, None, None, None
 
 
 class GBlock(torch.autograd.Function):

@@ -211,9 +211,10 @@ int bg_seg_argmax_f32(const float* logit, const int32_t* rowptr, int32_t* arg, i
 int bg_mask_gumbel_f32(const float* logits, int64_t ldl, const float* expn, float* soft0, float* hard0, int64_t n,
                        bgStream stream);
 
-/* d_logits [n,2] of <g_soft, soft0> + <g_hard, hard0>; either gradient may be NULL.            */
-int bg_mask_gumbel_bwd_f32(const float* soft0, const float* g_soft, const float* g_hard, float* d_logits,
-                           int64_t n, bgStream stream);
+/* d_logits of <g_soft + g_more, soft0> + <g_hard, hard0>; any gradient may be NULL.  d_logits is [n,2]
+ * (ldd == 2) or a 16-byte aligned 4-column slot (d, -d, 0, 0) of a wider row (ldd % 4 == 0).        */
+int bg_mask_gumbel_bwd_f32(const float* soft0, const float* g_soft, const float* g_hard, const float* g_more,
+                           float* d_logits, int64_t ldd, int64_t n, bgStream stream);
 
 /* One whole Attention call, forward only (no autograd graph: inference, critic-only iterations): the
  * two-way mask, the tanh cross logits, the segment Gumbel-softmax pointer, the soft-weighted gather of

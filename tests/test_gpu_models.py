@@ -371,8 +371,13 @@ def test_fused_attention_forward_equals_unfused(cuda):
     """The one-launch Attention call of graph-free passes (bg_attention_fwd_f32) against the five-kernel
     autograd path on identical weights, inputs and noise: same pointers, activations to rounding."""
     cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 41, True, cuda)
+    from building_gan_amd import models as hm
     nz = _to(noise, cuda)
-    ref = Gh(gpu, pz.to(cuda), vz.to(cuda), nz)                    # builds a graph -> unfused kernels
+    hm.FUSE_ATTENTION_NODE = hm.FUSE_GBLOCK = False
+    try:
+        ref = Gh(gpu, pz.to(cuda), vz.to(cuda), nz)                # builds a graph, op by op -> unfused kernels
+    finally:
+        hm.FUSE_ATTENTION_NODE = hm.FUSE_GBLOCK = True
     with torch.no_grad():
         got = Gh(gpu, pz.to(cuda), vz.to(cuda), nz)                # fused kernel
     out_r, soft_r, mask_r, att_r, idx_r = ref
@@ -411,3 +416,37 @@ def test_generator_block_node_equals_op_by_op_path(cuda):
     for a, b in zip(res[True], res[False]):
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-5 * scale
+
+
+def test_attention_node_equals_op_by_op_path(cuda):
+    """ops.AttentionNode (fused forward, hand-written backward) against the op-by-op Attention call on identical
+    weights, inputs and noise: all five outputs and every gradient (voxel features, program features, NN_v,
+    NN_p, decoder, theta), for a loss that uses every output."""
+    from building_gan_amd import models as hm
+    from building_gan_amd.plan import build_plan
+    cpu, gpu, sz, *_ = _setup("small", 52, True, cuda)
+    plan = build_plan(gpu)
+    torch.manual_seed(52)
+    att = hm.Attention(128).to(cuda)
+    v0 = torch.rand(sz["Nv"], 128, device=cuda) * 2 - 1
+    x0 = torch.rand(sz["Np"], 128, device=cuda) * 2 - 1
+    noise = (torch.empty(sz["Nv"], 2, device=cuda).exponential_(), torch.empty(sz["Ec"], device=cuda).exponential_())
+    w = [torch.rand(sz["Nv"], 1, device=cuda), torch.rand(sz["Nv"], 1, device=cuda), torch.rand(sz["Ec"], 1, device=cuda),
+         torch.rand(sz["Ec"], 1, device=cuda), torch.rand(sz["Nv"], 128, device=cuda) * 2 - 1]
+    res = {}
+    for fused in (True, False):
+        hm.FUSE_ATTENTION_NODE = fused
+        try:
+            for p in att.parameters():
+                p.grad = None
+            v, x = v0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+            mask, a, nv = att(x, v, plan, noise)
+            outs = [mask["soft"], mask["hard"], a["soft"], a["hard"], nv]
+            sum((o * wi).sum() for o, wi in zip(outs, w)).backward()
+            res[fused] = [o.detach() for o in outs] + [v.grad, x.grad] + [p.grad.clone() for p in att.parameters()]
+        finally:
+            hm.FUSE_ATTENTION_NODE = True
+    assert torch.equal(res[True][1].round(), res[False][1].round()) and torch.equal(res[True][3].round(), res[False][3].round())
+    for a_, b_ in zip(res[True], res[False]):
+        scale = float(b_.abs().max()) + 1e-12
+        assert float((a_ - b_).abs().max()) <= 5e-5 * scale
