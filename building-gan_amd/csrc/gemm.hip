@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_skinny(GemmArgs g) {
 }
 
 __global__ void k_splitk_reduce(const float* __restrict__ partial, int splits, int64_t M, int64_t N,
-                                float* __restrict__ C, int64_t ldc) {
+                                float* __restrict__ C, int64_t ldc, int accumulate) {
     // one float4 of C per thread (M*N % 4 == 0 checked by the launcher), splits added in order
     const int64_t MN = M * N;
     int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -581,14 +581,18 @@ __global__ void k_splitk_reduce(const float* __restrict__ partial, int splits, i
     for (; z < splits; ++z) acc = bg_add4(acc, bg_ld4(partial + (int64_t)z * MN + t));
     float v[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) C[((t + j) / N) * ldc + ((t + j) % N)] = v[j];
+    for (int j = 0; j < 4; ++j) {
+        float* c = C + ((t + j) / N) * ldc + ((t + j) % N);
+        *c = accumulate ? *c + v[j] : v[j];
+    }
 }
 
 // Few outputs, many splits (weight gradients of the narrow layers): the serial walk over the splits is the
 // whole cost, so 16 waves share it -- wave w adds splits w, w+16, .. for 64 consecutive outputs, the 16
 // partial sums are combined through LDS in wave order (deterministic).
 __global__ __launch_bounds__(1024) void k_splitk_reduce_small(const float* __restrict__ partial, int splits,
-                                                              int64_t M, int64_t N, float* __restrict__ C, int64_t ldc) {
+                                                              int64_t M, int64_t N, float* __restrict__ C, int64_t ldc,
+                                                              int accumulate) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t MN = M * N, t = (int64_t)blockIdx.x * 64 + lane;
@@ -608,23 +612,25 @@ __global__ __launch_bounds__(1024) void k_splitk_reduce_small(const float* __res
         float v = red[0][lane];
 #pragma unroll
         for (int w = 1; w < 16; ++w) v += red[w][lane];
-        C[(t / N) * ldc + (t % N)] = v;
+        float* c = C + (t / N) * ldc + (t % N);
+        *c = accumulate ? *c + v : v;
     }
 }
 
 __global__ void k_splitk_reduce_scalar(const float* __restrict__ partial, int splits, int64_t M, int64_t N,
-                                       float* __restrict__ C, int64_t ldc) {
+                                       float* __restrict__ C, int64_t ldc, int accumulate) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M * N) return;
     float acc = 0.f;
     for (int z = 0; z < splits; ++z) acc += partial[(int64_t)z * M * N + t];
-    C[(t / N) * ldc + (t % N)] = acc;
+    float* c = C + (t / N) * ldc + (t % N);
+    *c = accumulate ? *c + acc : acc;
 }
 
 // Column sums, phase 1: workgroup (bx, by) owns 64 columns x rows [by*RPB, (by+1)*RPB); its 4 waves
 // take every 4th row, 8 loads in flight per lane; the waves' sums are combined through LDS.
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ x, int64_t ldx, int64_t M, int64_t N,
-                                                        int rows_per_block, float* __restrict__ partial) {
+                                                        int rows_per_block, float* __restrict__ partial, int accumulate) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n = (int64_t)blockIdx.x * 64 + lane;
@@ -644,19 +650,23 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
     }
     red[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && n < N) partial[(int64_t)blockIdx.y * N + n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0 && n < N) {
+        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        float* p = partial + (int64_t)blockIdx.y * N + n;
+        *p = accumulate ? *p + v : v;       // accumulate only in the single-block form (partial == the result)
+    }
 }
 
 // phase 2: one wave per column adds the row-block partials (fixed shuffle tree: deterministic)
 __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ partial, int n_blocks, int64_t N,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, int accumulate) {
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     float acc = 0.f;
     for (int b = lane; b < n_blocks; b += 64) acc += partial[(int64_t)b * N + n];
     acc = bg_wave_sum(acc);
-    if (lane == 0) out[n] = acc;
+    if (lane == 0) out[n] = accumulate ? out[n] + acc : acc;
 }
 
 // tuning hook: BG_GEMM_XCD=0 keeps the hardware's round-robin tile order
@@ -896,7 +906,7 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
 
 int bg_gemm_tn_splitk_f32(int64_t M, int64_t R, const float* A, int64_t lda,
                           int n_seg, const float* const* B, const int64_t* ldb, const int64_t* Ns,
-                          float* C, int64_t ldc, float* partial, int32_t splits, bgStream stream) {
+                          float* C, int64_t ldc, float* partial, int32_t splits, int accumulate, bgStream stream) {
     if (M < 0 || R < 0 || splits < 1 || n_seg < 1 || n_seg > 4 || !B || !ldb || !Ns) return BG_ERR_ARG;
     int64_t N = 0;
     for (int s = 0; s < n_seg; ++s) {
@@ -925,17 +935,17 @@ int bg_gemm_tn_splitk_f32(int64_t M, int64_t R, const float* A, int64_t lda,
     int rc = launch_gemm<64, 64, 32, true>(1, 0, vec, g, splits, st, n_tiles);
     if (rc != BG_OK) return rc;
     if (M * N <= 65536 && splits >= 32)
-        k_splitk_reduce_small<<<bg_grid_for(M * N, 64, 0x7fffffff), 1024, 0, st>>>(partial, splits, M, N, C, ldc);
+        k_splitk_reduce_small<<<bg_grid_for(M * N, 64, 0x7fffffff), 1024, 0, st>>>(partial, splits, M, N, C, ldc, accumulate);
     else if ((M * N) % 4 == 0 && bg_aligned16(partial))
-        k_splitk_reduce<<<bg_grid_for((M * N) / 4, 256, 0x7fffffff), 256, 0, st>>>(partial, splits, M, N, C, ldc);
+        k_splitk_reduce<<<bg_grid_for((M * N) / 4, 256, 0x7fffffff), 256, 0, st>>>(partial, splits, M, N, C, ldc, accumulate);
     else
-        k_splitk_reduce_scalar<<<bg_grid_for(M * N, 256, 0x7fffffff), 256, 0, st>>>(partial, splits, M, N, C, ldc);
+        k_splitk_reduce_scalar<<<bg_grid_for(M * N, 256, 0x7fffffff), 256, 0, st>>>(partial, splits, M, N, C, ldc, accumulate);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }
 
 int bg_colsum_f32(const float* x, int64_t ldx, int64_t M, int64_t N, float* partial, int32_t n_blocks,
-                  float* out, bgStream stream) {
+                  float* out, int accumulate, bgStream stream) {
     if (M < 0 || N < 0 || n_blocks < 1) return BG_ERR_ARG;
     if (N == 0) return BG_OK;
     if (!out || !partial || (M > 0 && (!x || ldx < N))) return BG_ERR_ARG;
@@ -943,10 +953,11 @@ int bg_colsum_f32(const float* x, int64_t ldx, int64_t M, int64_t N, float* part
     const int rows_per_block = (int)((M + n_blocks - 1) / n_blocks);
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)n_blocks);
     // one row block: its "partial" row is the result (same value as the two-phase form would produce)
-    k_colsum_partial<<<grid, 256, 0, s>>>(x, ldx, M, N, rows_per_block > 0 ? rows_per_block : 1, n_blocks == 1 ? out : partial);
+    k_colsum_partial<<<grid, 256, 0, s>>>(x, ldx, M, N, rows_per_block > 0 ? rows_per_block : 1, n_blocks == 1 ? out : partial,
+                                          n_blocks == 1 ? accumulate : 0);
     BG_LAUNCH_CHECK();
     if (n_blocks == 1) return BG_OK;
-    k_colsum_final<<<bg_grid_for(N, 4), 256, 0, s>>>(partial, n_blocks, N, out);
+    k_colsum_final<<<bg_grid_for(N, 4), 256, 0, s>>>(partial, n_blocks, N, out, accumulate);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -33,6 +33,7 @@ FUSE_PROGRAM_BLOCK = True   # ProgramBlock: one launch for both aggregations, re
 FUSE_GATHER_STORY_MAX_ROWS = 1 << 16   # gather-mean + story projection share a launch up to this many voxels
 FUSE_ATTENTION_NODE = True   # Attention call with a graph: one autograd node with a hand-written backward
 FUSE_GBLOCK = True      # generator block with a graph: one autograd node with a hand-written backward
+SHARE_WEIGHT_GRADS = True   # the calls of one module in a forward sum their weight gradients in the producing launches
 FUSE_OUTPUT = True     # construct_output as one launch when no autograd graph is being built
 FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is being built
 COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
@@ -194,7 +195,8 @@ class Attention(nn.Module):
         bcat = torch.cat([self.NN_v.bias, bd, ops.zeros_view(2, device=bd.device)])
         return Wcat, bcat
 
-    def forward(self, program_graph_feature, voxel_feature, plan, noise=None, shared=None):
+    def forward(self, program_graph_feature, voxel_feature, plan, noise=None, shared=None, grads=None):
+        """``grads`` = (ops.SharedGrads, is-first-call) when the calls of one forward sum their weight gradients."""
         exp_mask, exp_att = (None, None) if noise is None else noise
         b, Wcat, bcat = shared if shared is not None else self.shared_terms(program_graph_feature)
         H = self.NN_v.weight.shape[0]
@@ -220,7 +222,8 @@ class Attention(nn.Module):
             if exp_att is None:
                 exp_att = torch.empty(plan.Ec, dtype=torch.float32, device=voxel_feature.device).exponential_()
             soft0, hard0, soft_att, hard_att, new_voxel_feature = ops.AttentionNode.apply(
-                voxel_feature, program_graph_feature, b, Wcat, bcat, self.theta, exp_mask, exp_att, plan, -1.0)
+                voxel_feature, program_graph_feature, b, Wcat, bcat, self.theta, exp_mask, exp_att, plan, -1.0,
+                *(grads if grads is not None else (None, True)))
             return ({"hard": hard0, "soft": soft0}, {"hard": hard_att.view(-1, 1), "soft": soft_att.view(-1, 1)},
                     new_voxel_feature)
         if Wcat is not None:
@@ -295,8 +298,8 @@ class VoxelBlock(nn.Module):
             return Wc, bc, torch.cat([parts[2] - parts[3], parts[3]], dim=1)
         return Wc, bc, None
 
-    def forward_composed(self, voxel_feature, plan, pdm4, composed):
-        """v + block(v) with the collapsed weights (valid when plan.vox_all_has)."""
+    def forward_composed(self, voxel_feature, plan, pdm4, composed, grads=None):
+        """v + block(v) with the collapsed weights (valid when plan.vox_all_has).  ``grads`` as in Attention.forward."""
         Wc, bc, Wsb = composed
         H = voxel_feature.shape[1]
         if (self.if_agg_story_in_update and FUSE_STORY_TERM and not torch.is_grad_enabled()
@@ -314,7 +317,8 @@ class VoxelBlock(nn.Module):
         if (self.if_agg_story_in_update and FUSE_GBLOCK and torch.is_grad_enabled() and "story_building_mean" in plan.ops
                 and H % 4 == 0 and H <= 256 and plan.Nv <= FUSE_GATHER_STORY_MAX_ROWS):
             # a graph is being built (generator update): the whole block as one autograd node
-            return ops.GBlock.apply(voxel_feature, Wc, bc, Wsb, pdm4, plan, 0.01)
+            return ops.GBlock.apply(voxel_feature, Wc, bc, Wsb, pdm4, plan, 0.01,
+                                    *(grads if grads is not None else (None, True)))
         gm = SpMM.apply(voxel_feature, plan.vox_mean)
         if not self.if_agg_story_in_update:
             return linear([voxel_feature, gm, pdm4], Wc, bc, residual=voxel_feature)
@@ -372,18 +376,22 @@ class VoxelGNN_G(nn.Module):
                    pre_add=self.pe, pre_gather=_level_op(plan, self.pe.shape[0]))
         use = derived is not None and derived[3] is not None
         shared = self.attention.shared_terms(x, (derived[3], derived[4]) if use else None)
-        _, _, v = self.attention(x, v, plan, next(draws), shared)
+        # the block's and the attention's calls chain through v: their nodes sum the shared weights' gradients
+        # in their own launches and the first call's node hands the sum on (ops.SharedGrads)
+        sg = ops.SharedGrads() if SHARE_WEIGHT_GRADS and torch.is_grad_enabled() else None
+        _, _, v = self.attention(x, v, plan, next(draws), shared, (sg, True) if sg is not None else None)
         out_mask = out_att = None
         composed = None
         if COMPOSE_BLOCKS and plan.vox_all_has:
             composed = tuple(derived[:3]) if derived is not None else self.block.compose()
         for i in range(self.layer_num):
             if composed is not None:
-                v = self.block.forward_composed(v, plan, pdm4, composed)
+                v = self.block.forward_composed(v, plan, pdm4, composed, (sg, i == 0) if sg is not None else None)
             else:
                 v = v + self.block(v, plan, pdm4)
             if i % 2 == 0 and i != 0:
-                out_mask, out_att, v = self.attention(x, v, plan, next(draws), shared)
+                out_mask, out_att, v = self.attention(x, v, plan, next(draws), shared,
+                                                      (sg, False) if sg is not None else None)
         return out_mask, out_att, v
 
 

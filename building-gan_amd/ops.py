@@ -325,8 +325,9 @@ def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: b
     return out
 
 
-def gemm_tn_raw(A: torch.Tensor, B) -> torch.Tensor:
-    """C[M,N] = A^T [B_0|B_1|..] for A [R,M], B_s [R,N_s] with a long R: split-K, deterministic order."""
+def gemm_tn_raw(A: torch.Tensor, B, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """C[M,N] = A^T [B_0|B_1|..] for A [R,M], B_s [R,N_s] with a long R: split-K, deterministic order.
+    ``out`` + ``accumulate``: add the product to an existing [M,N] buffer."""
     lib = _lib.load()
     A2 = _f32c(A)
     Bs = [_f32c(b) for b in ([B] if torch.is_tensor(B) else list(B))]
@@ -335,7 +336,12 @@ def gemm_tn_raw(A: torch.Tensor, B) -> torch.Tensor:
         raise _lib.BganError("gemm_tn: 1..4 B segments with the same reduction length as A")
     Ns = [b.shape[1] for b in Bs]
     N = sum(Ns)
-    out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    if out is None:
+        if accumulate:
+            raise _lib.BganError("gemm_tn: accumulate needs the buffer to add to")
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    elif tuple(out.shape) != (M, N) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise _lib.BganError("gemm_tn: `out` must be a contiguous fp32 [M, N] matrix")
     if M == 0 or N == 0:
         return out
     tiles = ((M + 63) // 64) * sum((n + 63) // 64 for n in Ns)
@@ -346,18 +352,23 @@ def gemm_tn_raw(A: torch.Tensor, B) -> torch.Tensor:
     lb = _I64Arr4(*([_ld(b) for b in Bs] + [0] * (4 - len(Bs))))
     nb = _I64Arr4(*(Ns + [0] * (4 - len(Bs))))
     check(lib.bg_gemm_tn_splitk_f32(M, R, ptr(A2), _ld(A2), len(Bs), pb, lb, nb, ptr(out), N, ptr(partial), splits,
-                                    stream()), "bg_gemm_tn_splitk_f32")
+                                    int(accumulate), stream()), "bg_gemm_tn_splitk_f32")
     return out
 
 
-def colsum_raw(x: torch.Tensor) -> torch.Tensor:
+def colsum_raw(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     lib = _lib.load()
     x2 = _f32c(x)
     M, N = x2.shape
     nb = max(1, min(256, (M + 127) // 128))
     partial = torch.empty(nb, N, dtype=torch.float32, device=x.device)
-    out = torch.empty(N, dtype=torch.float32, device=x.device)
-    check(lib.bg_colsum_f32(ptr(x2), _ld(x2), M, N, ptr(partial), nb, ptr(out), stream()), "bg_colsum_f32")
+    if out is None:
+        if accumulate:
+            raise _lib.BganError("colsum: accumulate needs the buffer to add to")
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+    elif out.numel() != N or not out.is_contiguous() or out.dtype != torch.float32:
+        raise _lib.BganError("colsum: `out` must be a contiguous fp32 vector of N elements")
+    check(lib.bg_colsum_f32(ptr(x2), _ld(x2), M, N, ptr(partial), nb, ptr(out), int(accumulate), stream()), "bg_colsum_f32")
     return out
 
 
@@ -816,6 +827,38 @@ def _identity_op(plan) -> LinOp:
     return op
 
 
+class SharedGrads:
+    """Gradient buffers of the weights that the nodes of ONE forward share (the generator applies the same block
+    and the same attention module 12 and 6 times, reference models.py:196-201).  Every node adds its share to
+    the buffer inside its own weight-gradient launch (``accumulate``) and only the node of the FIRST call --
+    the last to run in backward, since the calls form a chain through the voxel features -- hands the sum to
+    autograd; without it autograd sums the per-call gradients in one add launch each."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def slot(self, key, like: torch.Tensor):
+        """(buffer, accumulate): the first request of a backward pass creates the buffer (to be overwritten)."""
+        t = self.buf.get(key)
+        if t is not None:
+            return t, True
+        t = torch.empty(like.shape, dtype=torch.float32, device=like.device)
+        self.buf[key] = t
+        return t, False
+
+    def take(self, key, first: bool):
+        return self.buf.pop(key, None) if first else None
+
+
+def _wgrad(shared, key, first, like, fn):
+    """fn(out, accumulate) computes one weight gradient; with ``shared`` it lands in the common buffer."""
+    if shared is None:
+        return fn(None, False)
+    buf, acc = shared.slot(key, like)
+    fn(buf.view(-1) if buf.dim() != 2 else buf, acc)
+    return shared.take(key, first)
+
+
 class AttentionNode(torch.autograd.Function):
     """One Attention call (reference models.py:104-126) as ONE autograd node: the forward is the fused pair of
     the graph-free pass (NN_v product, then one launch for mask, cross logits, segment Gumbel-softmax pointer,
@@ -827,8 +870,9 @@ class AttentionNode(torch.autograd.Function):
     soft [Ec], hard [Ec], new voxel features)."""
 
     @staticmethod
-    def forward(ctx, v, x, b, Wcat, bcat, theta, exp_mask, exp_att, plan, tau: float):
+    def forward(ctx, v, x, b, Wcat, bcat, theta, exp_mask, exp_att, plan, tau: float, shared=None, first=True):
         H = v.shape[1]
+        ctx.shared, ctx.first = shared, first
         a = gemm_raw([v], Wcat[:H], False, True, bias=bcat[:H])
         soft0, hard0, soft, hard, out = attention_forward_raw(a, None, b, x, v, theta, plan, exp_mask, exp_att, tau,
                                                               wd=Wcat[H:H + 2], bd=bcat[H:H + 2])
@@ -879,17 +923,19 @@ class AttentionNode(torch.autograd.Function):
             if ctx.needs_input_grad[2]:
                 db = spmm_raw(plan.edge_program_gather.T, dpre)
             if ctx.needs_input_grad[5]:
-                dth = colsum_raw(dth_p).view(ctx.theta_shape)
+                dth = _wgrad(ctx.shared, "theta", ctx.first, theta, lambda o, acc: colsum_raw(dth_p, o, acc))
+                dth = dth.view(ctx.theta_shape) if dth is not None else None
         else:
             G_al[:, :H].zero_()
         gs0 = _f32c(g_soft0).contiguous() if g_soft0 is not None else None
         gh0 = _f32c(g_hard0).contiguous() if g_hard0 is not None else None
         check(lib.bg_mask_gumbel_bwd_f32(ptr(soft0), ptr(gs0), ptr(gh0), ptr(g_more), G_al.data_ptr() + 4 * H, H + 4, N,
                                          stream()), "bg_mask_gumbel_bwd_f32")
-        gW = gemm_tn_raw(G_al, [v]) if ctx.needs_input_grad[3] else None
-        gb = colsum_raw(G_al) if ctx.needs_input_grad[4] else None
+        sh, first = ctx.shared, ctx.first
+        gW = _wgrad(sh, "Wcat", first, Wcat, lambda o, acc: gemm_tn_raw(G_al, [v], o, acc)) if ctx.needs_input_grad[3] else None
+        gb = _wgrad(sh, "bcat", first, G_al[0], lambda o, acc: colsum_raw(G_al, o, acc)) if ctx.needs_input_grad[4] else None
         gv = gemm_raw([G_al], Wcat, False, False, residual=g_out) if ctx.needs_input_grad[0] else None
-        return gv, g_x, db, gW, gb, dth, None, None, None, None
+        return gv, g_x, db, gW, gb, dth, None, None, None, None, None, None
 
 
 class GBlock(torch.autograd.Function):
@@ -905,8 +951,9 @@ class GBlock(torch.autograd.Function):
     (the generator is never differentiated twice)."""
 
     @staticmethod
-    def forward(ctx, v, Wc, bc, Wsb, pdm4, plan, slope: float):
+    def forward(ctx, v, Wc, bc, Wsb, pdm4, plan, slope: float, shared=None, first=True):
         H = v.shape[1]
+        ctx.shared, ctx.first = shared, first
         gm, pq = gather_story_raw(plan.vox_mean, plan.story_seg, v, Wsb)
         term = spmm_add_raw(plan.story_building_mean, pq[:, H:], pq[:, :H])
         y = gemm_raw([v, gm, pdm4], Wc, False, True, bias=bc, act=ACT_LEAKY, slope=slope, pre_add=term,
@@ -925,21 +972,23 @@ class GBlock(torch.autograd.Function):
         gz = torch.ops.aten.leaky_relu_backward(g, y, ctx.slope, True)           # y = leaky(z) has the sign of z
         gterm = spmm_raw(plan.story_gather.T, gz)                                 # [S, H]: sum over each story's voxels
         gWc = gbc = gWsb = gv = None
+        sh, first = ctx.shared, ctx.first
         if ctx.needs_input_grad[1]:
-            gWc = gemm_tn_raw(gz, [v, gm, pdm4])
+            gWc = _wgrad(sh, "Wc", first, Wc, lambda o, acc: gemm_tn_raw(gz, [v, gm, pdm4], o, acc))
         if ctx.needs_input_grad[2]:
-            gbc = colsum_raw(gz)
+            gbc = _wgrad(sh, "bc", first, gz[0], lambda o, acc: colsum_raw(gz, o, acc))
         sbm = plan.story_building_mean                                            # symmetric: its own transpose
         if ctx.needs_input_grad[3]:
             story = spmm_raw(plan.story_mean, v)
-            gWsb = gemm_tn_raw(gterm, [story, spmm_raw(sbm, story)])
+            sb = spmm_raw(sbm, story)
+            gWsb = _wgrad(sh, "Wsb", first, Wsb, lambda o, acc: gemm_tn_raw(gterm, [story, sb], o, acc))
         if ctx.needs_input_grad[0]:
             gx = gemm_raw([gz], Wc[:, :2 * H], False, False)                      # [N, 2H]: to v | to A v
             gsb = gemm_raw([gterm], Wsb, False, False)                            # [S, 2H]: to story | to building
             g_story = spmm_add_raw(sbm, gsb[:, H:], gsb[:, :H])
             t1 = spmm_add_raw(plan.vox_mean.T, gx[:, H:], g, gx[:, :H])
             gv = spmm_add_raw(plan.story_mean.T, g_story, t1)
-        return gv, gWc, gbc, gWsb, None, None, None
+        return gv, gWc, gbc, gWsb, None, None, None, None, None
 
 
 def attention_forward_raw(a, logits, b, x, v, theta, plan, exp_mask, exp_att, tau: float, wd=None, bd=None):

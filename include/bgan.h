@@ -313,15 +313,17 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
 /* C[M,N] = A^T[M,R] * [B_0 | B_1 | ..][R,N] with the long reduction R split over `splits`
  * workgroups per tile: A is [R, M] (pitch lda), B_s is [R, Ns[s]] (pitch ldb[s]), N = sum Ns
  * (n_seg in 1..4: the concatenation of the layer inputs is never built); partial: [splits, M, N].
- * Partials are added in split order (deterministic).  The weight-gradient GEMM.
+ * Partials are added in split order (deterministic); accumulate != 0 adds the result to C instead of
+ * overwriting it (layers that share a weight sum their gradients here, in backward order, instead of in
+ * separate add launches).  The weight-gradient GEMM.
  * replaces: the grad-weight product of nn.Linear's autograd for the layers listed above.     */
 int bg_gemm_tn_splitk_f32(int64_t M, int64_t R, const float* A, int64_t lda,
                           int n_seg, const float* const* B, const int64_t* ldb, const int64_t* Ns,
-                          float* C, int64_t ldc, float* partial, int32_t splits, bgStream stream);
+                          float* C, int64_t ldc, float* partial, int32_t splits, int accumulate, bgStream stream);
 
-/* out[n] = sum_m x[m,n]   (bias gradient); partial: [n_blocks, N] workspace                  */
+/* out[n] (+)= sum_m x[m,n]   (bias gradient; accumulate != 0 adds to out); partial: [n_blocks, N] workspace */
 int bg_colsum_f32(const float* x, int64_t ldx, int64_t M, int64_t N, float* partial, int32_t n_blocks,
-                  float* out, bgStream stream);
+                  float* out, int accumulate, bgStream stream);
 
 /* ------------------------------------------------------------------ optimiser ----------- */
 

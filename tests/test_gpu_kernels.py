@@ -199,6 +199,32 @@ def test_gemm_tn_splitk_and_colsum(cuda):
     assert float((cs - A.double().sum(0)).abs().max()) < 2e-3
 
 
+@pytest.mark.parametrize("R,M,N", [(11520, 128, 260), (90, 128, 256), (11520, 132, 128), (64, 8, 3)])
+def test_gemm_tn_and_colsum_accumulate_into_a_buffer(cuda, R, M, N):
+    """accumulate != 0: the product / column sum is ADDED to the buffer (exactly buffer + what the plain call
+    writes, one fp32 addition), through every reduce kernel the split-K launcher picks."""
+    from building_gan_amd import ops
+    torch.manual_seed(61)
+    A = (torch.rand(R, M) * 2 - 1).to(cuda)
+    B = (torch.rand(R, N) * 2 - 1).to(cuda)
+    base = (torch.rand(M, N) * 2 - 1).to(cuda)
+    plain = ops.gemm_tn_raw(A, B)
+    buf = base.clone()
+    assert ops.gemm_tn_raw(A, B, out=buf, accumulate=True) is buf
+    assert torch.equal(buf, base + plain)
+    ops.gemm_tn_raw(A, B, out=buf, accumulate=False)
+    assert torch.equal(buf, plain)
+    vb = (torch.rand(M) * 2 - 1).to(cuda)
+    vplain = ops.colsum_raw(A)
+    v = vb.clone()
+    ops.colsum_raw(A, out=v, accumulate=True)
+    assert torch.equal(v, vb + vplain)
+    ops.colsum_raw(A, out=v)
+    assert torch.equal(v, vplain)
+    with pytest.raises(Exception):
+        ops.gemm_tn_raw(A, B, accumulate=True)
+
+
 def test_segment_gumbel_softmax_and_argmax(cuda):
     from building_gan_amd import ops
     from oracle.pointer import segment_gumbel_softmax, find_max_out_program_index

@@ -450,3 +450,31 @@ def test_attention_node_equals_op_by_op_path(cuda):
     for a_, b_ in zip(res[True], res[False]):
         scale = float(b_.abs().max()) + 1e-12
         assert float((a_ - b_).abs().max()) <= 5e-5 * scale
+
+
+def test_shared_weight_gradient_buffers_equal_autograd_sums(cuda):
+    """models.SHARE_WEIGHT_GRADS (the 12 block calls and 6 attention calls add their weight gradients to one
+    buffer inside the producing launches) against autograd's own per-call gradients summed by AccumulateGrad:
+    every generator parameter gradient to fp32 rounding (the order of the 12 / 6 additions differs), twice in a
+    row on the same module (the buffers are per forward)."""
+    from building_gan_amd import models as hm
+    from building_gan_amd.losses import VolumetricDesignLoss_G
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 53, True, cuda)
+    res = {}
+    for share in (True, False, True):
+        hm.SHARE_WEIGHT_GRADS = share
+        try:
+            for p in Gh.parameters():
+                p.grad = None
+            out_h, soft_h, mask_h, att_h, _ = Gh(gpu, pz.to(cuda), vz.to(cuda), _to(noise, cuda))
+            VolumetricDesignLoss_G()(Dh(gpu, out_h), gpu, att_h["hard"], mask_h["hard"], 6)[0].backward()
+            got = [p.grad.clone() for p in Gh.parameters()]
+        finally:
+            hm.SHARE_WEIGHT_GRADS = True
+        if share in res:
+            for a, b in zip(got, res[share]):
+                assert torch.equal(a, b)            # deterministic, and nothing left over from the first pass
+        res[share] = got
+    for (n, _), a, b in zip(Gh.named_parameters(), res[True], res[False]):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale, n
