@@ -160,7 +160,7 @@ __global__ void k_critic_loss_bwd(const float* __restrict__ go, const float* __r
 // (the mean over in-edges of pos_i - pos_j, reference Model/models.py:160-161, constant per batch);
 // slot order, IEEE division, products and differences rounded separately.
 __global__ void k_pos_terms(const float* __restrict__ pos, int64_t ldp, const int32_t* __restrict__ rowptr,
-                            const int32_t* __restrict__ col, float* __restrict__ out, int64_t n) {
+                            const int32_t* __restrict__ col, float* __restrict__ out, int64_t n, float pad) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
     const int32_t kb = rowptr[v], ke = rowptr[v + 1];
@@ -176,7 +176,7 @@ __global__ void k_pos_terms(const float* __restrict__ pos, int64_t ldp, const in
     o.x = __fsub_rn(__fmul_rn(has, pv[0]), __fdiv_rn(sx, cnt));
     o.y = __fsub_rn(__fmul_rn(has, pv[1]), __fdiv_rn(sy, cnt));
     o.z = __fsub_rn(__fmul_rn(has, pv[2]), __fdiv_rn(sz, cnt));
-    o.w = 0.f;
+    o.w = pad;
     *reinterpret_cast<float4*>(out + v * 4) = o;
 }
 
@@ -269,12 +269,12 @@ int bg_critic_loss_bwd_f32(const float* go, const float* wb, int64_t nb, const f
 }
 
 int bg_pos_terms_f32(const float* pos, int64_t ldp, const int32_t* rowptr, const int32_t* col, float* out, int64_t n,
-                     bgStream stream) {
+                     float pad, bgStream stream) {
     if (n < 0) return BG_ERR_ARG;
     if (n == 0) return BG_OK;
     if (!pos || !rowptr || !col || !out || ldp < 3) return BG_ERR_ARG;
     if (!bg_aligned16(out)) return BG_ERR_ALIGN;
-    k_pos_terms<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(pos, ldp, rowptr, col, out, n);
+    k_pos_terms<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(pos, ldp, rowptr, col, out, n, pad);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

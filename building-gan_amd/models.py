@@ -93,11 +93,16 @@ def extract_pos(feature):
     return feature[:, 3:6], torch.cat((feature[:, 0:3], feature[:, 6:]), dim=-1)
 
 
+PDM4_PAD = 1.0   # the 4th (pad) column of the position terms.  Every weight that multiplies it is zero-padded there, so
+                 # products do not see it; a weight GRADIENT against it is the column sum of the output gradient,
+                 # i.e. the bias gradient, which ops.GBlock reads there instead of launching a column sum.
+
+
 def _pos_terms(plan, pos):
-    """Per-node mean of (pos_i - pos_j) over in-edges, zero-padded to 4 columns (cached per plan)."""
+    """Per-node mean of (pos_i - pos_j) over in-edges, padded to 4 columns with PDM4_PAD (cached per plan)."""
     cached = plan.ops.get("pdm4")
     if cached is None:
-        cached = ops.pos_terms_raw(plan.vox_mean, pos.detach())       # one launch, straight off the feature columns
+        cached = ops.pos_terms_raw(plan.vox_mean, pos.detach(), PDM4_PAD)   # one launch, straight off the feature columns
         plan.ops["pdm4"] = cached
     return cached
 
@@ -318,7 +323,7 @@ class VoxelBlock(nn.Module):
                 and H % 4 == 0 and H <= 256 and plan.Nv <= FUSE_GATHER_STORY_MAX_ROWS):
             # a graph is being built (generator update): the whole block as one autograd node
             return ops.GBlock.apply(voxel_feature, Wc, bc, Wsb, pdm4, plan, 0.01,
-                                    *(grads if grads is not None else (None, True)))
+                                    *(grads if grads is not None else (None, True)), PDM4_PAD == 1.0)
         gm = SpMM.apply(voxel_feature, plan.vox_mean)
         if not self.if_agg_story_in_update:
             return linear([voxel_feature, gm, pdm4], Wc, bc, residual=voxel_feature)

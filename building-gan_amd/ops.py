@@ -951,9 +951,11 @@ class GBlock(torch.autograd.Function):
     (the generator is never differentiated twice)."""
 
     @staticmethod
-    def forward(ctx, v, Wc, bc, Wsb, pdm4, plan, slope: float, shared=None, first=True):
+    def forward(ctx, v, Wc, bc, Wsb, pdm4, plan, slope: float, shared=None, first=True, ones_pad=False):
+        """``ones_pad``: pdm4's last column is all ones and Wc's last column all zeros (the caller's promise), so
+        the last column of Wc's gradient IS the bias gradient and no column sum is launched."""
         H = v.shape[1]
-        ctx.shared, ctx.first = shared, first
+        ctx.shared, ctx.first, ctx.ones_pad = shared, first, bool(ones_pad)
         gm, pq = gather_story_raw(plan.vox_mean, plan.story_seg, v, Wsb)
         term = spmm_add_raw(plan.story_building_mean, pq[:, H:], pq[:, :H])
         y = gemm_raw([v, gm, pdm4], Wc, False, True, bias=bc, act=ACT_LEAKY, slope=slope, pre_add=term,
@@ -976,7 +978,10 @@ class GBlock(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gWc = _wgrad(sh, "Wc", first, Wc, lambda o, acc: gemm_tn_raw(gz, [v, gm, pdm4], o, acc))
         if ctx.needs_input_grad[2]:
-            gbc = _wgrad(sh, "bc", first, gz[0], lambda o, acc: colsum_raw(gz, o, acc))
+            if ctx.ones_pad and ctx.needs_input_grad[1]:
+                gbc = gWc[:, -1] if gWc is not None else None                     # gz^T 1, summed over the calls with gWc
+            else:
+                gbc = _wgrad(sh, "bc", first, gz[0], lambda o, acc: colsum_raw(gz, o, acc))
         sbm = plan.story_building_mean                                            # symmetric: its own transpose
         if ctx.needs_input_grad[3]:
             story = spmm_raw(plan.story_mean, v)
@@ -988,7 +993,7 @@ class GBlock(torch.autograd.Function):
             g_story = spmm_add_raw(sbm, gsb[:, H:], gsb[:, :H])
             t1 = spmm_add_raw(plan.vox_mean.T, gx[:, H:], g, gx[:, :H])
             gv = spmm_add_raw(plan.story_mean.T, g_story, t1)
-        return gv, gWc, gbc, gWsb, None, None, None, None, None
+        return gv, gWc, gbc, gWsb, None, None, None, None, None, None
 
 
 def attention_forward_raw(a, logits, b, x, v, theta, plan, exp_mask, exp_att, tau: float, wd=None, bd=None):
@@ -1073,8 +1078,8 @@ def construct_output_raw(mask_hard, att_hard, att_soft, plan, cls):
     return out, soft, idx
 
 
-def pos_terms_raw(op: LinOp, pos: torch.Tensor) -> torch.Tensor:
-    """[N, 4]: has * pos - mean over in-neighbours of pos, zero 4th column (``pos`` may be a column slice)."""
+def pos_terms_raw(op: LinOp, pos: torch.Tensor, pad: float = 0.0) -> torch.Tensor:
+    """[N, 4]: has * pos - mean over in-neighbours of pos, 4th column = ``pad`` (``pos`` may be a column slice)."""
     lib = _lib.load()
     _lib.require_device(pos, "pos_terms")
     c = op.csr
@@ -1082,7 +1087,7 @@ def pos_terms_raw(op: LinOp, pos: torch.Tensor) -> torch.Tensor:
     if p2.shape[1] != 3 or p2.shape[0] != c.n_rows or c.n_rows != c.n_cols or c.col is None:
         raise _lib.BganError("pos_terms: pos must be [N, 3] over a square CSR with explicit columns")
     out = torch.empty(c.n_rows, 4, dtype=torch.float32, device=pos.device)
-    check(lib.bg_pos_terms_f32(ptr(p2), p2.stride(0), ptr(c.rowptr), ptr(c.col), ptr(out), c.n_rows, stream()),
+    check(lib.bg_pos_terms_f32(ptr(p2), p2.stride(0), ptr(c.rowptr), ptr(c.col), ptr(out), c.n_rows, float(pad), stream()),
           "bg_pos_terms_f32")
     return out
 

@@ -257,12 +257,12 @@ int bg_construct_output_f32(const float* mask_hard, const float* att_hard, const
                             const int32_t* rowptr, const int32_t* col, const float* cls, int64_t ldc, int64_t C,
                             float* out, float* soft_out, int64_t* idx, int64_t n_vox, bgStream stream);
 
-/* out[v, 0:3] = has(v) * pos[v] - mean over v's in-neighbours j of pos[j], out[v, 3] = 0 (out [n, 4]
- * contiguous; pos[v] = 3 floats at pos + v*ldp; CSR by target): the per-voxel mean of pos_i - pos_j.
+/* out[v, 0:3] = has(v) * pos[v] - mean over v's in-neighbours j of pos[j], out[v, 3] = pad (out [n, 4]
+ * contiguous; pad 0, or 1 to carry a bias through the weight's pad column; pos[v] = 3 floats at pos + v*ldp; CSR by target): the per-voxel mean of pos_i - pos_j.
  * replaces: the pos_i - pos_j columns of the message and their scatter-mean, Model/models.py:158-161
  * (constant over the layers of a pass: evaluated once).                                          */
 int bg_pos_terms_f32(const float* pos, int64_t ldp, const int32_t* rowptr, const int32_t* col, float* out, int64_t n,
-                     bgStream stream);
+                     float pad, bgStream stream);
 
 /* out[v, 0:ds] = [ feat[v, 0:nf] | onehot(level[v]) (ML) | pdm4[v, 0:4] | 1 | 0 .. ]: the label-free input
  * columns of the discriminator's collapsed voxel GNN (ds >= nf + ML + 5).

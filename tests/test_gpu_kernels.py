@@ -637,6 +637,8 @@ def test_pos_terms_and_static_columns(cuda):
     got = ops.pos_terms_raw(p.vox_mean, g.voxel_feature[:, 3:6])
     assert torch.equal(got[:, :3].cpu(), ref) and bool((got[:, 3] == 0).all())
     assert float(got[3].abs().max()) == 0.0
+    one = ops.pos_terms_raw(p.vox_mean, g.voxel_feature[:, 3:6], 1.0)       # pad column of ones (bias carrier)
+    assert torch.equal(one[:, :3], got[:, :3]) and bool((one[:, 3] == 1).all())
     feat = torch.cat([cpu.voxel_feature[:, 0:3], cpu.voxel_feature[:, 6:]], dim=1)
     ML, ds = 20, 32
     Z = torch.full((p.Nv, 3 * ds), -7.0, device=cuda)
