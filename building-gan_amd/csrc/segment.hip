@@ -475,6 +475,63 @@ __global__ __launch_bounds__(1024) void k_story_project(const float* __restrict_
     story_project_body(x, ldx, rowptr, col, count, W, ldw, Hout, out, ldo, H, blockIdx.x);
 }
 
+// Backward companion of the above for the generator block (ops.GBlock): one workgroup per story walks the
+// story's voxels once and produces
+//   gz[c]    = g[c] * (y[c] > 0 ? 1 : slope)      (the leaky ReLU's backward from its RESULT y, every voxel c)
+//   gterm[s] = sum over the story's voxels of gz  (gradient of the per-story term gathered to the voxels)
+//   story[s] = mean over the story's voxels of v  (the forward's story mean, recomputed instead of stored)
+// in place of one elementwise launch and two segment reductions.  The segments must partition the voxels
+// (every voxel in exactly one story) for gz to be complete.  Fixed binary tree over the lane groups.
+__global__ __launch_bounds__(1024) void k_story_bwd(const float* __restrict__ g, int64_t ldg,
+                                                   const float* __restrict__ y, int64_t ldy,
+                                                   const float* __restrict__ v, int64_t ldv,
+                                                   const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                   const float* __restrict__ count, float slope,
+                                                   float* __restrict__ gz, int64_t ldz,
+                                                   float* __restrict__ gterm, int64_t ldt,
+                                                   float* __restrict__ story, int64_t lds, int H) {
+    __shared__ float4 part_g[1024];
+    __shared__ float4 part_v[1024];
+    const int row = blockIdx.x;
+    const int nt = blockDim.x;
+    const int H4 = H / 4;
+    int lpr = 1;
+    while (lpr < H4) lpr <<= 1;
+    const int spb = nt / lpr, sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
+    const int32_t k0 = rowptr[row], k1 = rowptr[row + 1];
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), av = ag;
+    if (sub < H4) {
+        for (int32_t k = k0 + grp; k < k1; k += spb) {
+            const int64_t c = col ? col[k] : k;
+            const float4 gv = bg_ld4(g + c * ldg + 4 * sub), yv = bg_ld4(y + c * ldy + 4 * sub);
+            const float4 vv = bg_ld4(v + c * ldv + 4 * sub);
+            float4 z;
+            z.x = yv.x > 0.f ? gv.x : gv.x * slope; z.y = yv.y > 0.f ? gv.y : gv.y * slope;
+            z.z = yv.z > 0.f ? gv.z : gv.z * slope; z.w = yv.w > 0.f ? gv.w : gv.w * slope;
+            *reinterpret_cast<float4*>(gz + c * ldz + 4 * sub) = z;
+            ag = bg_add4(ag, z);
+            av = bg_add4(av, vv);
+        }
+    }
+    part_g[threadIdx.x] = ag;
+    part_v[threadIdx.x] = av;
+    __syncthreads();
+    for (int stride = spb >> 1; stride > 0; stride >>= 1) {
+        if (grp < stride) {
+            ag = bg_add4(ag, part_g[(grp + stride) * lpr + sub]);
+            av = bg_add4(av, part_v[(grp + stride) * lpr + sub]);
+            part_g[threadIdx.x] = ag;
+            part_v[threadIdx.x] = av;
+        }
+        __syncthreads();
+    }
+    if (grp == 0 && sub < H4) {
+        const float c = count[row];
+        *reinterpret_cast<float4*>(gterm + (int64_t)row * ldt + 4 * sub) = ag;
+        *reinterpret_cast<float4*>(story + (int64_t)row * lds + 4 * sub) = make_float4(av.x / c, av.y / c, av.z / c, av.w / c);
+    }
+}
+
 // Both reductions that a generator block takes of the SAME voxel features, in one launch (they are
 // independent: the story workgroups -- the long pole -- are dealt first, the gather-mean rows fill the chip
 // beside them).  n_story_blocks is padded to a multiple of 8 so the gather-mean's XCD-aware row order holds.
@@ -892,6 +949,24 @@ int bg_story_project_f32(const float* x, int64_t ldx, const int32_t* rowptr, con
     if (!bg_aligned16(x) || !bg_aligned16(W) || ldx % 4 != 0 || ldw % 4 != 0) return BG_ERR_ALIGN;
     k_story_project<<<(unsigned)n_rows, 1024, 0, (hipStream_t)stream>>>(x, ldx, rowptr, col, count, W, ldw, (int)Hout,
                                                                       out, ldo, (int)H);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_story_bwd_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, const float* v, int64_t ldv,
+                     const int32_t* rowptr, const int32_t* col, const float* count, float slope,
+                     float* gz, int64_t ldz, float* gterm, int64_t ldt, float* story, int64_t lds,
+                     int64_t n_story, int64_t H, bgStream stream) {
+    if (n_story < 0 || H <= 0) return BG_ERR_ARG;
+    if (n_story == 0) return BG_OK;
+    if (!g || !y || !v || !rowptr || !count || !gz || !gterm || !story) return BG_ERR_ARG;
+    if (ldg < H || ldy < H || ldv < H || ldz < H || ldt < H || lds < H) return BG_ERR_ARG;
+    if (H % 4 != 0 || H > 256 || n_story > 0x7fffffff) return BG_ERR_SHAPE;
+    if (!bg_aligned16(g) || !bg_aligned16(y) || !bg_aligned16(v) || !bg_aligned16(gz) || !bg_aligned16(gterm) ||
+        !bg_aligned16(story) || ldg % 4 != 0 || ldy % 4 != 0 || ldv % 4 != 0 || ldz % 4 != 0 || ldt % 4 != 0 || lds % 4 != 0)
+        return BG_ERR_ALIGN;
+    k_story_bwd<<<(unsigned)n_story, 1024, 0, (hipStream_t)stream>>>(g, ldg, y, ldy, v, ldv, rowptr, col, count, slope,
+                                                                    gz, ldz, gterm, ldt, story, lds, (int)H);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

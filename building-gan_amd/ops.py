@@ -817,6 +817,24 @@ def gather_story_raw(op: LinOp, c: Csr, x: torch.Tensor, W: torch.Tensor):
     return gm, pq
 
 
+def story_bwd_raw(c: Csr, g: torch.Tensor, y: torch.Tensor, v: torch.Tensor, slope: float):
+    """(gz, gterm, story) of bg_story_bwd_f32: leaky-ReLU backward from its result, its per-story sums, and the
+    per-story means of v, in one launch.  ``c``: story segments that partition the voxel rows."""
+    lib = _lib.load()
+    _lib.require_device(g, "story_bwd")
+    g2, y2, v2 = _f32c(g), _f32c(y), _f32c(v)
+    N, H = g2.shape
+    if (c.count is None or c.n_cols != N or c.nnz != N or tuple(y2.shape) != (N, H) or tuple(v2.shape) != (N, H)):
+        raise _lib.BganError("story_bwd: the story segments must partition the rows of g, y and v")
+    gz = torch.empty(N, H, dtype=torch.float32, device=g.device)
+    gterm = torch.empty(c.n_rows, H, dtype=torch.float32, device=g.device)
+    story = torch.empty(c.n_rows, H, dtype=torch.float32, device=g.device)
+    check(lib.bg_story_bwd_f32(ptr(g2), _ld(g2), ptr(y2), _ld(y2), ptr(v2), _ld(v2), ptr(c.rowptr), ptr(c.col),
+                               ptr(c.count), float(slope), ptr(gz), H, ptr(gterm), H, ptr(story), H, c.n_rows, H,
+                               stream()), "bg_story_bwd_f32")
+    return gz, gterm, story
+
+
 def _identity_op(plan) -> LinOp:
     """Row i <- row i (one slot per row, no column list): lets bg_sddmm_f32 take per-row dot products."""
     op = plan.ops.get("vox_identity")
@@ -971,8 +989,13 @@ class GBlock(torch.autograd.Function):
         plan = ctx.plan
         H = v.shape[1]
         g = _f32c(g)
-        gz = torch.ops.aten.leaky_relu_backward(g, y, ctx.slope, True)           # y = leaky(z) has the sign of z
-        gterm = spmm_raw(plan.story_gather.T, gz)                                 # [S, H]: sum over each story's voxels
+        seg = plan.story_seg
+        if seg.nnz == v.shape[0] and seg.count is not None and H % 4 == 0 and H <= 256:
+            gz, gterm, story = story_bwd_raw(seg, g, y, v, ctx.slope)             # one launch for the three
+        else:
+            gz = torch.ops.aten.leaky_relu_backward(g, y, ctx.slope, True)       # y = leaky(z) has the sign of z
+            gterm = spmm_raw(plan.story_gather.T, gz)                             # [S, H]: sum over each story's voxels
+            story = None
         gWc = gbc = gWsb = gv = None
         sh, first = ctx.shared, ctx.first
         if ctx.needs_input_grad[1]:
@@ -984,7 +1007,8 @@ class GBlock(torch.autograd.Function):
                 gbc = _wgrad(sh, "bc", first, gz[0], lambda o, acc: colsum_raw(gz, o, acc))
         sbm = plan.story_building_mean                                            # symmetric: its own transpose
         if ctx.needs_input_grad[3]:
-            story = spmm_raw(plan.story_mean, v)
+            if story is None:
+                story = spmm_raw(plan.story_mean, v)
             sb = spmm_raw(sbm, story)
             gWsb = _wgrad(sh, "Wsb", first, Wsb, lambda o, acc: gemm_tn_raw(gterm, [story, sb], o, acc))
         if ctx.needs_input_grad[0]:

@@ -134,6 +134,17 @@ int bg_story_project_f32(const float* x, int64_t ldx, const int32_t* rowptr, con
                          const float* count, const float* W, int64_t ldw, int64_t Hout,
                          float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream);
 
+/* Backward companion of bg_story_project_f32 for a block with a leaky ReLU: per story segment s (voxels c),
+ *   gz[c] = g[c] * (y[c] > 0 ? 1 : slope),  gterm[s] = sum_c gz[c],  story[s] = (sum_c v[c]) / count[s]
+ * in ONE launch (one workgroup per story).  The segments must partition the voxel rows (each exactly once),
+ * or rows of gz stay unwritten.  H % 4 == 0, H <= 256, 16-byte aligned operands and pitches.
+ * replaces: the backward of LeakyReLU and of the story gather of updateMLP's input, and the avg_pool_x
+ * recomputation, Model/models.py:166-170, in the generator's backward.                              */
+int bg_story_bwd_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, const float* v, int64_t ldv,
+                     const int32_t* rowptr, const int32_t* col, const float* count, float slope,
+                     float* gz, int64_t ldz, float* gterm, int64_t ldt, float* story, int64_t lds,
+                     int64_t n_story, int64_t H, bgStream stream);
+
 /* bg_spmm_f32 (no edge weights, no column scale: gm = rs * P x over n_rows rows) and bg_story_project_f32
  * (pq over n_story segments) of the SAME x in ONE launch -- a generator block needs both of its input and
  * they are independent.  H % 4 == 0, H <= 256, 16-byte aligned operands.

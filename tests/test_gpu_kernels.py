@@ -621,6 +621,35 @@ def test_gather_story_one_launch_equals_two(cuda, preset, ragged, H):
     assert torch.equal(pq, ops.story_project_raw(p.story_seg, x, W))
 
 
+@pytest.mark.parametrize("preset,ragged,H", [("small", True, 128), ("dataset", False, 128), ("tiny", False, 64),
+                                             ("small", True, 256)])
+def test_story_backward_one_launch(cuda, preset, ragged, H):
+    """bg_story_bwd_f32 against the three steps it replaces: the leaky ReLU's backward (bit-exact: one multiply),
+    the per-story sums of it and the per-story means of v (fp64 statement; the summation order differs)."""
+    from building_gan_amd import ops
+    import copy
+    cpu = _batch(preset, 9, ragged)
+    g_, p = _plan(copy.deepcopy(cpu), cuda)
+    gen = torch.Generator().manual_seed(17)
+    g = (torch.rand(p.Nv, H, generator=gen) * 2 - 1)
+    y = (torch.rand(p.Nv, H, generator=gen) * 2 - 1)
+    y[::7] = 0.0                                                   # y == 0 takes the slope branch, as aten's does
+    v = (torch.rand(p.Nv, H, generator=gen) * 2 - 1)
+    gz, gterm, story = ops.story_bwd_raw(p.story_seg, g.to(cuda), y.to(cuda), v.to(cuda), 0.01)
+    ref = torch.ops.aten.leaky_relu_backward(g, y, 0.01, True)
+    assert torch.equal(gz.cpu(), ref)
+    vfc = cpu.voxel_floor_cluster.long()
+    S = p.S
+    sums = torch.zeros(S, H, dtype=torch.float64).index_add_(0, vfc, ref.double())
+    cnt = torch.zeros(S, dtype=torch.float64).index_add_(0, vfc, torch.ones(p.Nv, dtype=torch.float64)).clamp(min=1)
+    means = torch.zeros(S, H, dtype=torch.float64).index_add_(0, vfc, v.double()) / cnt.view(-1, 1)
+    assert float((gterm.cpu().double() - sums).abs().max()) <= 1e-5 * float(sums.abs().max())
+    assert float((story.cpu().double() - means).abs().max()) <= 1e-6
+    # and the separate launches agree with it to rounding
+    assert float((gterm - ops.spmm_raw(p.story_gather.T, gz)).abs().max()) <= 1e-5 * float(sums.abs().max())
+    assert float((story - ops.spmm_raw(p.story_mean, v.to(cuda))).abs().max()) <= 1e-6
+
+
 def test_pos_terms_and_static_columns(cuda):
     """bg_pos_terms_f32 against the scatter-mean statement (has * pos - mean_j pos_j: bit-exact, including an
     isolated voxel) and bg_d_static_cols_f32 against the concatenation it replaces."""
