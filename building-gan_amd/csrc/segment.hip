@@ -17,6 +17,8 @@ struct SpmmArgs {
     const float* add1; int64_t ld1;   // optional addends: out = rs * sum + add1 + add2
     const float* add2; int64_t ld2;
     int nt_store;                     // write the result with non-temporal stores (set by spmm_dispatch for big outputs)
+    // optional gathered addend, last in the sum: + gs(grow[i]) applied to gadd[grow[i], :]
+    const float* gadd; int64_t ldga; const int32_t* grow; const float* gscale; int gmode;
 };
 
 __device__ __forceinline__ float apply_scale(float v, float s, int mode) {
@@ -69,6 +71,16 @@ __device__ __forceinline__ void spmm_vec_body(const SpmmArgs& a, int64_t blk) {
     }
     if (a.add1) acc = bg_add4(acc, bg_ld4(a.add1 + row * a.ld1 + 4 * sub));
     if (a.add2) acc = bg_add4(acc, bg_ld4(a.add2 + row * a.ld2 + 4 * sub));
+    if (a.gadd) {
+        const int32_t r = a.grow[row];
+        float4 t = bg_ld4(a.gadd + (int64_t)r * a.ldga + 4 * sub);
+        if (a.gmode) {
+            const float s = a.gscale[r];
+            t.x = apply_scale(t.x, s, a.gmode); t.y = apply_scale(t.y, s, a.gmode);
+            t.z = apply_scale(t.z, s, a.gmode); t.w = apply_scale(t.w, s, a.gmode);
+        }
+        acc = bg_add4(acc, t);
+    }
     if (a.nt_store) {
         // a result far larger than the caches streams past them: the gathered rows keep the L2 / Infinity Cache
         typedef float v4f __attribute__((ext_vector_type(4)));
@@ -100,6 +112,12 @@ __global__ void k_spmm_scalar(SpmmArgs a, int H) {
     if (a.row_mode) acc = apply_scale(acc, a.row_scale[row], a.row_mode);
     if (a.add1) acc += a.add1[row * a.ld1 + h];
     if (a.add2) acc += a.add2[row * a.ld2 + h];
+    if (a.gadd) {
+        const int32_t r = a.grow[row];
+        float t = a.gadd[(int64_t)r * a.ldga + h];
+        if (a.gmode) t = apply_scale(t, a.gscale[r], a.gmode);
+        acc += t;
+    }
     a.out[row * a.ldo + h] = acc;
 }
 
@@ -125,7 +143,8 @@ int launch_spmm_vec(const SpmmArgs& a, hipStream_t s) {
 int spmm_dispatch(SpmmArgs a, int64_t H, hipStream_t s) {
     if (a.n_rows == 0 || H == 0) return BG_OK;
     bool vec = (H % 4 == 0) && (a.ldx % 4 == 0) && (a.ldo % 4 == 0) && bg_aligned16(a.x) && bg_aligned16(a.out) &&
-               (!a.add1 || (bg_aligned16(a.add1) && a.ld1 % 4 == 0)) && (!a.add2 || (bg_aligned16(a.add2) && a.ld2 % 4 == 0));
+               (!a.add1 || (bg_aligned16(a.add1) && a.ld1 % 4 == 0)) && (!a.add2 || (bg_aligned16(a.add2) && a.ld2 % 4 == 0)) &&
+               (!a.gadd || (bg_aligned16(a.gadd) && a.ldga % 4 == 0));
     if (!vec) {
         k_spmm_scalar<<<bg_grid_for(a.n_rows * H, 256, 0x7fffffff), 256, 0, s>>>(a, (int)H);
         BG_LAUNCH_CHECK();
@@ -141,6 +160,7 @@ int spmm_dispatch(SpmmArgs a, int64_t H, hipStream_t s) {
         p.x = a.x + h0; p.out = a.out + h0;
         if (a.add1) p.add1 = a.add1 + h0;
         if (a.add2) p.add2 = a.add2 + h0;
+        if (a.gadd) p.gadd = a.gadd + h0;
         p.H4 = (int)((H - h0 < 256 ? H - h0 : 256) / 4);
         int rc = general ? launch_spmm_vec<true>(p, s) : launch_spmm_vec<false>(p, s);
         if (rc != BG_OK) return rc;
@@ -797,14 +817,16 @@ int bg_spmm_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_
 int bg_spmm_add_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
                     const float* row_scale, int row_mode, const float* col_scale, int col_mode,
                     const float* add1, int64_t ld1, const float* add2, int64_t ld2,
+                    const float* gadd, int64_t ldga, const int32_t* grow, const float* gscale, int gmode,
                     float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream) {
     if (n_rows < 0 || H < 0) return BG_ERR_ARG;
     if (n_rows == 0 || H == 0) return BG_OK;
     if (!x || !rowptr || !out || ldx < H || ldo < H) return BG_ERR_ARG;
     if ((row_mode && !row_scale) || (col_mode && !col_scale)) return BG_ERR_ARG;
     if ((add1 && ld1 < H) || (add2 && ld2 < H)) return BG_ERR_ARG;
+    if (gadd && (!grow || ldga < H || (gmode && !gscale))) return BG_ERR_ARG;
     SpmmArgs a{x, ldx, rowptr, col, nullptr, nullptr, row_scale, row_mode, col_scale, col_mode, out, ldo, n_rows, 0,
-               add1, ld1, add2, ld2};
+               add1, ld1, add2, ld2, 0, gadd, ldga, grow, gscale, gmode};
     return spmm_dispatch(a, H, (hipStream_t)stream);
 }
 

@@ -112,8 +112,9 @@ def spmm_raw(op: LinOp, x: torch.Tensor, edge_w: Optional[torch.Tensor] = None,
     return out.view(-1) if squeeze else out
 
 
-def spmm_add_raw(op: LinOp, x: torch.Tensor, add1=None, add2=None, out=None) -> torch.Tensor:
-    """out = op(x) + add1 + add2 in one pass (short-row plans only)."""
+def spmm_add_raw(op: LinOp, x: torch.Tensor, add1=None, add2=None, out=None, gather=None) -> torch.Tensor:
+    """out = op(x) + add1 + add2 [+ gs * gadd[rows]] in one pass (short-row plans only).
+    ``gather`` = (gadd [R, H], rows int32 [n_rows], scale [R] or None, scale mode)."""
     lib = _lib.load()
     c: Csr = op.csr
     x2 = _f32c(x)
@@ -124,9 +125,21 @@ def spmm_add_raw(op: LinOp, x: torch.Tensor, add1=None, add2=None, out=None) -> 
         out = torch.empty(c.n_rows, H, dtype=torch.float32, device=x.device)
     a1 = _f32c(add1) if add1 is not None else None
     a2 = _f32c(add2) if add2 is not None else None
+    ga = grow = gs = None
+    gmode = SCALE_NONE
+    if gather is not None:
+        ga, grow, gs, gmode = gather
+        ga = _f32c(ga)
+        if (grow.dtype != torch.int32 or grow.numel() != c.n_rows or ga.shape[1] != H
+                or (gs is not None and gs.numel() != ga.shape[0])):
+            raise _lib.BganError("spmm_add: gathered addend does not fit the plan")
+        if gs is None:
+            gmode = SCALE_NONE
     check(lib.bg_spmm_add_f32(ptr(x2), _ld(x2), ptr(c.rowptr), ptr(c.col), ptr(op.row_scale), op.row_mode,
                               ptr(op.col_scale), op.col_mode, ptr(a1), _ld(a1) if a1 is not None else 0,
-                              ptr(a2), _ld(a2) if a2 is not None else 0, ptr(out), _ld(out), c.n_rows, H, stream()),
+                              ptr(a2), _ld(a2) if a2 is not None else 0,
+                              ptr(ga), _ld(ga) if ga is not None else 0, ptr(grow), ptr(gs), gmode,
+                              ptr(out), _ld(out), c.n_rows, H, stream()),
           "bg_spmm_add_f32")
     return out
 
@@ -1015,8 +1028,10 @@ class GBlock(torch.autograd.Function):
             gx = gemm_raw([gz], Wc[:, :2 * H], False, False)                      # [N, 2H]: to v | to A v
             gsb = gemm_raw([gterm], Wsb, False, False)                            # [S, 2H]: to story | to building
             g_story = spmm_add_raw(sbm, gsb[:, H:], gsb[:, :H])
-            t1 = spmm_add_raw(plan.vox_mean.T, gx[:, H:], g, gx[:, :H])
-            gv = spmm_add_raw(plan.story_mean.T, g_story, t1)
+            # g + gx_self + A^T gx_nbr + the voxel's share of its story's gradient (story_mean^T), one pass
+            sm = plan.story_mean
+            gv = spmm_add_raw(plan.vox_mean.T, gx[:, H:], g, gx[:, :H],
+                              gather=(g_story, plan.story_gather.csr.col, sm.row_scale, sm.row_mode))
         return gv, gWc, gbc, gWsb, None, None, None, None, None, None
 
 

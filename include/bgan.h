@@ -81,13 +81,16 @@ int bg_spmm_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_
                 const float* row_scale, int row_mode, const float* col_scale, int col_mode,
                 float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream);
 
-/* bg_spmm_f32 (without edge weights) plus up to two addend matrices fused into the store:
- * out[i,:] = rs(i) * sum_k cs(c_k) x[c_k,:] + add1[i,:] + add2[i,:]   (add1 / add2 may be NULL).
- * Used by the backward of a residual message-passing layer: g + gx_self + A^T gx_nbr in one pass.
+/* bg_spmm_f32 (without edge weights) plus up to two addend matrices and one GATHERED addend fused into the
+ * store:  out[i,:] = rs(i) * sum_k cs(c_k) x[c_k,:] + add1[i,:] + add2[i,:] + gs(grow[i]) gadd[grow[i],:]
+ * (add1 / add2 / gadd may be NULL; gs = the gmode scale by gscale[grow[i]], BG_SCALE_*; the caller keeps
+ * grow[i] inside gadd's rows).  Used by the backward of a residual message-passing layer:
+ * g + gx_self + A^T gx_nbr + (the voxel's story's share) in one pass.
  * replaces: the index_add / `+` chain autograd runs for Model/models.py:198,228 (v = v + block(v)). */
 int bg_spmm_add_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
                     const float* row_scale, int row_mode, const float* col_scale, int col_mode,
                     const float* add1, int64_t ld1, const float* add2, int64_t ld2,
+                    const float* gadd, int64_t ldga, const int32_t* grow, const float* gscale, int gmode,
                     float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream);
 
 /* n_steps applications of one BLOCK-DIAGONAL square operator in a single launch:

@@ -650,6 +650,26 @@ def test_story_backward_one_launch(cuda, preset, ragged, H):
     assert float((story - ops.spmm_raw(p.story_mean, v.to(cuda))).abs().max()) <= 1e-6
 
 
+@pytest.mark.parametrize("H", [128, 6])
+def test_spmm_add_with_gathered_addend(cuda, H):
+    """bg_spmm_add_f32's gathered addend: op(x) + add1 + add2 + gadd[rows] / scale[rows] in one launch equals the
+    plain launch followed by the gather, the division and the addition in the same order (bit-exact), on the
+    float4 path (H = 128) and on the scalar path (H = 6)."""
+    from building_gan_amd import ops
+    from building_gan_amd.plan import SCALE_DIV
+    import copy
+    g_, p = _plan(copy.deepcopy(_batch("small", 10, True)), cuda)
+    gen = torch.Generator().manual_seed(19)
+    x, a1, a2 = [(torch.rand(p.Nv, H, generator=gen) * 2 - 1).to(cuda) for _ in range(3)]
+    gs = (torch.rand(p.S, H, generator=gen) * 2 - 1).to(cuda)
+    rows, cnt = p.story_gather.csr.col, p.story_seg.count
+    base = ops.spmm_add_raw(p.vox_mean.T, x, a1, a2)
+    got = ops.spmm_add_raw(p.vox_mean.T, x, a1, a2, gather=(gs, rows, cnt, SCALE_DIV))
+    assert torch.equal(got, base + gs[rows.long()] / cnt[rows.long()].view(-1, 1))
+    got = ops.spmm_add_raw(p.vox_mean.T, x, a1, None, gather=(gs, rows, None, 0))
+    assert torch.equal(got, ops.spmm_add_raw(p.vox_mean.T, x, a1) + gs[rows.long()])
+
+
 def test_pos_terms_and_static_columns(cuda):
     """bg_pos_terms_f32 against the scatter-mean statement (has * pos - mean_j pos_j: bit-exact, including an
     isolated voxel) and bg_d_static_cols_f32 against the concatenation it replaces."""
