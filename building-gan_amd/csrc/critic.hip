@@ -196,6 +196,54 @@ __global__ void k_d_static_cols(const float* __restrict__ feat, int64_t ldf, int
     out[v * ldo + c] = val;
 }
 
+// Parameter-dependent rows of the collapsed discriminator's coefficient recurrence (ops.PolyCoefD): for the
+// du = ds + dl input columns and the 2H hidden channels [feature half | label half],
+//   x0[r, :]: r < nf: [fe_w[:, r]^T | 0];  nf <= r < nf+ML: [pe[r-nf] | 0];  r == rb = nf+ML+4: [fe_b | le_b];
+//             ds <= r < ds+nl: [0 | le_w[:, r-ds]^T];  else 0
+//   e[r, :]:  nf+ML <= r < rb: Wc[:, 4H + (r-nf-ML)]^T (the position block);  r == rb: bc;  else 0
+__global__ void k_d_coef_init(const float* __restrict__ fe_w, const float* __restrict__ fe_b,
+                              const float* __restrict__ le_w, const float* __restrict__ le_b,
+                              const float* __restrict__ pe, const float* __restrict__ Wc, int64_t ldw,
+                              const float* __restrict__ bc, int H, int nf, int nl, int ML, int ds, int du,
+                              float* __restrict__ x0, float* __restrict__ e) {
+    const int H2 = 2 * H;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= du * H2) return;
+    const int r = t / H2, c = t % H2;
+    const int rb = nf + ML + 4;
+    float xv = 0.f, ev = 0.f;
+    if (r < nf) { if (c < H) xv = fe_w[c * nf + r]; }
+    else if (r < nf + ML) { if (c < H) xv = pe[(r - nf) * H + c]; }
+    else if (r < rb) ev = Wc[(int64_t)c * ldw + 2 * H2 + (r - nf - ML)];
+    else if (r == rb) { xv = c < H ? fe_b[c] : le_b[c - H]; ev = bc[c]; }
+    else if (r >= ds && r < ds + nl) { if (c >= H) xv = le_w[(c - H) * nl + (r - ds)]; }
+    x0[t] = xv;
+    e[t] = ev;
+}
+
+// Its backward: G holds L+1 slabs (pitch `slab` floats) of [.., 2H] gradient states; slab 0 rows [0, du) are
+// d/d x0, the sum over slabs 1..L of rows [0, du) is d/d e.  Every output element is written exactly once.
+__global__ void k_d_coef_init_bwd(const float* __restrict__ G, int64_t slab, int L, int H, int nf, int nl, int ML,
+                                  int ds, int du, float* __restrict__ g_fe_w, float* __restrict__ g_fe_b,
+                                  float* __restrict__ g_le_w, float* __restrict__ g_le_b,
+                                  float* __restrict__ gw_tail, int64_t ldw, float* __restrict__ g_bc) {
+    const int H2 = 2 * H;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= du * H2) return;
+    const int r = t / H2, c = t % H2;
+    const int rb = nf + ML + 4;
+    const float g0 = G[t];
+    if (r < nf) { if (c < H) g_fe_w[c * nf + r] = g0; }
+    else if (r == rb) { if (c < H) g_fe_b[c] = g0; else g_le_b[c - H] = g0; }
+    else if (r >= ds && r < ds + nl) { if (c >= H) g_le_w[(c - H) * nl + (r - ds)] = g0; }
+    if (r >= nf + ML && r <= rb) {
+        float s = 0.f;
+        for (int m = 1; m <= L; ++m) s = __fadd_rn(s, G[(int64_t)m * slab + t]);
+        if (r < rb) gw_tail[(int64_t)c * ldw + (r - nf - ML)] = s;
+        else g_bc[c] = s;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -286,6 +334,33 @@ int bg_d_static_cols_f32(const float* feat, int64_t ldf, int64_t nf, const int32
     if (!feat || !level || !pdm4 || !out || ldf < nf) return BG_ERR_ARG;
     k_d_static_cols<<<bg_grid_for(n * ds, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(feat, ldf, (int)nf, level, (int)ML, pdm4,
                                                                                          out, ldo, (int)ds, n);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_d_coef_init_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b, const float* pe,
+                       const float* Wc, int64_t ldw, const float* bc, int64_t H, int64_t nf, int64_t nl, int64_t ML,
+                       int64_t ds, int64_t dl, float* x0, float* e, bgStream stream) {
+    if (H <= 0 || nf < 0 || nl < 0 || ML < 0 || ds < nf + ML + 5 || dl < nl || ldw < 4 * H + 4) return BG_ERR_ARG;
+    if (!fe_w || !fe_b || !le_w || !le_b || !pe || !Wc || !bc || !x0 || !e) return BG_ERR_ARG;
+    const int64_t n = (ds + dl) * 2 * H;
+    if (n > 0x7fffffff) return BG_ERR_SHAPE;
+    k_d_coef_init<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
+        fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, (int)H, (int)nf, (int)nl, (int)ML, (int)ds, (int)(ds + dl), x0, e);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_d_coef_init_bwd_f32(const float* G, int64_t slab, int64_t L, int64_t H, int64_t nf, int64_t nl, int64_t ML,
+                           int64_t ds, int64_t dl, float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b,
+                           float* gw_tail, int64_t ldw, float* g_bc, bgStream stream) {
+    if (H <= 0 || L < 0 || nf < 0 || nl < 0 || ML < 0 || ds < nf + ML + 5 || dl < nl || ldw < 4) return BG_ERR_ARG;
+    if (!G || !g_fe_w || !g_fe_b || !g_le_w || !g_le_b || !gw_tail || !g_bc) return BG_ERR_ARG;
+    const int64_t n = (ds + dl) * 2 * H;
+    if (n > 0x7fffffff || slab < n) return BG_ERR_SHAPE;
+    k_d_coef_init_bwd<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
+        G, slab, (int)L, (int)H, (int)nf, (int)nl, (int)ML, (int)ds, (int)(ds + dl), g_fe_w, g_fe_b, g_le_w, g_le_b,
+        gw_tail, ldw, g_bc);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

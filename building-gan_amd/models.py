@@ -36,6 +36,7 @@ FUSE_GBLOCK = True      # generator block with a graph: one autograd node with a
 SHARE_WEIGHT_GRADS = True   # the calls of one module in a forward sum their weight gradients in the producing launches
 FUSE_OUTPUT = True     # construct_output as one launch when no autograd graph is being built
 FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is being built
+FUSE_COEF_INPUTS = True   # collapsed discriminator: the recurrence's parameter rows by one launch (ops.PolyCoefD)
 COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
 
 
@@ -454,6 +455,12 @@ class VoxelGNN_D(nn.Module):
         H2 = Wc.shape[0]
         H, ML, L, du = H2 // 2, self.pe.shape[0], self.layer_num, ds + dl
         fe, le = self.feature_enc[0], self.label_enc[0]
+        if (FUSE_COEF_INPUTS and fe.weight.shape[0] == H and le.weight.shape[0] == H and Wc.shape[1] == 2 * H2 + 4
+                and fe.weight.shape[1] == n_feat):
+            # X0 / E written into the recurrence's buffers by one launch, their gradients read out by one
+            Ts, Tl = ops.PolyCoefD.apply(Wc, bc, fe.weight, fe.bias, le.weight, le.bias, self.pe, L, ds, dl
+                                         ).view(L + 1, du, H2).split([ds, dl], dim=1)
+            return torch.cat([Ts.reshape(-1, H2), Tl.reshape(-1, H2)], dim=0)
         z = lambda r, c: ops.zeros_view(r, c, device=Wc.device)     # cached zeros: no fill launches
         pad_s = ds - (n_feat + ML + 4 + 1)
         n_lab = le.weight.shape[1]

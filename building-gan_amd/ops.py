@@ -353,8 +353,8 @@ def gemm_tn_raw(A: torch.Tensor, B, out: Optional[torch.Tensor] = None, accumula
         if accumulate:
             raise _lib.BganError("gemm_tn: accumulate needs the buffer to add to")
         out = torch.empty(M, N, dtype=torch.float32, device=A.device)
-    elif tuple(out.shape) != (M, N) or not out.is_contiguous() or out.dtype != torch.float32:
-        raise _lib.BganError("gemm_tn: `out` must be a contiguous fp32 [M, N] matrix")
+    elif tuple(out.shape) != (M, N) or out.stride(1) != 1 or out.stride(0) < N or out.dtype != torch.float32:
+        raise _lib.BganError("gemm_tn: `out` must be an fp32 [M, N] matrix with contiguous rows")
     if M == 0 or N == 0:
         return out
     tiles = ((M + 63) // 64) * sum((n + 63) // 64 for n in Ns)
@@ -364,8 +364,8 @@ def gemm_tn_raw(A: torch.Tensor, B, out: Optional[torch.Tensor] = None, accumula
     pb = _PtrArr4(*([b.data_ptr() for b in Bs] + [None] * (4 - len(Bs))))
     lb = _I64Arr4(*([_ld(b) for b in Bs] + [0] * (4 - len(Bs))))
     nb = _I64Arr4(*(Ns + [0] * (4 - len(Bs))))
-    check(lib.bg_gemm_tn_splitk_f32(M, R, ptr(A2), _ld(A2), len(Bs), pb, lb, nb, ptr(out), N, ptr(partial), splits,
-                                    int(accumulate), stream()), "bg_gemm_tn_splitk_f32")
+    check(lib.bg_gemm_tn_splitk_f32(M, R, ptr(A2), _ld(A2), len(Bs), pb, lb, nb, ptr(out), out.stride(0), ptr(partial),
+                                    splits, int(accumulate), stream()), "bg_gemm_tn_splitk_f32")
     return out
 
 
@@ -1361,3 +1361,74 @@ class PolyCoef(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             gE = Gall[1:L + 1, :du].sum(dim=0)
         return gW, gX0, gE, None
+
+
+class PolyCoefD(torch.autograd.Function):
+    """PolyCoef with its inputs built from the discriminator's parameters inside the node: X0 (how the input
+    columns enter v_0 through feature_enc / pe / label_enc) and E (the position block of Wc and the bias, added
+    by every layer) are written straight into the recurrence's buffers by one launch (bg_d_coef_init_f32), and
+    the backward hands the parameters their gradients from one launch (bg_d_coef_init_bwd_f32) -- instead of
+    ~10 cat / transpose / copy launches forward and as many slice / add launches backward.
+
+    Wc [2H, 4H+4], bc [2H]; fe_w [H, nf], fe_b [H]; le_w [H, nl], le_b [H]; pe [ML, H] (no gradient).
+    Returns X^L [(L+1)*(ds+dl), 2H] as PolyCoef does."""
+
+    @staticmethod
+    def forward(ctx, Wc, bc, fe_w, fe_b, le_w, le_b, pe, L: int, ds: int, dl: int):
+        lib = _lib.load()
+        _lib.require_device(Wc, "PolyCoefD")
+        H2 = Wc.shape[0]
+        H, nf, nl, ML = H2 // 2, fe_w.shape[1], le_w.shape[1], pe.shape[0]
+        if (H2 != 2 * H or Wc.shape[1] != 2 * H2 + 4 or fe_w.shape[0] != H or le_w.shape[0] != H or pe.shape[1] != H
+                or ds < nf + ML + 5 or dl < nl):
+            raise _lib.BganError("PolyCoefD: parameter shapes do not fit the collapsed discriminator")
+        du = ds + dl
+        N = (L + 1) * du
+        S = N + du
+        dev = Wc.device
+        buf = torch.zeros((L + 1) * S * H2 + N * H2, dtype=torch.float32, device=dev)     # one fill for both
+        Xall = buf[:(L + 1) * S * H2].view(L + 1, S, H2)
+        Efull = buf[(L + 1) * S * H2:].view(N, H2)
+        Wc2, args = _f32c(Wc), [_f32c(t).contiguous() for t in (fe_w, fe_b, le_w, le_b, pe, bc)]
+        check(lib.bg_d_coef_init_f32(ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(args[4]), ptr(Wc2),
+                                     _ld(Wc2), ptr(args[5]), H, nf, nl, ML, ds, dl, ptr(Xall[0, du:2 * du]),
+                                     ptr(Efull[:du]), stream()), "bg_d_coef_init_f32")
+        W2 = Wc2[:, :2 * H2]
+        for m in range(L):
+            rows = min(N, (m + 2) * du)               # blocks above m+1 are still zero
+            cur = Xall[m]
+            gemm_raw([cur[du:du + rows], cur[:rows]], W2, False, True, residual=cur[du:du + rows],
+                     pre_add=Efull[:rows], out=Xall[m + 1, du:du + rows])
+        ctx.dims = (L, du, ds, dl, H, nf, nl, ML)
+        ctx.save_for_backward(Xall, Wc2)
+        return Xall[L, du:]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        Xall, Wc = ctx.saved_tensors
+        L, du, ds, dl, H, nf, nl, ML = ctx.dims
+        H2 = 2 * H
+        N = (L + 1) * du
+        S = N + du
+        dev = g.device
+        Gall = torch.zeros(L + 1, S, H2, dtype=torch.float32, device=dev)
+        Gall[L, :N].copy_(g)
+        Wab = torch.cat([Wc[:, :H2], Wc[:, H2:2 * H2]], dim=0)       # [2*H2, H2]: G Wa + shiftup(G) Wb
+        for m in range(L - 1, -1, -1):
+            nxt = Gall[m + 1]
+            gemm_raw([nxt[:N], nxt[du:du + N]], Wab, False, False, residual=nxt[:N], out=Gall[m, :N])
+        gW = torch.empty(H2, 2 * H2 + 4, dtype=torch.float32, device=dev)
+        Gf = Gall[1:L + 1].reshape(L * S, H2)
+        Xf = Xall.view((L + 1) * S, H2)
+        gemm_tn_raw(Gf, [Xf[du:du + L * S], Xf[:L * S]], out=gW[:, :2 * H2])
+        g_fe_w = torch.empty(H, nf, dtype=torch.float32, device=dev)
+        g_le_w = torch.empty(H, nl, dtype=torch.float32, device=dev)
+        g_fe_b = torch.empty(H, dtype=torch.float32, device=dev)
+        g_le_b = torch.empty(H, dtype=torch.float32, device=dev)
+        g_bc = torch.empty(H2, dtype=torch.float32, device=dev)
+        check(lib.bg_d_coef_init_bwd_f32(ptr(Gall), S * H2, L, H, nf, nl, ML, ds, dl, ptr(g_fe_w), ptr(g_fe_b),
+                                         ptr(g_le_w), ptr(g_le_b), gW.data_ptr() + 4 * 2 * H2, 2 * H2 + 4, ptr(g_bc),
+                                         stream()), "bg_d_coef_init_bwd_f32")
+        return gW, g_bc, g_fe_w, g_fe_b, g_le_w, g_le_b, None, None, None, None

@@ -63,6 +63,32 @@ class FlatAdam:
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + p.numel()].view_as(p)
 
+    def detach_grads(self):
+        """Before a backward pass whose gradients ``collect`` will gather: with ``.grad`` unset autograd hands
+        every parameter its gradient tensor as is, instead of one add launch per parameter into the views of a
+        freshly zeroed flat buffer."""
+        for p in self.params:
+            p.grad = None
+
+    def collect(self):
+        """All parameter gradients into the flat buffer by ONE concatenation (pads and parameters without a
+        gradient read a cached zero block); ``.grad`` is a view of the flat buffer again afterwards."""
+        dev = self.grad.device
+        pieces = []
+        end = 0
+        for p, off in zip(self.params, self.offsets):
+            if off > end:
+                pieces.append(ops.zeros_view(off - end, device=dev))
+            g = p.grad
+            pieces.append(g.detach().reshape(-1) if g is not None else ops.zeros_view(p.numel(), device=dev))
+            end = off + p.numel()
+        if self.grad.numel() > end:
+            pieces.append(ops.zeros_view(self.grad.numel() - end, device=dev))
+        with torch.no_grad():
+            torch.cat(pieces, out=self.grad)
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.grad[off:off + p.numel()].view_as(p)
+
     def all_reduce(self, group=None):
         if _world(group) > 1:
             if self.grad.is_cuda and dist.get_backend(group) == "gloo":
@@ -222,7 +248,7 @@ class Trainer:
             plan.begin_iteration()
         for p in self.opt_d.params:
             p.requires_grad = True
-        self.opt_d.zero_grad()
+        self.opt_d.detach_grads()
         if program_z is None:
             program_z = torch.rand(batch.program_class_feature.shape[0], self.noise_dim, device=dev)
         if voxel_z is None and getattr(getattr(G, "voxelGNN", None), "noise_dim", 1) != 0:
@@ -286,6 +312,7 @@ class Trainer:
                 d_loss = d_loss + self.gp_lambda * gp
                 stats["gp"] = gp.detach()
             d_loss.backward()
+            self.opt_d.collect()
             stats["d_loss"] = d_loss.detach()
         return gen, stats
 
@@ -295,12 +322,13 @@ class Trainer:
         out, soft_out, mask, att, _ = gen
         for p in self.opt_d.params:
             p.requires_grad = False
-        self.opt_g.zero_grad()
+        self.opt_g.detach_grads()
         val_b, val_s = self.discriminator(batch, out)
         # get_program_ratio runs in every G step although its losses have zero weight (losses.py:65)
         self.g_loss_fn((val_b, val_s), batch, att["hard"], mask["hard"], 6)
         g_loss = self._g_adversarial(val_b, val_s, Bg, Sg)
         g_loss.backward()
+        self.opt_g.collect()
         return {"g_loss": g_loss.detach()}
 
     # ------------------------------------------------------------------ eager iteration

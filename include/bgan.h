@@ -285,6 +285,25 @@ int bg_pos_terms_f32(const float* pos, int64_t ldp, const int32_t* rowptr, const
 int bg_d_static_cols_f32(const float* feat, int64_t ldf, int64_t nf, const int32_t* level, int64_t ML, const float* pdm4,
                          float* out, int64_t ldo, int64_t ds, int64_t n, bgStream stream);
 
+/* The parameter-dependent rows of the collapsed discriminator's coefficient recurrence (ops.PolyCoefD), H = the
+ * width of each encoder (hidden state [feature half | label half] = 2H channels), du = ds + dl input columns:
+ *   x0[r, :] (how input column r enters v_0): r < nf: [fe_w[:, r]^T | 0];  nf <= r < nf+ML: [pe[r-nf] | 0];
+ *             r == rb = nf+ML+4: [fe_b | le_b];  ds <= r < ds+nl: [0 | le_w[:, r-ds]^T];  else 0
+ *   e[r, :] (what every layer adds): nf+ML <= r < rb: Wc[:, 4H + (r-nf-ML)]^T;  r == rb: bc;  else 0
+ * x0, e: [du, 2H] contiguous; fe_w [H, nf], le_w [H, nl], pe [ML, H] contiguous; Wc [2H, >= 4H+4] pitch ldw.
+ * replaces: feature_enc / label_enc / pe[level] and the position + bias terms of a VoxelBlock as linear maps
+ * of the input columns, Model/models.py:221-228 (a dozen cat / transpose / copy launches).              */
+int bg_d_coef_init_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b, const float* pe,
+                       const float* Wc, int64_t ldw, const float* bc, int64_t H, int64_t nf, int64_t nl, int64_t ML,
+                       int64_t ds, int64_t dl, float* x0, float* e, bgStream stream);
+
+/* Backward of bg_d_coef_init_f32: G = L+1 slabs (pitch `slab` floats) of gradient states [.., 2H]; rows [0, du)
+ * of slab 0 are d/d x0, the sum over slabs 1..L of rows [0, du) is d/d e.  Writes the gradients of fe_w, fe_b,
+ * le_w, le_b (contiguous), of Wc's position block (gw_tail = &gWc[0, 4H], pitch ldw) and of bc.           */
+int bg_d_coef_init_bwd_f32(const float* G, int64_t slab, int64_t L, int64_t H, int64_t nf, int64_t nl, int64_t ML,
+                           int64_t ds, int64_t dl, float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b,
+                           float* gw_tail, int64_t ldw, float* g_bc, bgStream stream);
+
 /* WGAN-GP critic objective in two launches:
  *   loss[0] = <val_b, wb> + <val_s, ws> + coef * sum_r (||grads[r, 0:W]|| - 1)^2 ,  r < n_rows
  * (wb / ws carry the -+1/count weights of the real / fake means; grads may be NULL with n_rows = 0);

@@ -478,3 +478,32 @@ def test_shared_weight_gradient_buffers_equal_autograd_sums(cuda):
     for (n, _), a, b in zip(Gh.named_parameters(), res[True], res[False]):
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-5 * scale, n
+
+
+def test_coefficient_inputs_by_one_launch_equal_cat_construction(cuda):
+    """ops.PolyCoefD (X0 / E written into the recurrence's buffers by bg_d_coef_init_f32, parameter gradients
+    read out by bg_d_coef_init_bwd_f32) against the cat / transpose construction feeding ops.PolyCoef: the
+    collapsed weight bit for bit, every discriminator gradient to fp32 rounding (the sum over the layers'
+    slabs runs in a different order)."""
+    from building_gan_amd import models as hm
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 54, True, cuda)
+    res = {}
+    for fused in (True, False):
+        hm.FUSE_COEF_INPUTS = fused
+        try:
+            for p in Dh.parameters():
+                p.grad = None
+            W = Dh.voxelGNN_D.coefficients(gpu.voxel_feature.shape[1] - 3, 32, 8)
+            lab = gpu.voxel_label.clone().requires_grad_(True)
+            b, s = Dh(gpu, lab)
+            (b.sum() + 2 * s.sum()).backward()
+            res[fused] = [W.detach().clone(), b.detach(), s.detach(), lab.grad] + \
+                         [p.grad.clone() for p in Dh.parameters()]
+        finally:
+            hm.FUSE_COEF_INPUTS = True
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+    names = ["W", "b", "s", "dlabel"] + [n for n, _ in Dh.named_parameters()]
+    for n, a, r in zip(names, res[True], res[False]):
+        scale = float(r.abs().max()) + 1e-12
+        assert float((a - r).abs().max()) <= 2e-5 * scale, n
