@@ -368,6 +368,20 @@ __global__ void k_scatter_arg(const float* __restrict__ g, int64_t ldg, const in
     if (a >= 0) out[(int64_t)a * ldo + h] = g[s * ldg + h];
 }
 
+// The same result written row by row when every row knows its segment (seg_of[r], -1 = none): no zero fill,
+// no scatter -- out[r, h] = (arg[seg_of[r], h] == r) ? g[seg_of[r], h] : 0.
+__global__ void k_scatter_arg_dense(const float* __restrict__ g, int64_t ldg, const int32_t* __restrict__ arg,
+                                    const int32_t* __restrict__ seg_of, float* __restrict__ out, int64_t ldo,
+                                    int64_t n_rows, int H) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * H) return;
+    int64_t r = t / H; int h = (int)(t % H);
+    const int32_t s = seg_of[r];
+    float v = 0.f;
+    if (s >= 0 && arg[(int64_t)s * H + h] == (int32_t)r) v = g[(int64_t)s * ldg + h];
+    out[r * ldo + h] = v;
+}
+
 // one wave per row; 64/LPR slots in flight, LPR lanes per dot product (float4 per lane per step)
 template <int LPR>
 __global__ __launch_bounds__(256) void k_sddmm(const float* __restrict__ A, int64_t lda,
@@ -922,12 +936,17 @@ int bg_gather_arg_f32(const float* x, int64_t ldx, const int32_t* arg, float* ou
     return BG_OK;
 }
 
-int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, float* out, int64_t ldo,
+int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, const int32_t* seg_of, float* out, int64_t ldo,
                        int64_t n_seg, int64_t n_rows, int64_t H, bgStream stream) {
     if (n_seg < 0 || H < 0 || n_rows < 0) return BG_ERR_ARG;
     if (n_rows == 0 || H == 0) return BG_OK;
     if (!out || ldo < H || (n_seg > 0 && (!g || !arg))) return BG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (seg_of && n_seg > 0) {          // one launch: every row looks its own value up
+        k_scatter_arg_dense<<<bg_grid_for(n_rows * H, 256, 0x7fffffff), 256, 0, s>>>(g, ldg, arg, seg_of, out, ldo, n_rows, (int)H);
+        BG_LAUNCH_CHECK();
+        return BG_OK;
+    }
     if (ldo == H) {
         BG_HIP(hipMemsetAsync(out, 0, sizeof(float) * n_rows * H, s));
     } else {

@@ -298,7 +298,8 @@ class VoxelBlock(nn.Module):
         # split / one cat per result: each is ONE autograd node (a slice would cost a zero-fill + add in backward)
         parts = Wu.split(H, dim=1)
         P, pb, _ = ops.MatMul.apply(parts[1], Wm_ext, False, False).split([2 * H + 4, 1, 3], dim=1)   # Wu2 @ [Wm | 0 | bm]
-        Wc = P + F.pad(parts[0], (0, H + 4))
+        Wc = P + torch.cat([parts[0], ops.zeros_view(parts[0].shape[0], P.shape[1] - parts[0].shape[1],
+                                                     device=P.device)], dim=1)      # (F.pad: a fill and a copy)
         bc = pb.view(-1) + bu
         if self.if_agg_story_in_update:
             return Wc, bc, torch.cat([parts[2] - parts[3], parts[3]], dim=1)
@@ -449,6 +450,23 @@ class VoxelGNN_D(nn.Module):
             self._coef_cache = (key, W)
         return W
 
+    def _coef_row_order(self, L, ds, dl, device) -> LinOp:
+        key = (L, ds, dl, str(device))
+        cache = self.__dict__.setdefault("_row_order", {})
+        op = cache.get(key)
+        if op is None:
+            from .plan import Csr
+            du, n = ds + dl, (L + 1) * (ds + dl)
+            k = torch.arange(L + 1).view(-1, 1) * du
+            src = torch.cat([(k + torch.arange(ds)).reshape(-1), (k + ds + torch.arange(dl)).reshape(-1)])
+            inv = torch.empty(n, dtype=torch.int64)
+            inv[src] = torch.arange(n)
+            rowptr = torch.arange(n + 1, dtype=torch.int32, device=device)
+            op = LinOp.pair(Csr(rowptr, src.to(torch.int32).to(device), None, n, n, n),
+                            Csr(rowptr, inv.to(torch.int32).to(device), None, n, n, n))
+            cache[key] = op
+        return op
+
     def _collapsed_weight(self, composed, n_feat, ds, dl):
         """W [(L+1)*ds + (L+1)*dl, 2H] such that v_L = [Zs | Zl] W (rows ordered (k, input column))."""
         Wc, bc = composed[0], composed[1]
@@ -458,9 +476,10 @@ class VoxelGNN_D(nn.Module):
         if (FUSE_COEF_INPUTS and fe.weight.shape[0] == H and le.weight.shape[0] == H and Wc.shape[1] == 2 * H2 + 4
                 and fe.weight.shape[1] == n_feat):
             # X0 / E written into the recurrence's buffers by one launch, their gradients read out by one
-            Ts, Tl = ops.PolyCoefD.apply(Wc, bc, fe.weight, fe.bias, le.weight, le.bias, self.pe, L, ds, dl
-                                         ).view(L + 1, du, H2).split([ds, dl], dim=1)
-            return torch.cat([Ts.reshape(-1, H2), Tl.reshape(-1, H2)], dim=0)
+            XL = ops.PolyCoefD.apply(Wc, bc, fe.weight, fe.bias, le.weight, le.bias, self.pe, L, ds, dl)
+            # rows (k, column) -> all static columns first, then all label columns: a row permutation as one
+            # gather launch (its backward: the inverse gather) instead of split / two reshape copies / cat
+            return SpMM.apply(XL, self._coef_row_order(L, ds, dl, XL.device))
         z = lambda r, c: ops.zeros_view(r, c, device=Wc.device)     # cached zeros: no fill launches
         pad_s = ds - (n_feat + ML + 4 + 1)
         n_lab = le.weight.shape[1]
@@ -619,7 +638,8 @@ class DiscriminatorVoxel(nn.Module):
             hat_s, arg_s = ops.segmax_raw(plan.story_seg, vs[2])
             if plan.stories_all_nonempty:
                 hat_b, arg_sb = ops.segmax_raw(plan.story_graph_seg, hat_s)       # arg-max story of each graph ..
-                arg_b = ops.gather_arg_raw(arg_s.float(), arg_sb).to(torch.int32)  # .. and that story's arg-max voxel
+                # .. and that story's arg-max voxel: the int32 indices travel through the gather as raw bits
+                arg_b = ops.gather_arg_raw(arg_s.view(torch.float32), arg_sb).view(torch.int32)
             else:
                 hat_b, arg_b = ops.segmax_raw(plan.graph_seg, vs[2])
         gpools = []
@@ -628,7 +648,8 @@ class DiscriminatorVoxel(nn.Module):
             with ops.input_grads_only():
                 val = run_mlp(dec, pooled)
             gpools.append(torch.autograd.grad(val, pooled, torch.ones_like(val), create_graph=True)[0])
-        G2 = ops.ScatterArgPair.apply(gpools[0], arg_b, gpools[1], arg_s, N)       # [2N, 2H]: building rows first
+        G2 = ops.ScatterArgPair.apply(gpools[0], arg_b, gpools[1], arg_s, N,       # [2N, 2H]: building rows first
+                                      plan.graph_seg.seg_of, plan.story_seg.seg_of)
         X = ops.MatMul.apply(G2, Wl, False, True)                                  # [2N, (L+1)*dl]
         # sum_k (A^T)^k Y_k over both outputs' columns side by side: one launch on block-diagonal plans
         Ys = X.view(2, N, L + 1, dl).permute(1, 2, 0, 3).reshape(N, L + 1, 2 * dl)

@@ -187,13 +187,18 @@ def gather_arg_raw(x: torch.Tensor, arg: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def scatter_arg_raw(g: torch.Tensor, arg: torch.Tensor, n_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def scatter_arg_raw(g: torch.Tensor, arg: torch.Tensor, n_rows: int, out: Optional[torch.Tensor] = None,
+                    seg_of: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[arg[s, h], h] = g[s, h], zero elsewhere.  ``seg_of`` (int32 [n_rows], the segment of every row; the
+    pooling plans carry it as Csr.seg_of): one launch instead of a zero fill + scatter."""
     lib = _lib.load()
     g2 = _f32c(g)
     S, H = arg.shape
     if out is None:
         out = torch.empty(n_rows, H, dtype=torch.float32, device=g.device)
-    check(lib.bg_scatter_arg_f32(ptr(g2), _ld(g2), ptr(arg), ptr(out), H, S, n_rows, H, stream()),
+    if seg_of is not None and (seg_of.dtype != torch.int32 or seg_of.numel() != n_rows or not arg.is_contiguous()):
+        raise _lib.BganError("scatter_arg: seg_of must be int32 [n_rows] and arg contiguous")
+    check(lib.bg_scatter_arg_f32(ptr(g2), _ld(g2), ptr(arg), ptr(seg_of), ptr(out), H, S, n_rows, H, stream()),
           "bg_scatter_arg_f32")
     return out
 
@@ -639,58 +644,66 @@ class SegMax(torch.autograd.Function):
     def forward(ctx, x, csr: Csr):
         out, arg = segmax_raw(csr, x)
         ctx.n_rows = x.shape[0]
+        ctx.seg_of = csr.seg_of
         ctx.save_for_backward(arg)
         ctx.mark_non_differentiable(arg)
+        ctx.set_materialize_grads(False)       # no zero int tensor for the arg output's absent gradient
         return out, arg
 
     @staticmethod
     def backward(ctx, g, _garg):
         (arg,) = ctx.saved_tensors
-        return ScatterArg.apply(g, arg, ctx.n_rows), None
+        if g is None:
+            return None, None
+        return ScatterArg.apply(g, arg, ctx.n_rows, ctx.seg_of), None
 
 
 class ScatterArg(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, g, arg, n_rows):
+    def forward(ctx, g, arg, n_rows, seg_of=None):
         ctx.save_for_backward(arg)
-        return scatter_arg_raw(g, arg, n_rows)
+        ctx.seg_of = seg_of
+        return scatter_arg_raw(g, arg, n_rows, seg_of=seg_of)
 
     @staticmethod
     def backward(ctx, gg):
         (arg,) = ctx.saved_tensors
-        return GatherArg.apply(gg, arg), None, None
+        return GatherArg.apply(gg, arg, ctx.seg_of), None, None, None
 
 
 class ScatterArgPair(torch.autograd.Function):
     """[scatter(g1, arg1); scatter(g2, arg2)] stacked into one [2 * n_rows, H] matrix (no concatenation)."""
 
     @staticmethod
-    def forward(ctx, g1, arg1, g2, arg2, n_rows):
+    def forward(ctx, g1, arg1, g2, arg2, n_rows, seg_of1=None, seg_of2=None):
         ctx.n_rows = n_rows
+        ctx.seg = (seg_of1, seg_of2)
         ctx.save_for_backward(arg1, arg2)
         out = torch.empty(2 * n_rows, arg1.shape[1], dtype=torch.float32, device=g1.device)
-        scatter_arg_raw(g1, arg1, n_rows, out=out[:n_rows])
-        scatter_arg_raw(g2, arg2, n_rows, out=out[n_rows:])
+        scatter_arg_raw(g1, arg1, n_rows, out=out[:n_rows], seg_of=seg_of1)
+        scatter_arg_raw(g2, arg2, n_rows, out=out[n_rows:], seg_of=seg_of2)
         return out
 
     @staticmethod
     def backward(ctx, gg):
         arg1, arg2 = ctx.saved_tensors
         n = ctx.n_rows
-        return GatherArg.apply(gg[:n], arg1), None, GatherArg.apply(gg[n:], arg2), None, None
+        return (GatherArg.apply(gg[:n], arg1, ctx.seg[0]), None, GatherArg.apply(gg[n:], arg2, ctx.seg[1]), None, None,
+                None, None)
 
 
 class GatherArg(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, arg):
+    def forward(ctx, x, arg, seg_of=None):
         ctx.n_rows = x.shape[0]
+        ctx.seg_of = seg_of
         ctx.save_for_backward(arg)
         return gather_arg_raw(x, arg)
 
     @staticmethod
     def backward(ctx, g):
         (arg,) = ctx.saved_tensors
-        return ScatterArg.apply(g, arg, ctx.n_rows), None
+        return ScatterArg.apply(g, arg, ctx.n_rows, ctx.seg_of), None, None
 
 
 # ------------------------------------------------------------------------------- attention ops

@@ -35,6 +35,7 @@ class Csr:
     rows_per_chunk: int = 0
     n_chunks_ub: int = 0
     max_len: int = 0                           # longest segment (known for chunked CSRs after the plan's sync)
+    seg_of: Optional[torch.Tensor] = None      # int32 [n_cols]: the segment of every row, where the segments partition the rows
 
     @property
     def long_rows(self) -> bool:
@@ -229,6 +230,7 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     b.maybe_chunks(gr, force=True)
     gr_gather = b.gather_csr(vbi.to(torch.int32), B)
     o["graph_gather"] = LinOp.pair(gr_gather, gr)
+    st.seg_of, gr.seg_of = st_gather.col, gr_gather.col        # voxel -> story / graph (int32 [Nv])
     o["story_seg"], o["graph_seg"] = st, gr
     # graph id of a story = graph of (any) member voxel, as avg_pool_x's batch[perm]
     story_graph = torch.zeros(S, dtype=torch.int64, device=dev)
@@ -239,6 +241,7 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     # the mean over a graph's few stories keeps the one-launch short-row path
     sgr_seg = dataclasses.replace(sgr)
     b.maybe_chunks(sgr_seg, force=True)
+    sgr_seg.seg_of = story_graph.to(torch.int32)               # story -> graph
     o["story_graph_seg"] = sgr_seg
     sgr_gather = b.gather_csr(story_graph.to(torch.int32), B)
     o["graph_of_story_mean"] = LinOp.pair(sgr, sgr_gather, sgr.count, SCALE_DIV)

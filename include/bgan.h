@@ -174,8 +174,10 @@ int bg_gather_arg_f32(const float* x, int64_t ldx, const int32_t* arg, float* ou
                       int64_t n_seg, int64_t H, bgStream stream);
 
 /* out (n_rows x H, zero-filled here) ; out[arg[s,h], h] = g[s,h] where arg >= 0.
+ * seg_of (may be NULL): int32 [n_rows], the segment every row belongs to (-1: none; every arg[s,h] must then be
+ * a row of segment s): the same result in ONE launch, each row looking up its own value -- no fill, no scatter.
  * replaces: torch_scatter.scatter_max backward (gradient to the arg element only).          */
-int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, float* out, int64_t ldo,
+int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, const int32_t* seg_of, float* out, int64_t ldo,
                        int64_t n_seg, int64_t n_rows, int64_t H, bgStream stream);
 
 /* out[k] = dot(a[r_k,:], b[c_k,:]) for every CSR slot k (r_k = the row owning slot k),

@@ -670,6 +670,24 @@ def test_spmm_add_with_gathered_addend(cuda, H):
     assert torch.equal(got, ops.spmm_add_raw(p.vox_mean.T, x, a1) + gs[rows.long()])
 
 
+def test_scatter_arg_row_lookup_equals_fill_and_scatter(cuda):
+    """bg_scatter_arg_f32 with the rows' segment ids (one launch, every row looks its value up) against the zero
+    fill + scatter form, for the voxel -> story, voxel -> graph and story -> graph pooling plans: identical."""
+    from building_gan_amd import ops
+    import copy
+    g_, p = _plan(copy.deepcopy(_batch("small", 11, True)), cuda)
+    gen = torch.Generator().manual_seed(23)
+    H = 64
+    for csr, n in ((p.story_seg, p.Nv), (p.graph_seg, p.Nv), (p.story_graph_seg, p.S)):
+        assert csr.seg_of is not None and csr.seg_of.numel() == n
+        x = (torch.rand(n, H, generator=gen) * 2 - 1).to(cuda)
+        _, arg = ops.segmax_raw(csr, x)
+        g = (torch.rand(csr.n_rows, H, generator=gen) * 2 - 1).to(cuda)
+        want = ops.scatter_arg_raw(g, arg, n)
+        assert torch.equal(ops.scatter_arg_raw(g, arg, n, seg_of=csr.seg_of), want)
+        assert float(want.abs().sum()) > 0
+
+
 def test_pos_terms_and_static_columns(cuda):
     """bg_pos_terms_f32 against the scatter-mean statement (has * pos - mean_j pos_j: bit-exact, including an
     isolated voxel) and bg_d_static_cols_f32 against the concatenation it replaces."""
