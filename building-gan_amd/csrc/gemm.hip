@@ -27,6 +27,7 @@ struct GemmArgs {
     const float* residual; int64_t ldr;
     const float* pre_add; int64_t ldp;
     const int32_t* pre_rows;   // optional: pre_add row of output row i is pre_rows[i] (a fused gather)
+    const float* acc0; int64_t ld0;   // optional: the accumulators start from acc0[i, j] instead of zero (k_gemm only)
     int64_t M, N;
     int total_steps;      // sum over segments of ceil(K_s / BK)
     int steps_per_split;  // == total_steps when not split
@@ -248,6 +249,21 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    if (!SPLIT && g.acc0) {
+        // C = acc0 + A B: the addend is loaded straight into the accumulator registers (no extra registers, and
+        // the loads travel with the first operand tile's) -- a K-independent term costs no K step this way
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int64_t col = n0 + (wn * TN + j) * 32 + r;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int64_t row = m0 + (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    if (row < g.M && col < g.N) acc[i][j][q] = g.acc0[row * g.ld0 + col];
+                }
+            }
+    }
 
     Stage<BM, A_KC, VEC, BK> sa;
     Stage<BN, B_KC, VEC, BK> sb;
@@ -821,12 +837,13 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
                 const float* B, int64_t ldb, float* C, int64_t ldc,
                 const float* bias, const float* row_scale, int act, float slope,
                 const float* residual, int64_t ldr, const float* pre_add, int64_t ldp,
-                const int32_t* pre_add_rows, bgStream stream) {
+                const int32_t* pre_add_rows, const float* acc_init, int64_t ld_acc, bgStream stream) {
     if (M < 0 || N < 0 || n_seg < 1 || n_seg > 4 || !A || !lda || !Ks) return BG_ERR_ARG;
     if (M == 0 || N == 0) return BG_OK;
-    if (!B || !C || ldc < N || (residual && ldr < N) || (pre_add && ldp < N)) return BG_ERR_ARG;
+    if (!B || !C || ldc < N || (residual && ldr < N) || (pre_add && ldp < N) || (acc_init && ld_acc < N)) return BG_ERR_ARG;
     GemmArgs g{};
     g.n_seg = n_seg;
+    g.acc0 = acc_init; g.ld0 = ld_acc;
     g.pre_add = pre_add; g.ldp = ldp; g.pre_rows = pre_add ? pre_add_rows : nullptr;
     int tile = tile_override();
     if (tile == 0) {
@@ -842,7 +859,7 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
     int bk = tile == 0 ? 64 : 32;
     if (tile == 0 && bk_override()) bk = bk_override();
     // LDS-DMA ring kernel: K-contiguous A on the vector path (decided below), 64x64 tiles
-    int dma = (tile == 0 && !transA && M >= 1 && N >= 4) ? dma_mode() : 0;
+    int dma = (tile == 0 && !transA && M >= 1 && N >= 4 && !acc_init) ? dma_mode() : 0;
     if (dma == 1) {
         // measured on the train step's shapes (tools/gemm_shapes.py): with >= 2 workgroups per CU the
         // register-free ring wins (33 vs 38 us at 720 tiles), below that the 64-deep register-staged
@@ -875,7 +892,7 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
     hipStream_t st = (hipStream_t)stream;
     // few tiles and a moderate K: one 32x32 tile per workgroup, K split over its waves (needs the
     // 16-byte path on A; B is read by 16-byte chunks when K-contiguous, by dwords otherwise)
-    if (tile_override() == 0 && !transA && vec && skinny_mode() && Ktot <= 4096 &&
+    if (tile_override() == 0 && !transA && vec && skinny_mode() && Ktot <= 4096 && !acc_init &&
         ((M + 31) / 32) * ((N + 31) / 32) <= skinny_max_tiles()) {
         bool nonempty = true;
         for (int s = 0; s < n_seg; ++s) nonempty = nonempty && Ks[s] > 0;

@@ -36,6 +36,7 @@ FUSE_GBLOCK = True      # generator block with a graph: one autograd node with a
 SHARE_WEIGHT_GRADS = True   # the calls of one module in a forward sum their weight gradients in the producing launches
 FUSE_OUTPUT = True     # construct_output as one launch when no autograd graph is being built
 FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is being built
+FUSE_POS_TERM = True      # generator: position columns x weight + bias once per forward, the 12 products start from it
 FUSE_COEF_INPUTS = True   # collapsed discriminator: the recurrence's parameter rows by one launch (ops.PolyCoefD)
 COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
 
@@ -305,8 +306,9 @@ class VoxelBlock(nn.Module):
             return Wc, bc, torch.cat([parts[2] - parts[3], parts[3]], dim=1)
         return Wc, bc, None
 
-    def forward_composed(self, voxel_feature, plan, pdm4, composed, grads=None):
-        """v + block(v) with the collapsed weights (valid when plan.vox_all_has).  ``grads`` as in Attention.forward."""
+    def forward_composed(self, voxel_feature, plan, pdm4, composed, grads=None, posb=None):
+        """v + block(v) with the collapsed weights (valid when plan.vox_all_has).  ``grads`` as in Attention.forward;
+        ``posb`` = ops.block_pos_term(pdm4, Wc, bc) when the caller evaluated it once for all calls of a forward."""
         Wc, bc, Wsb = composed
         H = voxel_feature.shape[1]
         if (self.if_agg_story_in_update and FUSE_STORY_TERM and not torch.is_grad_enabled()
@@ -319,13 +321,17 @@ class VoxelBlock(nn.Module):
                 gm = ops.spmm_raw(plan.vox_mean, voxel_feature)
                 pq = ops.story_project_raw(plan.story_seg, voxel_feature, Wsb)
             term = ops.spmm_add_raw(plan.story_building_mean, pq[:, H:], pq[:, :H])
+            if posb is not None:        # the product starts from the position + bias term and runs over K = 2H
+                return ops.gemm_raw([voxel_feature, gm], Wc[:, :2 * H], False, True, act=ACT_LEAKY, slope=0.01,
+                                    pre_add=term, pre_rows=plan.story_gather.csr.col, residual=voxel_feature,
+                                    acc_init=posb)
             return linear([voxel_feature, gm, pdm4], Wc, bc, ACT_LEAKY, 0.01, pre_add=term,
                           pre_gather=plan.story_gather, residual=voxel_feature)
         if (self.if_agg_story_in_update and FUSE_GBLOCK and torch.is_grad_enabled() and "story_building_mean" in plan.ops
                 and H % 4 == 0 and H <= 256 and plan.Nv <= FUSE_GATHER_STORY_MAX_ROWS):
             # a graph is being built (generator update): the whole block as one autograd node
             return ops.GBlock.apply(voxel_feature, Wc, bc, Wsb, pdm4, plan, 0.01,
-                                    *(grads if grads is not None else (None, True)), PDM4_PAD == 1.0)
+                                    *(grads if grads is not None else (None, True)), PDM4_PAD == 1.0, posb)
         gm = SpMM.apply(voxel_feature, plan.vox_mean)
         if not self.if_agg_story_in_update:
             return linear([voxel_feature, gm, pdm4], Wc, bc, residual=voxel_feature)
@@ -391,9 +397,14 @@ class VoxelGNN_G(nn.Module):
         composed = None
         if COMPOSE_BLOCKS and plan.vox_all_has:
             composed = tuple(derived[:3]) if derived is not None else self.block.compose()
+        posb = None
+        if (composed is not None and FUSE_POS_TERM and self.block.if_agg_story_in_update and plan.Nv <= FUSE_GATHER_STORY_MAX_ROWS
+                and "story_building_mean" in plan.ops and v.shape[1] % 4 == 0 and v.shape[1] <= 256):
+            # the position columns and the bias enter every one of the 12 calls alike (same module): once
+            posb = ops.block_pos_term(pdm4, composed[0], composed[1])
         for i in range(self.layer_num):
             if composed is not None:
-                v = self.block.forward_composed(v, plan, pdm4, composed, (sg, i == 0) if sg is not None else None)
+                v = self.block.forward_composed(v, plan, pdm4, composed, (sg, i == 0) if sg is not None else None, posb)
             else:
                 v = v + self.block(v, plan, pdm4)
             if i % 2 == 0 and i != 0:

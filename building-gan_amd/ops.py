@@ -289,8 +289,8 @@ def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: b
              bias: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
              act: int = ACT_NONE, slope: float = 0.01, residual: Optional[torch.Tensor] = None,
              pre_add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-             pre_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """C = epilogue(cat(A, -1 (or 0 when transA)) (x) B); see bg_gemm_f32."""
+             pre_rows: Optional[torch.Tensor] = None, acc_init: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = epilogue(acc_init + cat(A, -1 (or 0 when transA)) (x) B); see bg_gemm_f32."""
     lib = _lib.load()
     n_seg = len(A)
     if n_seg < 1 or n_seg > 4:
@@ -337,9 +337,15 @@ def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: b
         ldp = _ld(pre_add)
         if pre_rows is not None and (pre_rows.dtype != torch.int32 or pre_rows.numel() != M):
             raise _lib.BganError("gemm: pre_rows must hold one int32 row index per output row")
+    ld0 = 0
+    if acc_init is not None:
+        acc_init = _f32c(acc_init)
+        if tuple(acc_init.shape) != (M, N):
+            raise _lib.BganError("gemm: acc_init must be an [M, N] matrix")
+        ld0 = _ld(acc_init)
     check(lib.bg_gemm_f32(int(transA), int(transB), M, N, n_seg, pa, la, ka, ptr(B2), _ld(B2), ptr(out), _ld(out),
                           ptr(bias), ptr(row_scale), act, slope, ptr(residual), ldr, ptr(pre_add), ldp,
-                          ptr(pre_rows), stream()), "bg_gemm_f32")
+                          ptr(pre_rows), ptr(acc_init), ld0, stream()), "bg_gemm_f32")
     return out
 
 
@@ -982,6 +988,14 @@ class AttentionNode(torch.autograd.Function):
         return gv, g_x, db, gW, gb, dth, None, None, None, None, None, None
 
 
+def block_pos_term(pdm4: torch.Tensor, Wc: torch.Tensor, bc: torch.Tensor) -> torch.Tensor:
+    """[N, H]: pdm4 Wc[:, 2H:2H+4]^T + bc -- what the composed generator block adds in EVERY one of its calls
+    (same weights, same positions): evaluated once per forward (no autograd graph: see GBlock)."""
+    H = Wc.shape[0]
+    with torch.no_grad():
+        return gemm_raw([pdm4], Wc[:, 2 * H:2 * H + 4], False, True, bias=bc)
+
+
 class GBlock(torch.autograd.Function):
     """v + block(v) of the generator's composed VoxelBlock (models.VoxelBlock.compose) as ONE autograd node:
 
@@ -995,15 +1009,22 @@ class GBlock(torch.autograd.Function):
     (the generator is never differentiated twice)."""
 
     @staticmethod
-    def forward(ctx, v, Wc, bc, Wsb, pdm4, plan, slope: float, shared=None, first=True, ones_pad=False):
+    def forward(ctx, v, Wc, bc, Wsb, pdm4, plan, slope: float, shared=None, first=True, ones_pad=False, posb=None):
         """``ones_pad``: pdm4's last column is all ones and Wc's last column all zeros (the caller's promise), so
-        the last column of Wc's gradient IS the bias gradient and no column sum is launched."""
+        the last column of Wc's gradient IS the bias gradient and no column sum is launched.
+        ``posb`` = pdm4 Wc[:, 2H:]^T + bc (block_pos_term), the same for every call of a forward: the product
+        then starts from it and runs over K = 2H (the gradients do not change: they are taken from the
+        formula, not from how the forward evaluated it)."""
         H = v.shape[1]
         ctx.shared, ctx.first, ctx.ones_pad = shared, first, bool(ones_pad)
         gm, pq = gather_story_raw(plan.vox_mean, plan.story_seg, v, Wsb)
         term = spmm_add_raw(plan.story_building_mean, pq[:, H:], pq[:, :H])
-        y = gemm_raw([v, gm, pdm4], Wc, False, True, bias=bc, act=ACT_LEAKY, slope=slope, pre_add=term,
-                     pre_rows=plan.story_gather.csr.col)
+        if posb is not None:
+            y = gemm_raw([v, gm], Wc[:, :2 * H], False, True, act=ACT_LEAKY, slope=slope, pre_add=term,
+                         pre_rows=plan.story_gather.csr.col, acc_init=posb)
+        else:
+            y = gemm_raw([v, gm, pdm4], Wc, False, True, bias=bc, act=ACT_LEAKY, slope=slope, pre_add=term,
+                         pre_rows=plan.story_gather.csr.col)
         ctx.plan, ctx.slope = plan, slope
         ctx.save_for_backward(v, gm, y, Wc, Wsb, pdm4)
         return v + y
@@ -1045,7 +1066,7 @@ class GBlock(torch.autograd.Function):
             sm = plan.story_mean
             gv = spmm_add_raw(plan.vox_mean.T, gx[:, H:], g, gx[:, :H],
                               gather=(g_story, plan.story_gather.csr.col, sm.row_scale, sm.row_mode))
-        return gv, gWc, gbc, gWsb, None, None, None, None, None, None
+        return gv, gWc, gbc, gWsb, None, None, None, None, None, None, None
 
 
 def attention_forward_raw(a, logits, b, x, v, theta, plan, exp_mask, exp_att, tau: float, wd=None, bd=None):

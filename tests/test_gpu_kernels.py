@@ -186,6 +186,24 @@ def test_gemm_layouts(cuda, ta, tb):
     assert torch.equal(out, Bm)
 
 
+@pytest.mark.parametrize("M,N,K", [(11520, 128, 256), (300, 70, 36), (64, 64, 8)])
+def test_gemm_accumulator_start(cuda, M, N, K):
+    """bg_gemm_f32's acc_init: the product starts from a given [M, N] matrix (before bias / activation /
+    residual), against the fp64 statement; ragged edge tiles included."""
+    from building_gan_amd import ops
+    torch.manual_seed(62)
+    A = torch.rand(M, K) * 2 - 1
+    W = torch.rand(N, K) * 2 - 1
+    Q = torch.rand(M, N) * 2 - 1
+    b = torch.rand(N) * 2 - 1
+    R = torch.rand(M, N) * 2 - 1
+    out = ops.gemm_raw([A.to(cuda)], W.to(cuda), False, True, bias=b.to(cuda), act=ops.ACT_LEAKY, slope=0.01,
+                       residual=R.to(cuda), acc_init=Q.to(cuda)).cpu().double()
+    z = Q.double() + A.double() @ W.double().t() + b.double()
+    ref = torch.where(z > 0, z, 0.01 * z) + R.double()
+    assert float((out - ref).abs().max()) < 2e-5 * K ** 0.5
+
+
 def test_gemm_tn_splitk_and_colsum(cuda):
     from building_gan_amd import ops
     torch.manual_seed(6)

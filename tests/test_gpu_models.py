@@ -401,21 +401,31 @@ def test_generator_block_node_equals_op_by_op_path(cuda):
     pdm4 = hm.position_terms(gpu)
     v0 = (torch.rand(sz["Nv"], 128, device=cuda) * 2 - 1)
     gout = torch.rand(sz["Nv"], 128, device=cuda) * 2 - 1
+    from building_gan_amd import ops
     res = {}
-    for fused in (True, False):
-        hm.FUSE_GBLOCK = fused
+    for fused in (True, "posb", False):
+        hm.FUSE_GBLOCK = bool(fused)
         try:
             for p in blk.parameters():
                 p.grad = None
             v = v0.clone().requires_grad_(True)
-            out = blk.forward_composed(v, plan, pdm4, blk.compose())
+            comp = blk.compose()
+            # "posb": the position + bias term evaluated once, the product starting from it (K = 2H)
+            posb = ops.block_pos_term(pdm4, comp[0], comp[1]) if fused == "posb" else None
+            out = blk.forward_composed(v, plan, pdm4, comp, posb=posb)
             (out * gout).sum().backward()
             res[fused] = [out.detach(), v.grad] + [p.grad.clone() for p in blk.parameters()]
         finally:
             hm.FUSE_GBLOCK = True
-    for a, b in zip(res[True], res[False]):
-        scale = float(b.abs().max()) + 1e-12
-        assert float((a - b).abs().max()) <= 2e-5 * scale
+    for key in (True, "posb"):
+        for a, b in zip(res[key], res[False]):
+            scale = float(b.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) <= 2e-5 * scale
+    with torch.no_grad():       # and the graph-free pass with / without the precomputed term
+        comp = blk.compose()
+        a = blk.forward_composed(v0, plan, pdm4, comp)
+        b = blk.forward_composed(v0, plan, pdm4, comp, posb=ops.block_pos_term(pdm4, comp[0], comp[1]))
+    assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
 
 
 def test_attention_node_equals_op_by_op_path(cuda):

@@ -1,6 +1,6 @@
 """Launches only the roofline kernels (for rocprofv3 --kernel-trace / --pmc passes): the train step's
-dominant GEMM (the generator block's collapsed Linear: [v | mean_j v_j | dpos] -> H with the per-story
-term gathered in the epilogue and LeakyReLU) and the 10^6-edge gather-mean of the microbench."""
+dominant GEMM (the generator block's collapsed Linear: [v | mean_j v_j] -> H starting from the position + bias
+term, with the per-story term gathered in the epilogue, LeakyReLU and the residual) and the 10^6-edge gather-mean of the microbench."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,13 +16,13 @@ if which in ("gemm", "both"):
     batch = make_batch("dataset", seed=0).to(dev)
     plan = build_plan(batch)
     M, H = batch_sizes(batch)["Nv"], 128
-    xs = [torch.rand(M, H, device=dev) * 2 - 1, torch.rand(M, H, device=dev) * 2 - 1, torch.rand(M, 4, device=dev) * 2 - 1]
-    W = torch.rand(H, 2 * H + 4, device=dev) * 2 - 1
-    b = torch.rand(H, device=dev)
+    xs = [torch.rand(M, H, device=dev) * 2 - 1, torch.rand(M, H, device=dev) * 2 - 1]
+    W = torch.rand(H, 2 * H, device=dev) * 2 - 1
+    posb = torch.rand(M, H, device=dev) * 2 - 1
     term = torch.rand(plan.S, H, device=dev)
     for _ in range(iters):
-        ops.gemm_raw(xs, W, False, True, bias=b, act=ops.ACT_LEAKY, slope=0.01, pre_add=term,
-                     pre_rows=plan.story_gather.csr.col)
+        ops.gemm_raw(xs, W, False, True, act=ops.ACT_LEAKY, slope=0.01, pre_add=term,
+                     pre_rows=plan.story_gather.csr.col, residual=xs[0], acc_init=posb)
 if which in ("spmm", "both"):
     batch = make_batch("microbench", seed=0).to(dev)
     plan = build_plan(batch)
