@@ -347,6 +347,38 @@ def test_bad_arguments_are_rejected(cuda):
         ops.gemm_raw([torch.zeros(4, 4)], torch.zeros(4, 4), False, True)            # CPU tensors: no fallback
 
 
+def test_bad_arguments_of_the_generator_and_critic_nodes_are_rejected(cuda):
+    """The entry points added for the one-node generator / critic paths refuse what they cannot run, before
+    any launch: missing operands (BG_ERR_ARG = -1), unsupported widths (BG_ERR_SHAPE = -2); the Python
+    wrappers raise BganError for plans / shapes that do not fit."""
+    from building_gan_amd import _lib, ops
+    import copy
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(64, 128, device=cuda)
+    i32 = torch.zeros(65, dtype=torch.int32, device=cuda)
+    # story backward: a missing output, a width that is not a multiple of 4
+    assert lib.bg_story_bwd_f32(x.data_ptr(), 128, x.data_ptr(), 128, x.data_ptr(), 128, i32.data_ptr(), None,
+                                x.data_ptr(), 0.01, None, 128, x.data_ptr(), 128, x.data_ptr(), 128, 1, 128, st) == -1
+    assert lib.bg_story_bwd_f32(x.data_ptr(), 128, x.data_ptr(), 128, x.data_ptr(), 128, i32.data_ptr(), None,
+                                x.data_ptr(), 0.01, x.data_ptr(), 128, x.data_ptr(), 128, x.data_ptr(), 128, 1, 126,
+                                st) == -2
+    # gathered addend without its row index; accumulator start with too small a pitch
+    assert lib.bg_spmm_add_f32(x.data_ptr(), 128, i32.data_ptr(), None, None, 0, None, 0, None, 0, None, 0,
+                               x.data_ptr(), 128, None, None, 0, x.data_ptr(), 128, 64, 128, st) == -1
+    g_, p = _plan(copy.deepcopy(_batch("tiny", 12, False)), cuda)
+    with pytest.raises(_lib.BganError):          # story segments that do not cover the operand's rows
+        ops.story_bwd_raw(p.story_seg, x[:8], x[:8], x[:8], 0.01)
+    with pytest.raises(_lib.BganError):          # accumulator start of the wrong shape
+        ops.gemm_raw([x], torch.zeros(32, 128, device=cuda), False, True, acc_init=torch.zeros(64, 16, device=cuda))
+    with pytest.raises(_lib.BganError):          # row-lookup scatter with a segment map of the wrong length
+        ops.scatter_arg_raw(x[:4], torch.zeros(4, 128, dtype=torch.int32, device=cuda), 64,
+                            seg_of=torch.zeros(3, dtype=torch.int32, device=cuda))
+    # coefficient inputs: the static column block must hold features + levels + 4 position columns + the one
+    assert lib.bg_d_coef_init_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                                  4 * 128 + 4, x.data_ptr(), 128, 4, 6, 20, 28, 8, x.data_ptr(), x.data_ptr(), st) == -1
+
+
 def test_mask_gumbel_two_way(cuda):
     """Fused mask kernel against the reference expression (models.py:109-111, util.py:6-10), with its gradient."""
     from building_gan_amd import ops
