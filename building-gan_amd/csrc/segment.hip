@@ -601,6 +601,9 @@ struct ChainArgs {
     const float* add; int64_t ld_add; int64_t add_step;
     float* out; int64_t ldo; int64_t out_step;
     int n_steps;
+    // optional second matrix under the same operator and step count (k_spmm_chain_short only): column chunks
+    // blockIdx.y >= split_y belong to it (no addend)
+    int split_y; const float* x0b; int64_t ldxb; float* outb; int64_t ldob; int64_t out_stepb;
 };
 
 template <bool IDX_LDS>
@@ -709,8 +712,12 @@ __global__ __launch_bounds__(1024) void k_spmm_chain_short(ChainArgs a) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int32_t r0 = a.blk_ptr[blockIdx.x];
     const int32_t nr = a.blk_ptr[blockIdx.x + 1] - r0;
-    const int cc = 4 * blockIdx.y;
+    int cc = 4 * blockIdx.y;
     if (nr <= 0 || nr > a.max_rows || nr > RPT * nt) return;   // uniform per workgroup (host checks the plan)
+    if (a.x0b && (int)blockIdx.y >= a.split_y) {                // uniform per workgroup: the second matrix
+        cc = 4 * ((int)blockIdx.y - a.split_y);
+        a.x0 = a.x0b; a.ldx = a.ldxb; a.out = a.outb; a.ldo = a.ldob; a.out_step = a.out_stepb; a.add = nullptr;
+    }
     const int zero_slot = a.max_rows;                           // both images carry one extra, all-zero row
     float4* buf0 = chain_smem;
     float4* buf1 = chain_smem + (a.max_rows + 1);
@@ -869,6 +876,27 @@ int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const
     lds = chain_lds_bytes(max_rows, max_nnz, false);
     if (lds <= BG_CHAIN_LDS_LIMIT) return launch_chain<false>(a, n_blk, W, lds, s);
     return BG_ERR_SHAPE;          // a diagonal block does not fit in LDS: run the steps as separate launches
+}
+
+int bg_spmm_chain_pair_f32(const float* x0, int64_t ldx, float* out, int64_t ldo, int64_t out_step, int64_t W,
+                           const float* x0b, int64_t ldxb, float* outb, int64_t ldob, int64_t out_stepb, int64_t Wb,
+                           const int32_t* rowptr, const int32_t* col,
+                           const float* row_scale, int row_mode, const float* col_scale, int col_mode,
+                           const int32_t* blk_ptr, int64_t n_blk, int64_t max_rows, int64_t max_nnz, int64_t max_deg,
+                           int64_t n_steps, bgStream stream) {
+    if (n_blk < 0 || W <= 0 || Wb <= 0 || n_steps < 0 || max_rows < 0 || max_nnz < 0 || max_deg < 0) return BG_ERR_ARG;
+    if (n_blk == 0 || n_steps == 0 || max_rows == 0) return BG_OK;
+    if (!x0 || !out || !x0b || !outb || !rowptr || !col || !blk_ptr || ldx < W || ldo < W || ldxb < Wb || ldob < Wb)
+        return BG_ERR_ARG;
+    if ((row_mode && !row_scale) || (col_mode && !col_scale)) return BG_ERR_ARG;
+    if (W % 4 != 0 || Wb % 4 != 0 || n_blk > 65535 || (W + Wb) / 4 > 65535 || n_steps > (1 << 20)) return BG_ERR_SHAPE;
+    if (!bg_aligned16(x0) || !bg_aligned16(out) || !bg_aligned16(x0b) || !bg_aligned16(outb) || ldx % 4 != 0 ||
+        ldo % 4 != 0 || out_step % 4 != 0 || ldxb % 4 != 0 || ldob % 4 != 0 || out_stepb % 4 != 0) return BG_ERR_ALIGN;
+    if (!(max_deg <= 8 && max_rows <= 2048)) return BG_ERR_SHAPE;      // short-row plans only: else two bg_spmm_chain_f32 calls
+    ChainArgs a{x0, ldx, rowptr, col, row_scale, row_mode, col_scale, col_mode, blk_ptr, (int)max_rows, (int)max_nnz,
+                nullptr, 0, 0, out, ldo, out_step, (int)n_steps, (int)(W / 4), x0b, ldxb, outb, ldob, out_stepb};
+    hipStream_t s = (hipStream_t)stream;
+    return max_deg <= 6 ? dispatch_chain_short<6>(a, n_blk, W + Wb, s) : dispatch_chain_short<8>(a, n_blk, W + Wb, s);
 }
 
 int bg_segreduce_sum_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,

@@ -434,7 +434,7 @@ class VoxelGNN_D(nn.Module):
     # parameters by the recurrence T^{m+1}_k = T^m_k (I + Wa^T) + T^m_{k-1} Wb^T + [k=0] E.
     # One pass costs L thin gather-means (8 label columns; the label-free columns are shared by every
     # pass of an iteration) and ONE [N, (L+1)*40] x [.., 2H] GEMM instead of L GEMMs of K = 4H+4.
-    def _static_powers(self, plan, feat, pdm4):
+    def _static_powers(self, plan, feat, pdm4, rider=None):
         """[N, (L+1)*ds]: A^k [feature | onehot(level) | mean dpos | 1 | 0..] for k = 0..L (label-free
         columns; no gradient).  Kept on the plan until Trainer / the caller starts the next iteration."""
         key = ("d_static_powers", self.layer_num, self.pe.shape[0])
@@ -447,7 +447,11 @@ class VoxelGNN_D(nn.Module):
             # column group 0 in one launch; the chain of operator powers writes groups 1..L
             Z = torch.empty(feat.shape[0], (self.layer_num + 1) * ds, device=feat.device)
             ops.d_static_cols_raw(feat.detach(), plan.level, ML, pdm4, Z, ds)
-            ops.power_chain_raw(plan.vox_mean, Z, self.layer_num, ds, plan.vox_blocks)
+            if rider is not None:      # (Zk, width): another matrix whose powers are due -- both in one launch
+                ops.power_chain_pair_raw(plan.vox_mean, Z, ds, rider[0], rider[1], self.layer_num, plan.vox_blocks)
+                rider[2] = True
+            else:
+                ops.power_chain_raw(plan.vox_mean, Z, self.layer_num, ds, plan.vox_blocks)
             plan.ops[key] = Z
         return Z
 
@@ -523,15 +527,17 @@ class VoxelGNN_D(nn.Module):
         evaluated once; each pass adds its own thin product.  Returns ([v_L per pass], Wl, dl) where
         Wl [(L+1)*dl, 2H] maps label powers to the output (rows ordered (k, label column))."""
         L, P, N = self.layer_num, len(labels), feat.shape[0]
-        Zs = self._static_powers(plan, feat, pdm4)
-        ds = Zs.shape[1] // (L + 1)
         n_lab = labels[0].shape[1]
         dl = (n_lab + 3) // 4 * 4
-        W = self.coefficients(feat.shape[1], ds, dl)
-        Ws, Wl = W.split([(L + 1) * ds, (L + 1) * dl], dim=0)
         Zk = torch.empty(N, L + 1, P * dl, device=feat.device)       # group 0 packed here, the rest by the chain
         ops.pack_columns_raw([l.detach() for l in labels], dl, Zk.view(N, -1))
-        ops.power_chain_raw(plan.vox_mean, Zk, L, P * dl, plan.vox_blocks)
+        rider = [Zk, P * dl, False]      # when the label-free powers are still to be made, the label powers ride along
+        Zs = self._static_powers(plan, feat, pdm4, rider)
+        ds = Zs.shape[1] // (L + 1)
+        W = self.coefficients(feat.shape[1], ds, dl)
+        Ws, Wl = W.split([(L + 1) * ds, (L + 1) * dl], dim=0)
+        if not rider[2]:
+            ops.power_chain_raw(plan.vox_mean, Zk, L, P * dl, plan.vox_blocks)
         Zp = Zk.view(N, L + 1, P, dl).permute(0, 2, 1, 3).contiguous().view(N, P, (L + 1) * dl)
         S = linear([Zs], Ws, w_t=True)
         return [linear([Zp[:, p]], Wl, pre_add=S, w_t=True) for p in range(P)], Wl, dl

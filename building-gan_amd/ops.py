@@ -247,6 +247,29 @@ def power_chain_raw(op: LinOp, Z: torch.Tensor, L: int, W: int, blocks=None) -> 
     return Z
 
 
+def power_chain_pair_raw(op: LinOp, Z1: torch.Tensor, W1: int, Z2: torch.Tensor, W2: int, L: int, blocks=None) -> None:
+    """power_chain_raw on two matrices under the same operator: ONE launch when both fit the short-row chain
+    kernel (a chain's time does not depend on its width, so the second one rides along), else two calls."""
+    N = Z1.shape[0]
+    A, B = Z1.view(N, -1), Z2.view(N, -1)
+    ok = (blocks is not None and L > 0 and N > 0 and blocks.max_deg <= 8 and blocks.max_rows <= 2048
+          and A.dtype == torch.float32 and B.dtype == torch.float32 and A.stride(1) == 1 and B.stride(1) == 1
+          and A.shape[1] >= (L + 1) * W1 and B.shape[1] >= (L + 1) * W2 and B.shape[0] == N and N == op.csr.n_cols
+          and _chain_fits(op, blocks, W1, A) and _chain_fits(op, blocks, W2, B))
+    if not ok:
+        power_chain_raw(op, Z1, L, W1, blocks)
+        power_chain_raw(op, Z2, L, W2, blocks)
+        return
+    _lib.require_device(Z1, "power_chain_pair")
+    lib = _lib.load()
+    c = op.csr
+    check(lib.bg_spmm_chain_pair_f32(A.data_ptr(), A.stride(0), A.data_ptr() + 4 * W1, A.stride(0), W1, W1,
+                                     B.data_ptr(), B.stride(0), B.data_ptr() + 4 * W2, B.stride(0), W2, W2,
+                                     ptr(c.rowptr), ptr(c.col), ptr(op.row_scale), op.row_mode, ptr(op.col_scale),
+                                     op.col_mode, ptr(blocks.ptr), blocks.n, blocks.max_rows, blocks.max_nnz,
+                                     blocks.max_deg, L, stream()), "bg_spmm_chain_pair_f32")
+
+
 def horner_chain_raw(op: LinOp, Y: torch.Tensor, L: int, W: int, blocks=None) -> torch.Tensor:
     """sum_k op^k Y_k for Y [N, (L+1)*W] (column group k = Y_k), evaluated as
     acc = Y_L; acc = op(acc) + Y_k for k = L-1..0.  One launch under the conditions of power_chain_raw."""

@@ -112,6 +112,17 @@ int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const
                       const float* add, int64_t ld_add, int64_t add_step,
                       float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, bgStream stream);
 
+/* bg_spmm_chain_f32 (no addend) on TWO matrices under the same operator and step count in one launch: the
+ * column chunks of both fill the chip side by side (a chain's time does not depend on its width).  Short-row
+ * plans only (max_deg <= 8, max_rows <= 2048), else BG_ERR_SHAPE and the caller launches them one by one.
+ * replaces: the label-free and the label operator powers of the collapsed discriminator, Model/models.py:227-228. */
+int bg_spmm_chain_pair_f32(const float* x0, int64_t ldx, float* out, int64_t ldo, int64_t out_step, int64_t W,
+                           const float* x0b, int64_t ldxb, float* outb, int64_t ldob, int64_t out_stepb, int64_t Wb,
+                           const int32_t* rowptr, const int32_t* col,
+                           const float* row_scale, int row_mode, const float* col_scale, int col_mode,
+                           const int32_t* blk_ptr, int64_t n_blk, int64_t max_rows, int64_t max_nnz, int64_t max_deg,
+                           int64_t n_steps, bgStream stream);
+
 /* Same contraction for LONG rows, two phases: phase 1 reduces chunks of at most rows_per_chunk
  * slots (chunk_ptr from bg_plan_chunks, n_chunks_ub >= chunk_ptr[n_rows]) into
  * partial[n_chunks_ub, H]; phase 2 adds a row's partials in chunk order.  Deterministic.

@@ -548,6 +548,30 @@ def test_operator_chain_autograd_pair(cuda):
     np.testing.assert_allclose(Yg.grad.cpu().numpy(), Yd.grad.numpy(), rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("preset,ragged", [("small", True), ("dataset", False)])
+def test_operator_chain_pair_equals_two_chains(cuda, preset, ragged):
+    """bg_spmm_chain_pair_f32 (the powers of two matrices of different width and pitch in ONE launch) against
+    two bg_spmm_chain_f32 launches: identical bits, for both register-index variants; a plan outside the
+    short-row kernel falls back to the two launches."""
+    from building_gan_amd import ops
+    import dataclasses
+    g, p = _plan(_batch(preset, 13, ragged), cuda)
+    gen = torch.Generator().manual_seed(29)
+    N, L, W1, W2 = p.Nv, 12, 32, 24
+    x1 = (torch.rand(N, W1, generator=gen) * 2 - 1).to(cuda)
+    x2 = (torch.rand(N, W2, generator=gen) * 2 - 1).to(cuda)
+    for blk in (p.vox_blocks, dataclasses.replace(p.vox_blocks, max_deg=8),
+                dataclasses.replace(p.vox_blocks, max_deg=1 << 20)):
+        Z1 = torch.zeros(N, (L + 1) * W1, device=cuda); Z1[:, :W1] = x1
+        Z2 = torch.zeros(N, (L + 1) * W2 + 8, device=cuda); Z2[:, :W2] = x2
+        R1, R2 = Z1.clone(), Z2.clone()
+        ops.power_chain_pair_raw(p.vox_mean, Z1, W1, Z2, W2, L, blk)
+        ops.power_chain_raw(p.vox_mean, R1, L, W1, blk)
+        ops.power_chain_raw(p.vox_mean, R2, L, W2, blk)
+        assert torch.equal(Z1, R1) and torch.equal(Z2, R2)
+        assert float(Z1[:, -W1:].abs().max()) > 0 and float(Z2[:, L * W2:(L + 1) * W2].abs().max()) > 0
+
+
 def test_operator_chain_rejects_oversized_blocks(cuda):
     """A diagonal block that cannot live in LDS is refused (BG_ERR_SHAPE); the host then runs the steps one by one."""
     from building_gan_amd import _lib, ops
