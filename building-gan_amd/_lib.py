@@ -56,6 +56,8 @@ SIGNATURES = {
     "bg_d_coef_init_bwd_f32": [_p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i64, _p, _p],
     "bg_spmm_chain_pair_f32": [_p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _int, _p, _int,
                                _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "bg_attention_bwd_head_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _i64,
+                                  _i64, _i64, _p],
     "bg_pos_terms_f32": [_p, _i64, _p, _p, _p, _i64, _f, _p],
     "bg_d_static_cols_f32": [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p],
     "bg_critic_loss_f32": [_p, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _f, _p, _p, _p],

@@ -303,6 +303,88 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
     }
 }
 
+// Head of one Attention call's backward (ops.AttentionNode), one wave per voxel -- what a weighted gather, two
+// sampled dot products, an elementwise product, the additions of the incoming edge gradients, the segment
+// softmax's backward and the mask's backward do as seven or eight launches.  With out = v + s0 * gathered,
+// gathered = sum_k soft_k x[col_k]:
+//   gg      = g_out * s0                                     (written: the program-side gather-transpose reads it)
+//   g_k     = <gg, x[col_k]> (+ g_soft_k + g_hard_k)         gradient at soft_k (hard passes its own straight on)
+//   d_att_k = soft_k (g_k - sum_j soft_j g_j) / tau          (k_seg_softmax_bwd)
+//   d_mask  = (g_soft0 + g_hard0 + <g_out, gathered>) s0 (1 - s0)  -> (d, -d, 0, 0) into a 4-column slot (k_mask_gumbel_bwd)
+// Slots of a voxel are in edge order (checked plan); degree <= 64.
+template <int CPL>
+__global__ __launch_bounds__(256) void k_attention_bwd_head(const float* __restrict__ G, int64_t ldg,       // g_out [Nv, H]
+                                                            const float* __restrict__ X, int64_t ldx,       // program features
+                                                            const float* __restrict__ soft0, const float* __restrict__ soft,
+                                                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                            const float* __restrict__ g_soft, const float* __restrict__ g_hard,
+                                                            const float* __restrict__ g_soft0, const float* __restrict__ g_hard0,
+                                                            float tau, float* __restrict__ gg, int64_t ldgg,
+                                                            float* __restrict__ d_att, float* __restrict__ d_mask, int64_t ldd,
+                                                            int64_t n_vox) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_vox) return;                                       // wave-uniform
+    const float s0 = soft0[v];
+    float go[CPL], gs[CPL], gath[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        go[j] = G[v * ldg + lane + 64 * j];
+        gs[j] = go[j] * s0;
+        gg[v * ldgg + lane + 64 * j] = gs[j];
+        gath[j] = 0.f;
+    }
+    const int32_t b = rowptr[v], e = rowptr[v + 1];
+    const int deg = e - b;
+    const int32_t my_col = lane < deg ? col[b + lane] : 0;
+    const float my_soft = lane < deg ? soft[b + lane] : 0.f;
+    float my_g = 0.f;
+    if (lane < deg) {
+        if (g_soft) my_g += g_soft[b + lane];
+        if (g_hard) my_g += g_hard[b + lane];
+    }
+    for (int k0 = 0; k0 < deg; k0 += 4) {
+        float xv[4][CPL];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int32_t c = __shfl(my_col, k0 + i < deg ? k0 + i : k0, 64);
+            const float* xp = X + (int64_t)c * ldx;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) xv[i][j] = xp[lane + 64 * j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (k0 + i < deg) {                                   // wave-uniform
+                const float w = __shfl(my_soft, k0 + i, 64);
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    gath[j] = fmaf(w, xv[i][j], gath[j]);
+                    acc = fmaf(gs[j], xv[i][j], acc);
+                }
+                acc = bg_wave_sum(acc);
+                if (lane == k0 + i) my_g += acc;
+            }
+        }
+    }
+    // segment softmax backward over the voxel's edges, in slot order
+    float dot = 0.f;
+    for (int k = 0; k < deg; ++k) dot = fmaf(__shfl(my_soft, k, 64), __shfl(my_g, k, 64), dot);
+    if (lane < deg) d_att[b + lane] = my_soft * (my_g - dot) / tau;
+    // mask
+    float gm = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) gm = fmaf(go[j], gath[j], gm);
+    gm = bg_wave_sum(gm);
+    if (lane == 0) {
+        float g = gm;
+        if (g_soft0) g += g_soft0[v];
+        if (g_hard0) g += g_hard0[v];
+        const float d = g * s0 * (1.f - s0);
+        *reinterpret_cast<float4*>(d_mask + v * ldd) = make_float4(d, -d, 0.f, 0.f);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -426,6 +508,33 @@ int bg_attention_fwd_f32(const float* a, int64_t lda, const float* logits, int64
         BG_ATT_CASE(5) BG_ATT_CASE(6) BG_ATT_CASE(7) BG_ATT_CASE(8)
     }
 #undef BG_ATT_CASE
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_attention_bwd_head_f32(const float* g_out, int64_t ldg, const float* x, int64_t ldx,
+                              const float* soft0, const float* soft, const int32_t* rowptr, const int32_t* col,
+                              const float* g_soft, const float* g_hard, const float* g_soft0, const float* g_hard0,
+                              float tau, float* gg, int64_t ldgg, float* d_att, float* d_mask, int64_t ldd,
+                              int64_t n_vox, int64_t H, bgStream stream) {
+    if (n_vox < 0 || H <= 0 || tau == 0.f) return BG_ERR_ARG;
+    if (n_vox == 0) return BG_OK;
+    if (!g_out || !x || !soft0 || !soft || !rowptr || !col || !gg || !d_att || !d_mask || ldg < H || ldx < H ||
+        ldgg < H || ldd < 4) return BG_ERR_ARG;
+    if (H % 64 != 0 || H > 64 * kMaxCPL) return BG_ERR_SHAPE;
+    if (!bg_aligned16(d_mask) || ldd % 4 != 0) return BG_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = bg_grid_for(n_vox, 4, 0x7fffffff);
+#define BG_ATTB_CASE(C)                                                                                          \
+    case C:                                                                                                      \
+        k_attention_bwd_head<C><<<grid, 256, 0, s>>>(g_out, ldg, x, ldx, soft0, soft, rowptr, col, g_soft, g_hard, \
+                                                     g_soft0, g_hard0, tau, gg, ldgg, d_att, d_mask, ldd, n_vox); \
+        break;
+    switch ((int)(H / 64)) {
+        BG_ATTB_CASE(1) BG_ATTB_CASE(2) BG_ATTB_CASE(3) BG_ATTB_CASE(4)
+        BG_ATTB_CASE(5) BG_ATTB_CASE(6) BG_ATTB_CASE(7) BG_ATTB_CASE(8)
+    }
+#undef BG_ATTB_CASE
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

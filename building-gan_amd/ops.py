@@ -932,6 +932,9 @@ def _wgrad(shared, key, first, like, fn):
     return shared.take(key, first)
 
 
+FUSE_ATTENTION_BWD_HEAD = True      # AttentionNode.backward: everything up to the softmax / mask backward in one launch
+
+
 class AttentionNode(torch.autograd.Function):
     """One Attention call (reference models.py:104-126) as ONE autograd node: the forward is the fused pair of
     the graph-free pass (NN_v product, then one launch for mask, cross logits, segment Gumbel-softmax pointer,
@@ -969,6 +972,23 @@ class AttentionNode(torch.autograd.Function):
         g_e = None
         g_x = None
         g_more = None
+        if (FUSE_ATTENTION_BWD_HEAD and g_out is not None and H % 64 == 0 and H <= 512 and 0 < cv.max_len <= 64
+                and cv.col is not None):
+            # everything up to the softmax's and the mask's backward in ONE launch (one wave per voxel)
+            g_out = _f32c(g_out)
+            x2 = _f32c(x)
+            G_al = torch.empty(N, H + 4, dtype=torch.float32, device=dev)
+            gg = torch.empty(N, H, dtype=torch.float32, device=dev)
+            d_att = torch.empty_like(soft)
+            cont = lambda t: _f32c(t).reshape(-1).contiguous() if t is not None else None
+            gse, ghe, gs0, gh0 = cont(g_soft), cont(g_hard), cont(g_soft0), cont(g_hard0)
+            check(lib.bg_attention_bwd_head_f32(ptr(g_out), _ld(g_out), ptr(x2), _ld(x2), ptr(soft0), ptr(soft),
+                                                ptr(cv.rowptr), ptr(cv.col), ptr(gse), ptr(ghe), ptr(gs0), ptr(gh0),
+                                                ctx.tau, ptr(gg), H, ptr(d_att), G_al.data_ptr() + 4 * H, H + 4, N, H,
+                                                stream()), "bg_attention_bwd_head_f32")
+            if ctx.needs_input_grad[1]:
+                g_x = spmm_raw(plan.cross_v_sum.T, gg, soft)
+            return AttentionNode._backward_tail(ctx, lib, G_al, d_att, g_out, g_x, True)
         if g_out is not None:
             g_out = _f32c(g_out)
             gathered = spmm_raw(plan.cross_v_sum, x, soft)
@@ -982,11 +1002,29 @@ class AttentionNode(torch.autograd.Function):
                 g_e = extra.reshape(-1) if g_e is None else g_e + extra.reshape(-1)
         # ---- one [Nv, H+4] matrix of gradients at the stacked Linear's output: [d a | d logits | 0 0]
         G_al = torch.empty(N, H + 4, dtype=torch.float32, device=dev)
-        db = dth = None
+        d_att = None
         if g_e is not None:
             d_att = torch.empty_like(soft)
             check(lib.bg_seg_softmax_bwd_f32(ptr(soft), ptr(_f32c(g_e)), ptr(cv.rowptr), ctx.tau, ptr(d_att), cv.n_rows,
                                              stream()), "bg_seg_softmax_bwd_f32")
+        gs0 = _f32c(g_soft0).contiguous() if g_soft0 is not None else None
+        gh0 = _f32c(g_hard0).contiguous() if g_hard0 is not None else None
+        check(lib.bg_mask_gumbel_bwd_f32(ptr(soft0), ptr(gs0), ptr(gh0), ptr(g_more), G_al.data_ptr() + 4 * H, H + 4, N,
+                                         stream()), "bg_mask_gumbel_bwd_f32")
+        return AttentionNode._backward_tail(ctx, lib, G_al, d_att, g_out, g_x, False)
+
+    @staticmethod
+    def _backward_tail(ctx, lib, G_al, d_att, g_out, g_x, _fused):
+        """From d_att (gradient at the cross-edge logits; None = zero) and the mask slot of G_al to the gradients
+        of v, NN_p(x), the stacked weight / bias and theta."""
+        v, x, b, a, Wcat, theta, soft0, soft = ctx.saved_tensors
+        plan = ctx.plan
+        cv = plan.cross_v
+        N, H = v.shape
+        dev = v.device
+        th = _f32c(theta.reshape(-1))
+        db = dth = None
+        if d_att is not None:
             nb = max(1, min(1024, (cv.n_rows + 3) // 4))
             dpre = torch.empty(cv.nnz, H, dtype=torch.float32, device=dev)
             dth_p = torch.empty(nb, H, dtype=torch.float32, device=dev)
@@ -1000,10 +1038,6 @@ class AttentionNode(torch.autograd.Function):
                 dth = dth.view(ctx.theta_shape) if dth is not None else None
         else:
             G_al[:, :H].zero_()
-        gs0 = _f32c(g_soft0).contiguous() if g_soft0 is not None else None
-        gh0 = _f32c(g_hard0).contiguous() if g_hard0 is not None else None
-        check(lib.bg_mask_gumbel_bwd_f32(ptr(soft0), ptr(gs0), ptr(gh0), ptr(g_more), G_al.data_ptr() + 4 * H, H + 4, N,
-                                         stream()), "bg_mask_gumbel_bwd_f32")
         sh, first = ctx.shared, ctx.first
         gW = _wgrad(sh, "Wcat", first, Wcat, lambda o, acc: gemm_tn_raw(G_al, [v], o, acc)) if ctx.needs_input_grad[3] else None
         gb = _wgrad(sh, "bcat", first, G_al[0], lambda o, acc: colsum_raw(G_al, o, acc)) if ctx.needs_input_grad[4] else None

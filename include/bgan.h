@@ -317,6 +317,22 @@ int bg_d_coef_init_bwd_f32(const float* G, int64_t slab, int64_t L, int64_t H, i
                            int64_t ds, int64_t dl, float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b,
                            float* gw_tail, int64_t ldw, float* g_bc, bgStream stream);
 
+/* Head of one Attention call's backward in one launch (one wave per voxel; slots of a voxel in edge order,
+ * degree <= 64, H % 64 == 0, H <= 512).  With out = v + s0 * sum_k soft_k x[col_k] and the incoming gradients
+ * g_out [n_vox, H], g_soft / g_hard [Ec] (NULL = none), g_soft0 / g_hard0 [n_vox] (NULL = none):
+ *   gg[v, :]  = g_out[v, :] * soft0[v]
+ *   g_k       = <gg[v], x[col_k]> + g_soft_k + g_hard_k
+ *   d_att_k   = soft_k (g_k - sum_j soft_j g_j) / tau
+ *   d_mask[v] = (d, -d, 0, 0),  d = (g_soft0 + g_hard0 + <g_out[v], sum_k soft_k x[col_k]>) s0 (1 - s0)
+ * (d_mask: 16-byte aligned 4-float slots, pitch ldd).
+ * replaces: the backward of Model/models.py:109-111,120-126 (weighted gather, its two sampled dot products, the
+ * segment softmax and the mask's Gumbel-softmax) that autograd runs as seven or eight launches.            */
+int bg_attention_bwd_head_f32(const float* g_out, int64_t ldg, const float* x, int64_t ldx,
+                              const float* soft0, const float* soft, const int32_t* rowptr, const int32_t* col,
+                              const float* g_soft, const float* g_hard, const float* g_soft0, const float* g_hard0,
+                              float tau, float* gg, int64_t ldgg, float* d_att, float* d_mask, int64_t ldd,
+                              int64_t n_vox, int64_t H, bgStream stream);
+
 /* WGAN-GP critic objective in two launches:
  *   loss[0] = <val_b, wb> + <val_s, ws> + coef * sum_r (||grads[r, 0:W]|| - 1)^2 ,  r < n_rows
  * (wb / ws carry the -+1/count weights of the real / fake means; grads may be NULL with n_rows = 0);

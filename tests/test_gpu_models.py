@@ -517,3 +517,38 @@ def test_coefficient_inputs_by_one_launch_equal_cat_construction(cuda):
     for n, a, r in zip(names, res[True], res[False]):
         scale = float(r.abs().max()) + 1e-12
         assert float((a - r).abs().max()) <= 2e-5 * scale, n
+
+
+def test_attention_backward_head_one_launch_equals_separate_launches(cuda):
+    """bg_attention_bwd_head_f32 (the head of ops.AttentionNode's backward in one launch) against the same node
+    with the head as its seven separate launches: every gradient to fp32 rounding, with all five outputs used
+    and with only the voxel features used (absent edge / mask gradients)."""
+    from building_gan_amd import models as hm, ops
+    from building_gan_amd.plan import build_plan
+    cpu, gpu, sz, *_ = _setup("small", 55, True, cuda)
+    plan = build_plan(gpu)
+    torch.manual_seed(55)
+    att = hm.Attention(128).to(cuda)
+    v0 = torch.rand(sz["Nv"], 128, device=cuda) * 2 - 1
+    x0 = torch.rand(sz["Np"], 128, device=cuda) * 2 - 1
+    noise = (torch.empty(sz["Nv"], 2, device=cuda).exponential_(), torch.empty(sz["Ec"], device=cuda).exponential_())
+    w = [torch.rand(sz["Nv"], 1, device=cuda), torch.rand(sz["Nv"], 1, device=cuda), torch.rand(sz["Ec"], 1, device=cuda),
+         torch.rand(sz["Ec"], 1, device=cuda), torch.rand(sz["Nv"], 128, device=cuda) * 2 - 1]
+    for used in ((0, 1, 2, 3, 4), (4,)):
+        res = {}
+        for fused in (True, False):
+            ops.FUSE_ATTENTION_BWD_HEAD = fused
+            try:
+                for p in att.parameters():
+                    p.grad = None
+                v, x = v0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+                mask, a, nv = att(x, v, plan, noise)
+                outs = [mask["soft"], mask["hard"], a["soft"], a["hard"], nv]
+                sum((outs[i] * w[i]).sum() for i in used).backward()
+                res[fused] = [v.grad, x.grad] + [p.grad.clone() for p in att.parameters() if p.grad is not None]
+            finally:
+                ops.FUSE_ATTENTION_BWD_HEAD = True
+        assert len(res[True]) == len(res[False])
+        for a_, b_ in zip(res[True], res[False]):
+            scale = float(b_.abs().max()) + 1e-12
+            assert float((a_ - b_).abs().max()) <= 5e-6 * scale
