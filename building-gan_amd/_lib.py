@@ -63,7 +63,7 @@ SIGNATURES = {
     "bg_critic_loss_f32": [_p, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _f, _p, _p, _p],
     "bg_critic_loss_bwd_f32": [_p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _f, _p, _p, _p, _p],
     "bg_gemm_f32": [_int, _int, _i64, _i64, _int, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _int, _f, _p, _i64, _p, _i64,
-                    _p, _p, _i64, _p],
+                    _p, _p, _i64, _p, _i64, _p],
     "bg_gemm_tn_splitk_f32": [_i64, _i64, _p, _i64, _int, _p, _p, _p, _p, _i64, _p, _i32, _int, _p],
     "bg_colsum_f32": [_p, _i64, _i64, _i64, _p, _i32, _p, _int, _p],
     "bg_adam_f32": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i32, _p, _p],

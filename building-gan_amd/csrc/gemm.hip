@@ -28,6 +28,7 @@ struct GemmArgs {
     const float* pre_add; int64_t ldp;
     const int32_t* pre_rows;   // optional: pre_add row of output row i is pre_rows[i] (a fused gather)
     const float* acc0; int64_t ld0;   // optional: the accumulators start from acc0[i, j] instead of zero (k_gemm only)
+    float* C2; int64_t ldc2;          // optional: the value BEFORE the residual is added is also written here
     int64_t M, N;
     int total_steps;      // sum over segments of ceil(K_s / BK)
     int steps_per_split;  // == total_steps when not split
@@ -199,8 +200,10 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc,
         if (g.row_scale) v *= rs[q];
         if (g.pre_add) v += pa[q];
         if (g.act == BG_ACT_LEAKY) v = v > 0.f ? v : v * g.slope;
+        const bool in_range = row0 + (q & 3) + 8 * (q >> 2) < g.M;
+        if (g.C2 && in_range) g.C2[rows[q] * g.ldc2 + col] = v;
         if (g.residual) v += rd[q];
-        if (row0 + (q & 3) + 8 * (q >> 2) < g.M) g.C[rows[q] * g.ldc + col] = v;
+        if (in_range) g.C[rows[q] * g.ldc + col] = v;
     }
 }
 
@@ -837,13 +840,16 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
                 const float* B, int64_t ldb, float* C, int64_t ldc,
                 const float* bias, const float* row_scale, int act, float slope,
                 const float* residual, int64_t ldr, const float* pre_add, int64_t ldp,
-                const int32_t* pre_add_rows, const float* acc_init, int64_t ld_acc, bgStream stream) {
+                const int32_t* pre_add_rows, const float* acc_init, int64_t ld_acc,
+                float* pre_residual_out, int64_t ld_pro, bgStream stream) {
     if (M < 0 || N < 0 || n_seg < 1 || n_seg > 4 || !A || !lda || !Ks) return BG_ERR_ARG;
     if (M == 0 || N == 0) return BG_OK;
     if (!B || !C || ldc < N || (residual && ldr < N) || (pre_add && ldp < N) || (acc_init && ld_acc < N)) return BG_ERR_ARG;
     GemmArgs g{};
     g.n_seg = n_seg;
     g.acc0 = acc_init; g.ld0 = ld_acc;
+    if (pre_residual_out && ld_pro < N) return BG_ERR_ARG;
+    g.C2 = pre_residual_out; g.ldc2 = ld_pro;
     g.pre_add = pre_add; g.ldp = ldp; g.pre_rows = pre_add ? pre_add_rows : nullptr;
     int tile = tile_override();
     if (tile == 0) {
@@ -892,7 +898,7 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
     hipStream_t st = (hipStream_t)stream;
     // few tiles and a moderate K: one 32x32 tile per workgroup, K split over its waves (needs the
     // 16-byte path on A; B is read by 16-byte chunks when K-contiguous, by dwords otherwise)
-    if (tile_override() == 0 && !transA && vec && skinny_mode() && Ktot <= 4096 && !acc_init &&
+    if (tile_override() == 0 && !transA && vec && skinny_mode() && Ktot <= 4096 && !acc_init && !pre_residual_out &&
         ((M + 31) / 32) * ((N + 31) / 32) <= skinny_max_tiles()) {
         bool nonempty = true;
         for (int s = 0; s < n_seg; ++s) nonempty = nonempty && Ks[s] > 0;

@@ -312,7 +312,8 @@ def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: b
              bias: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
              act: int = ACT_NONE, slope: float = 0.01, residual: Optional[torch.Tensor] = None,
              pre_add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-             pre_rows: Optional[torch.Tensor] = None, acc_init: Optional[torch.Tensor] = None) -> torch.Tensor:
+             pre_rows: Optional[torch.Tensor] = None, acc_init: Optional[torch.Tensor] = None,
+             pre_residual_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C = epilogue(acc_init + cat(A, -1 (or 0 when transA)) (x) B); see bg_gemm_f32."""
     lib = _lib.load()
     n_seg = len(A)
@@ -366,9 +367,13 @@ def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: b
         if tuple(acc_init.shape) != (M, N):
             raise _lib.BganError("gemm: acc_init must be an [M, N] matrix")
         ld0 = _ld(acc_init)
+    if pre_residual_out is not None and (tuple(pre_residual_out.shape) != (M, N) or pre_residual_out.stride(-1) != 1
+                                         or pre_residual_out.dtype != torch.float32):
+        raise _lib.BganError("gemm: pre_residual_out must be an fp32 [M, N] matrix with unit inner stride")
     check(lib.bg_gemm_f32(int(transA), int(transB), M, N, n_seg, pa, la, ka, ptr(B2), _ld(B2), ptr(out), _ld(out),
                           ptr(bias), ptr(row_scale), act, slope, ptr(residual), ldr, ptr(pre_add), ldp,
-                          ptr(pre_rows), ptr(acc_init), ld0, stream()), "bg_gemm_f32")
+                          ptr(pre_rows), ptr(acc_init), ld0, ptr(pre_residual_out),
+                          _ld(pre_residual_out) if pre_residual_out is not None else 0, stream()), "bg_gemm_f32")
     return out
 
 
@@ -1076,15 +1081,17 @@ class GBlock(torch.autograd.Function):
         ctx.shared, ctx.first, ctx.ones_pad = shared, first, bool(ones_pad)
         gm, pq = gather_story_raw(plan.vox_mean, plan.story_seg, v, Wsb)
         term = spmm_add_raw(plan.story_building_mean, pq[:, H:], pq[:, :H])
+        # one launch writes both y = leaky(..) (kept for the backward) and v + y (the result)
+        y = torch.empty(v.shape[0], Wc.shape[0], dtype=torch.float32, device=v.device)
         if posb is not None:
-            y = gemm_raw([v, gm], Wc[:, :2 * H], False, True, act=ACT_LEAKY, slope=slope, pre_add=term,
-                         pre_rows=plan.story_gather.csr.col, acc_init=posb)
+            out = gemm_raw([v, gm], Wc[:, :2 * H], False, True, act=ACT_LEAKY, slope=slope, pre_add=term,
+                           pre_rows=plan.story_gather.csr.col, acc_init=posb, residual=v, pre_residual_out=y)
         else:
-            y = gemm_raw([v, gm, pdm4], Wc, False, True, bias=bc, act=ACT_LEAKY, slope=slope, pre_add=term,
-                         pre_rows=plan.story_gather.csr.col)
+            out = gemm_raw([v, gm, pdm4], Wc, False, True, bias=bc, act=ACT_LEAKY, slope=slope, pre_add=term,
+                           pre_rows=plan.story_gather.csr.col, residual=v, pre_residual_out=y)
         ctx.plan, ctx.slope = plan, slope
         ctx.save_for_backward(v, gm, y, Wc, Wsb, pdm4)
-        return v + y
+        return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable

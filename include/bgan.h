@@ -364,6 +364,8 @@ int bg_critic_loss_bwd_f32(const float* go, const float* wb, int64_t nb, const f
  *   acc_init (may be NULL; pitch ld_acc): the sum v starts from acc_init[m,n] instead of 0 -- a term that does
  *   not depend on the layer (the position columns times their weight block plus the bias of a block applied
  *   12 times with the same weights, models.py:196-198) is then computed once and costs no K step.
+ *   pre_residual_out (may be NULL; pitch ld_pro): the value before the residual is added (the activation's
+ *   result, which a backward pass needs apart from the sum) is written here as well.
  * n_seg in 1..4 fuses torch.cat((A_0,..), -1) into the product.  Exact fp32 (v_mfma_f32_32x32x2_f32).
  * Vector path needs 16-byte aligned bases and pitches / K_s % 4 == 0; anything else runs a
  * scalar-load path of the same kernel.
@@ -373,7 +375,8 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
                 const float* B, int64_t ldb, float* C, int64_t ldc,
                 const float* bias, const float* row_scale, int act, float slope,
                 const float* residual, int64_t ldr, const float* pre_add, int64_t ldp,
-                const int32_t* pre_add_rows, const float* acc_init, int64_t ld_acc, bgStream stream);
+                const int32_t* pre_add_rows, const float* acc_init, int64_t ld_acc,
+                float* pre_residual_out, int64_t ld_pro, bgStream stream);
 
 /* C[M,N] = A^T[M,R] * [B_0 | B_1 | ..][R,N] with the long reduction R split over `splits`
  * workgroups per tile: A is [R, M] (pitch lda), B_s is [R, Ns[s]] (pitch ldb[s]), N = sum Ns

@@ -197,11 +197,17 @@ def test_gemm_accumulator_start(cuda, M, N, K):
     Q = torch.rand(M, N) * 2 - 1
     b = torch.rand(N) * 2 - 1
     R = torch.rand(M, N) * 2 - 1
-    out = ops.gemm_raw([A.to(cuda)], W.to(cuda), False, True, bias=b.to(cuda), act=ops.ACT_LEAKY, slope=0.01,
-                       residual=R.to(cuda), acc_init=Q.to(cuda)).cpu().double()
+    y = torch.full((M, N), -7.0, device=cuda)
+    out_d = ops.gemm_raw([A.to(cuda)], W.to(cuda), False, True, bias=b.to(cuda), act=ops.ACT_LEAKY, slope=0.01,
+                         residual=R.to(cuda), acc_init=Q.to(cuda), pre_residual_out=y)
+    out = out_d.cpu().double()
     z = Q.double() + A.double() @ W.double().t() + b.double()
-    ref = torch.where(z > 0, z, 0.01 * z) + R.double()
+    act = torch.where(z > 0, z, 0.01 * z)
+    ref = act + R.double()
     assert float((out - ref).abs().max()) < 2e-5 * K ** 0.5
+    # the second output holds the value before the residual: out == y + R exactly (one fp32 addition)
+    assert float((y.cpu().double() - act).abs().max()) < 2e-5 * K ** 0.5
+    assert torch.equal(out_d, y + R.to(cuda))
 
 
 def test_gemm_tn_splitk_and_colsum(cuda):
