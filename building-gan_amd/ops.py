@@ -972,7 +972,6 @@ class AttentionNode(torch.autograd.Function):
         cv = plan.cross_v
         N, H = v.shape
         dev = v.device
-        th = _f32c(theta.reshape(-1))
         # ---- new_v = v + soft0 * gathered,  gathered = sum_e soft_e x[cep_e]
         g_e = None
         g_x = None
@@ -993,7 +992,7 @@ class AttentionNode(torch.autograd.Function):
                                                 stream()), "bg_attention_bwd_head_f32")
             if ctx.needs_input_grad[1]:
                 g_x = spmm_raw(plan.cross_v_sum.T, gg, soft)
-            return AttentionNode._backward_tail(ctx, lib, G_al, d_att, g_out, g_x, True)
+            return AttentionNode._backward_tail(ctx, lib, G_al, d_att, g_out, g_x)
         if g_out is not None:
             g_out = _f32c(g_out)
             gathered = spmm_raw(plan.cross_v_sum, x, soft)
@@ -1016,10 +1015,10 @@ class AttentionNode(torch.autograd.Function):
         gh0 = _f32c(g_hard0).contiguous() if g_hard0 is not None else None
         check(lib.bg_mask_gumbel_bwd_f32(ptr(soft0), ptr(gs0), ptr(gh0), ptr(g_more), G_al.data_ptr() + 4 * H, H + 4, N,
                                          stream()), "bg_mask_gumbel_bwd_f32")
-        return AttentionNode._backward_tail(ctx, lib, G_al, d_att, g_out, g_x, False)
+        return AttentionNode._backward_tail(ctx, lib, G_al, d_att, g_out, g_x)
 
     @staticmethod
-    def _backward_tail(ctx, lib, G_al, d_att, g_out, g_x, _fused):
+    def _backward_tail(ctx, lib, G_al, d_att, g_out, g_x):
         """From d_att (gradient at the cross-edge logits; None = zero) and the mask slot of G_al to the gradients
         of v, NN_p(x), the stacked weight / bias and theta."""
         v, x, b, a, Wcat, theta, soft0, soft = ctx.saved_tensors
