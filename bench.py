@@ -6,16 +6,32 @@
 A "step" is one G+D training iteration (reference train.py:73-114) over one synthetic batch of 8
 "dataset-sized" buildings per GPU (BASELINE.json configs[1]); the index i of the iteration keeps
 running through warm-up and timed steps, so every 5th step carries the generator update.
-value = voxel-graphs/s over the whole job.  Extra objects on the same JSON line:
-  roofline     -- the dominant kernel of the step (fp32 MFMA GEMM of the generator block),
-                  timed live with HIP events on the launch stream;
-  microbench   -- configs[2]: one message-passing gather-mean layer at 10^6 edges (HBM roofline);
-  cpu_baseline -- the CPU oracle (a "port": the reference itself cannot run) timed
-                  on this host on a bounded sample of the same workload (rank 0, N=1 only).
+
+``value`` is what a training loop over a stream of batches gets: the timed steps rotate over
+``--batches`` (default 8) DISTINCT batches of different shapes, every step rebuilds the batch's index
+plan inside the timed region (as for a batch fresh from the loader) and launches its kernels eagerly
+-- a captured hipGraph is tied to one batch's shapes.  The hipGraph replay of ONE fixed batch (round
+1's headline) is reported beside it as ``replay_best_case``.
+
+With ``--gpus N`` (N > 1) and no WORLD_SIZE in the environment this process only LAUNCHES N ranks
+(children of its own, one per GPU, before it makes any GPU call) and exits with their status; under
+torchrun (WORLD_SIZE set) it is one of the ranks.
+
+Extra objects on the JSON line rank 0 prints:
+  roofline         -- the dominant kernel of the step (fp32 MFMA GEMM of the generator block),
+                      timed live with HIP events on the launch stream;
+  microbench       -- configs[2]: one message-passing gather-mean layer at 10^6 edges (HBM roofline);
+  cpu_baseline     -- the CPU oracle (a "port": the reference itself cannot run) timed
+                      on this host on a bounded sample of the same workload (rank 0, N=1 only);
+  replay_best_case -- hipGraph replay of one fixed batch, plan build outside the timed region.
 """
 import argparse
+import importlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -23,14 +39,52 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
 
+# ------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """Start n ranks of this script as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and
+    wait for them.  The parent has not touched the GPU (it never does: nothing here imports torch) and is
+    not replaced by another program; rank 0 prints the JSON line on the inherited stdout.  Returns the exit
+    status: 0 only when every rank returned 0; the first failure ends the others."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    status = 0
+    pending = set(range(n))
+    while pending:
+        for r in list(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                print("bench.py: rank %d exited with status %d; stopping the other ranks" % (r, rc), file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()
+        if pending:
+            time.sleep(0.05)
+    return status
+
+
+# ------------------------------------------------------------------------------------ helpers
 def event_time_ms(fn, iters, warm=3):
+    import torch
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -44,21 +98,23 @@ def event_time_ms(fn, iters, warm=3):
 
 
 def pmc_traffic(key):
-    """HBM bytes per launch from the committed PMC pass (profiles/r01_traffic.json; collected with
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for gfx950), or None when that file does not cover the kernel."""
+    """HBM bytes per launch from the committed PMC pass (TRAFFIC_FILE; collected with rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950), or None when that file does not cover the kernel.  A constant from a committed profile: PMC
+    counters cannot be collected from inside this process."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             return json.load(f).get(key)
     except (OSError, ValueError):
         return None
 
 
 def roofline_dominant_gemm(dev, batch, plan, hidden=128):
-    """The kernel with the largest share of the step (profiles/r01_bench_kernel_stats*): the generator
-    block's collapsed Linear as the step launches it, [v | mean_j v_j] (K = 2H) -> H starting from the
-    position + bias term (evaluated once per forward), the per-story term gathered in the epilogue,
-    LeakyReLU and the residual.  Algorithmic flops = 2 M N K."""
+    """The kernel with the largest share of the step (profiles/r02_step_kernels*): the generator block's
+    collapsed Linear as the step launches it, [v | mean_j v_j] (K = 2H) -> H starting from the position +
+    bias term (evaluated once per forward), the per-story term gathered in the epilogue, LeakyReLU and the
+    residual.  Algorithmic flops = 2 M N K."""
+    import torch
     from building_gan_amd import ops
     H, Nv = hidden, int(batch.voxel_feature.shape[0])
     torch.manual_seed(1)
@@ -82,18 +138,24 @@ def roofline_dominant_gemm(dev, batch, plan, hidden=128):
     ms = event_time_ms(g.replay, 10) / 20
     flops = 2.0 * Nv * (2 * H) * H
     ach = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "k_gemm<64,64,64> (generator block Linear, M=%d N=%d K=%d from the position + bias term, "
-                      "fused gather + LeakyReLU + residual epilogue)" % (Nv, H, 2 * H),
+    return {"kernel": "generator block Linear, M=%d N=%d K=%d from the position + bias term, "
+                      "fused gather + LeakyReLU + residual epilogue" % (Nv, H, 2 * H),
             "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_generator_block"),
+            "traffic_source": TRAFFIC_FILE,
             "avg_launch_us": round(ms * 1e3, 2), "algorithmic_flops_per_launch": flops,
             # operands [Nv, 2H] + weight + accumulator start [Nv, H] + result [Nv, H] + story term + row index
             # (the residual re-reads the first operand)
             "algorithmic_bytes_per_launch": 4.0 * (Nv * 2 * H + H * 2 * H + 2 * Nv * H + plan.S * H + Nv)}
 
 
-def microbench_message_passing(dev):
-    """configs[2]: gather-mean over a 10^6-edge voxel graph, H = 128 fp32 (SURVEY.md 8d bytes formula)."""
+def microbench_message_passing(dev, pairs=4):
+    """configs[2]: gather-mean over a 10^6-edge voxel graph, fp32.  The timed launches rotate over ``pairs``
+    operand / result pairs (H=128: 4 x 178 MB) so that no launch finds its operand in the 256 MiB Infinity
+    Cache.  roofline.frac is PHYSICAL: HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE from the committed
+    pass over this same rotation, else the compulsory bytes operand + result + index read once) / time / peak;
+    the logical rate of SURVEY.md 8(d) (every neighbour row counted once per edge) is quoted beside it."""
+    import torch
     from building_gan_amd import ops
     from building_gan_amd.plan import build_plan
     from building_gan_amd.synthetic import batch_sizes, make_batch
@@ -101,146 +163,304 @@ def microbench_message_passing(dev):
     sz = batch_sizes(batch)
     batch.to(dev)
     plan = build_plan(batch)
-    res = {"workload": "8 x (20x33x33) voxel graphs", "Nv": sz["Nv"], "Ev": sz["Ev"]}
+    res = {"workload": "8 x (20x33x33) voxel graphs", "Nv": sz["Nv"], "Ev": sz["Ev"], "operand_result_pairs": pairs}
     for H in (128, 256):
-        x = torch.rand(sz["Nv"], H, device=dev) * 2 - 1
-        ms = event_time_ms(lambda: ops.spmm_raw(plan.vox_mean, x), 50)
-        nbytes = sz["Ev"] * (4 * H + 4) + sz["Nv"] * (4 * H + 4 + 4)
-        gbs = nbytes / (ms * 1e-3) / 1e9
+        xs = [torch.rand(sz["Nv"], H, device=dev) * 2 - 1 for _ in range(pairs)]
+        outs = [torch.empty(sz["Nv"], H, device=dev) for _ in range(pairs)]
+        k = [0]
+
+        def run():
+            ops.spmm_raw(plan.vox_mean, xs[k[0] % pairs], out=outs[k[0] % pairs])
+            k[0] += 1
+        ms = event_time_ms(run, 48, warm=4)
+        logical = sz["Ev"] * (4 * H + 4) + sz["Nv"] * (4 * H + 4 + 4)
+        compulsory = 2 * sz["Nv"] * 4 * H + sz["Ev"] * 4 + sz["Nv"] * 8
+        traffic = pmc_traffic("spmm_H%d" % H)
+        phys = traffic if traffic else compulsory
+        gbs = phys / (ms * 1e-3) / 1e9
         res["H%d" % H] = {"edges_per_s": round(sz["Ev"] / (ms * 1e-3), 1), "avg_launch_us": round(ms * 1e3, 2),
                           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("spmm_H%d" % H),
-                                       "algorithmic_bytes_per_launch": nbytes}}
+                                       "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                       "traffic_source": TRAFFIC_FILE if traffic else None,
+                                       "bytes_basis": "pmc" if traffic else "compulsory (operand + result + index once)",
+                                       "compulsory_bytes_per_launch": compulsory,
+                                       "logical_bytes_per_launch": logical,
+                                       "logical_GBs": round(logical / (ms * 1e-3) / 1e9, 1)}}
+        del xs, outs
     return res
 
 
-def cpu_baseline(graphs=2):
-    """CPU oracle on `graphs` dataset-sized buildings: iteration 0 (D+G update) and iteration 1
-    (D update only); a 5-iteration cycle costs t0 + 4*t1."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_share():
+    """Host threads this job may use: the affinity mask, capped by the box's share (OMP_NUM_THREADS is set to
+    the share on the GPU box; os.cpu_count() there shows the whole machine)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        n = min(n, int(os.environ.get("OMP_NUM_THREADS", n)))
+    except ValueError:
+        pass
+    return max(n, 1)
+
+
+def cpu_baseline(graphs=1, budget_s=45.0):
+    """CPU oracle (pure-PyTorch restatement, literal per-edge formulation) on ``graphs`` dataset-sized buildings,
+    iterations in the reference's schedule (every 5th carries the generator update), SURVEY.md 8(d): 5 warm-up +
+    20 timed iterations on all the host threads of this job, median per iteration kind; a 5-iteration cycle costs
+    t(D+G) + 4 t(D).  The 1-thread figure runs 1 + 5 iterations (time-bounded)."""
+    import torch
     from building_gan_amd.graph import detach_batch
     from building_gan_amd.synthetic import batch_sizes, make_batch
     from oracle.networks import DiscriminatorVoxel, Generator
     from oracle.objectives import train_iteration
-    cores = min(16, os.cpu_count() or 1)
-    try:
-        cores = min(cores, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        pass
-    torch.set_num_threads(cores)
     batch = make_batch("dataset", seed=0, graphs=graphs)
     sz = batch_sizes(batch)
-    torch.manual_seed(0)
-    G, D = Generator(7, 7, 128, 32, 4, 12), DiscriminatorVoxel(7, 6, 128, 12)
-    og = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999))
-    od = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.999))
-    times = []
-    for i in (5, 0, 1):      # first call = untimed warm-up (allocator, thread pool)
-        pz, vz = torch.rand(sz["Np"], 32), torch.rand(sz["Nv"], 32)
-        t = time.perf_counter()
-        train_iteration(G, D, og, od, batch, detach_batch, i, pz, vz, None, None)
-        times.append(time.perf_counter() - t)
-    cycle = times[1] + 4 * times[2]
-    return {"value": round(5 * graphs / cycle, 4), "unit": "voxel-graphs/s", "cores": cores, "kind": "port",
-            "sample": "%d dataset-sized graphs (Nv=%d, Ev=%d); iteration 0 (D+G) %.2fs + 4 x iteration 1 (D) %.2fs; "
-                      "pure-PyTorch CPU oracle, literal per-edge formulation, torch %s"
-                      % (graphs, sz["Nv"], sz["Ev"], times[1], times[2], torch.__version__)}
+
+    def run(threads, warm, timed, budget):
+        torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        G, D = Generator(7, 7, 128, 32, 4, 12), DiscriminatorVoxel(7, 6, 128, 12)
+        og = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        od = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        t_g, t_d = [], []
+        start = time.perf_counter()
+        for i in range(warm + timed):
+            pz, vz = torch.rand(sz["Np"], 32), torch.rand(sz["Nv"], 32)
+            t = time.perf_counter()
+            train_iteration(G, D, og, od, batch, detach_batch, i, pz, vz, None, None)
+            dt = time.perf_counter() - t
+            if i >= warm:
+                (t_g if i % 5 == 0 else t_d).append(dt)
+            if t_g and t_d and time.perf_counter() - start > budget:
+                break
+        cycle = statistics.median(t_g) + 4 * statistics.median(t_d)
+        return 5 * graphs / cycle, statistics.median(t_g), statistics.median(t_d), len(t_g) + len(t_d)
+
+    prev = torch.get_num_threads()
+    cores = _cpu_share()
+    try:
+        v_all, tg, td, n_all = run(cores, 5, 20, budget_s)
+        v_one, tg1, td1, n_one = run(1, 1, 6, budget_s / 2)
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": round(v_all, 4), "unit": "voxel-graphs/s", "cores": cores, "kind": "port",
+            "one_thread_value": round(v_one, 4), "cpu_model": _cpu_model(), "torch": torch.__version__,
+            "timed_iterations": n_all, "timed_iterations_one_thread": n_one,
+            "sample": "%d dataset-sized graph(s) (Nv=%d, Ev=%d, Ec=%d); reference schedule, median of %d timed "
+                      "iterations after 5 warm-ups on %d threads: iteration with G update %.3fs, critic-only %.3fs; "
+                      "1 thread: %.3fs / %.3fs (%d timed); pure-PyTorch CPU oracle, literal per-edge formulation"
+                      % (graphs, sz["Nv"], sz["Ev"], sz["Ec"], n_all, cores, tg, td, tg1, td1, n_one)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--preset", default="dataset")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-microbench", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of hipGraph replay")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------ the workload
+class HipWorkload:
+    """BASELINE.json configs[1] on one rank: a stream of distinct batches through train.Trainer."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    local = local % max(torch.cuda.device_count(), 1)      # rehearsal: several ranks may share one card
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("BG_DIST_BACKEND", "nccl")  # "gloo" only to rehearse the N > 1 path on one GPU
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    from building_gan_amd.plan import build_plan
-    from building_gan_amd.synthetic import batch_sizes, make_batch
-    from building_gan_amd.train import Trainer
-
-    batch = make_batch(args.preset, seed=rank)
-    sz = batch_sizes(batch)
-    batch.to(dev)
-    torch.manual_seed(0)
-    trainer = Trainer(dev)
-    trainer.broadcast_parameters(0)
-    torch.manual_seed(1000 + rank)
-    build_plan(batch)                     # first build also loads the library and warms the allocator
-    batch.__dict__.pop("_bg_plan", None)
-    torch.cuda.synchronize()
-    t_plan = time.perf_counter()
-    build_plan(batch)                     # per-batch index preprocessing (CSR by target/source, segment tables)
-    torch.cuda.synchronize()
-    plan_ms = round((time.perf_counter() - t_plan) * 1e3, 3)
-
-    def sync():
-        torch.cuda.synchronize()
+    def __init__(self, args, rank, world):
+        import torch
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("BG_DIST_BACKEND", "nccl") == "nccl" and world > torch.cuda.device_count():
+            raise SystemExit("bench.py: %d ranks asked for, %d GPUs visible" % (world, torch.cuda.device_count()))
+        local = local % max(torch.cuda.device_count(), 1)      # gloo rehearsal: several ranks may share one card
+        torch.cuda.set_device(local)
+        self.dev = dev = torch.device("cuda", local)
+        self.world, self.rank, self.args = world, rank, args
         if world > 1:
+            backend = os.environ.get("BG_DIST_BACKEND", "nccl")  # "gloo" only to rehearse the N > 1 path on one GPU
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        from building_gan_amd.plan import build_plan
+        from building_gan_amd.synthetic import batch_sizes, make_batch
+        from building_gan_amd.train import Trainer
+        self.build_plan = build_plan
+        # the stream: distinct batches of different shapes (stories, grid, program nodes vary per graph around
+        # the dataset preset), resident in HBM before the timed region starts
+        self.batches = [make_batch(args.preset, seed=1000 * rank + k, ragged="jitter") for k in range(args.batches)]
+        self.sizes = [batch_sizes(b) for b in self.batches]
+        for b in self.batches:
+            b.to(dev)
+        self.fixed = make_batch(args.preset, seed=rank)          # the fixed batch of the replay figure / roofline
+        self.fixed_sz = batch_sizes(self.fixed)
+        self.fixed.to(dev)
+        torch.manual_seed(0)
+        self.trainer = Trainer(dev)
+        self.trainer.broadcast_parameters(0)
+        torch.manual_seed(1000 + rank)
+        build_plan(self.fixed)                    # first build also loads the library and warms the allocator
+        self.graphs_per_step = self.sizes[0]["B"]
+
+    def step(self, i):
+        b = self.batches[i % len(self.batches)]
+        b.__dict__.pop("_bg_plan", None)          # a fresh batch: its index plan is part of the step
+        self.build_plan(b)
+        self.trainer.train_iteration(b, i)
+
+    def sync(self):
+        import torch
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.no_graph:
-        step_fn = lambda it: trainer.train_iteration(batch, it)
+    def max_over_ranks(self, dt):
+        import torch
+        import torch.distributed as dist
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def joined(self):
+        import torch.distributed as dist
+        return dist.get_world_size() if self.world > 1 else 1
+
+    def plan_build_ms(self):
+        import torch
+        b = self.batches[0]
+        ts = []
+        for _ in range(5):
+            b.__dict__.pop("_bg_plan", None)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            self.build_plan(b)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t) * 1e3)
+        return round(statistics.median(ts), 3)
+
+    def replay_best_case(self, steps, warmup):
+        """hipGraph replay of the captured iteration on ONE fixed batch, plan build outside (all ranks)."""
+        tr = self.trainer
+        tr.capture(self.fixed)
+        i = 0
+        for _ in range(warmup):
+            tr.train_iteration_graphed(i)
+            i += 1
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.train_iteration_graphed(i)
+            i += 1
+        self.sync()
+        dt = self.max_over_ranks(time.perf_counter() - t0)
+        return {"value": round(self.fixed_sz["B"] * self.world * steps / dt, 3), "unit": "voxel-graphs/s",
+                "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+                "what": "hipGraph replay of one fixed batch (Nv=%d), plan build outside the timed region"
+                        % self.fixed_sz["Nv"]}
+
+    def config(self):
+        a = self.args
+        n = len(self.sizes)
+        mean = lambda k: round(sum(s[k] for s in self.sizes) / n, 1)
+        return {"workload": "G+D WGAN-GP train step over a stream of %d distinct synthetic 6types-shaped batches per "
+                            "GPU, %d graphs each (stories 8-11, grid 10-14 x 10-14 per graph, 2-6 program nodes per "
+                            "story), plan build + eager launches inside the timed region" % (n, self.sizes[0]["B"]),
+                "preset": a.preset, "graphs_per_gpu": self.sizes[0]["B"], "distinct_batches": n,
+                "Nv_mean": mean("Nv"), "Ev_mean": mean("Ev"), "Ec_mean": mean("Ec"), "Np_mean": mean("Np"),
+                "Nv_min": min(s["Nv"] for s in self.sizes), "Nv_max": max(s["Nv"] for s in self.sizes),
+                "hidden": 128, "voxel_layer": 12, "program_layer": 4, "n_critic_g": 5,
+                "parallelism": "dp%d" % self.world,
+                "launch": "eager kernels + eager RCCL all-reduce of the flat gradient buffers"}
+
+    def extras(self, line):
+        a = self.args
+        plan = self.build_plan(self.fixed)
+        line["roofline"] = roofline_dominant_gemm(self.dev, self.fixed, plan)
+        line["plan_build_ms"] = self.plan_build_ms()
+        if self.world == 1 and not a.no_microbench:
+            line["microbench"] = microbench_message_passing(self.dev)
+        if self.world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+
+    def close(self):
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preset", default="dataset")
+    ap.add_argument("--batches", type=int, default=8, help="distinct batches the timed steps rotate over")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-microbench", action="store_true")
+    ap.add_argument("--no-replay", action="store_true", help="skip the fixed-batch hipGraph replay figure")
+    ap.add_argument("--workload", default=None, metavar="MODULE:CLASS",
+                    help="replace the HIP workload by MODULE:CLASS(args, rank, world) with the same methods "
+                         "(tests/ rehearse the launcher and the timing harness on CPU ranks with it)")
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, argv)              # before anything in this process touches a GPU
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.workload:
+        mod, cls = args.workload.split(":")
+        wl = getattr(importlib.import_module(mod), cls)(args, rank, world)
     else:
-        trainer.capture(batch)
-        step_fn = trainer.train_iteration_graphed
+        wl = HipWorkload(args, rank, world)
+    joined = wl.joined()
+    if joined != args.gpus:
+        raise SystemExit("bench.py: %d ranks joined, --gpus %d" % (joined, args.gpus))
+
     i = 0
     for _ in range(args.warmup):
-        step_fn(i)
+        wl.step(i)
         i += 1
-    sync()
+    wl.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step_fn(i)
+        wl.step(i)
         i += 1
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    wl.sync()
+    dt = wl.max_over_ranks(time.perf_counter() - t0)
+
+    replay = None
+    if not args.no_replay and hasattr(wl, "replay_best_case"):
+        replay = wl.replay_best_case(args.steps, args.warmup)
 
     if rank == 0:
-        graphs = sz["B"] * world * args.steps
+        graphs = wl.graphs_per_step * joined * args.steps
         line = {
             "metric": "voxel-graphs/sec (G+D train step)", "value": round(graphs / dt, 3), "unit": "voxel-graphs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "n_gpus": joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "G+D WGAN-GP train step, %d synthetic 6types-shaped graphs per GPU "
-                                   "(10 stories x 12x12 voxels, 4 program nodes/story)" % sz["B"],
-                       "preset": args.preset, "graphs_per_gpu": sz["B"], "Nv": sz["Nv"], "Ev": sz["Ev"], "Ec": sz["Ec"],
-                       "Np": sz["Np"], "hidden": 128, "voxel_layer": 12, "program_layer": 4,
-                       "n_critic_g": 5, "parallelism": "dp%d" % world,
-                       "launch": "eager" if args.no_graph else "hipGraph segments + eager RCCL all-reduce"},
+            "config": wl.config(),
         }
-        line["roofline"] = roofline_dominant_gemm(dev, batch, build_plan(batch))
-        line["plan_build_ms"] = plan_ms
-        if world == 1 and not args.no_microbench:
-            line["microbench"] = microbench_message_passing(dev)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+        if replay is not None:
+            line["replay_best_case"] = replay
+        wl.extras(line)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    wl.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

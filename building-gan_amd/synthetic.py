@@ -151,14 +151,21 @@ def make_graph(rng: np.random.Generator, stories: int, gx: int, gy: int,
 
 def make_batch(preset: str = "dataset", seed: int = 0, graphs: Optional[int] = None,
                ragged: bool = False, follow_batch=DEFAULT_FOLLOW_BATCH) -> Batch:
-    """A batch of synthetic buildings.  ``ragged`` varies stories / grid / programs per graph."""
+    """A batch of synthetic buildings.  ``ragged`` varies stories / grid / programs per graph: True draws
+    them anywhere up to the preset's size; "jitter" keeps every graph near the preset's size (stories F-2..F+1,
+    grid +-2 cells, 2-6 program nodes per story), i.e. a stream of differently-shaped batches of one scale."""
     B, F, gx, gy = PRESETS[preset]
     if graphs is not None:
         B = graphs
     rng = np.random.default_rng(seed)
     data: List[VolumeDesignGraph] = []
     for g in range(B):
-        if ragged:
+        if ragged == "jitter":
+            f = int(rng.integers(max(1, F - 2), F + 2))
+            x = int(rng.integers(max(1, gx - 2), gx + 3))
+            y = int(rng.integers(max(1, gy - 2), gy + 3))
+            pps = rng.integers(2, 7, size=f).tolist()
+        elif ragged:
             f = int(rng.integers(1, F + 1))
             x = int(rng.integers(max(1, gx // 2), gx + 1))
             y = int(rng.integers(max(1, gy // 2), gy + 1))

@@ -95,16 +95,25 @@ class FlatAdam:
                 torch.cuda.current_stream().synchronize()      # gloo reads the buffer from the host side
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
 
+    def _need_device(self, what):
+        if self.t is None:
+            from ._lib import BganError
+            raise BganError(f"FlatAdam.{what}: the parameters live on {self.flat.device}; the HIP library is the only "
+                            "compute path of building-gan_amd (a CPU Trainer can form gradients, not step)")
+
     def step(self):
+        self._need_device("step")
         self.t_host += 1
         self.t += 1                                # device-side count: valid under hipGraph replay
         ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
                       0, self.t)
 
     def state(self):
+        self._need_device("state")
         return [self.flat.clone(), self.m.clone(), self.v.clone(), self.t.clone(), self.t_host]
 
     def restore(self, st):
+        self._need_device("restore")
         self.flat.copy_(st[0]); self.m.copy_(st[1]); self.v.copy_(st[2]); self.t.copy_(st[3])
         self.t_host = st[4]
 
@@ -361,6 +370,9 @@ class Trainer:
         """
         if self.n_critic_d != 1:
             raise NotImplementedError("graph capture assumes n_critic_d == 1 (the reference default)")
+        if warmup < 1:
+            raise ValueError("capture needs >= 1 eager warm-up iteration (host-side caches such as the critic's "
+                             "+-1/count weights are uploaded there, not inside a stream capture)")
         saved = (self.opt_g.state(), self.opt_d.state())
         counts = global_counts(batch, self.group)
         self._overlap_stream = torch.cuda.Stream() if overlap else None
