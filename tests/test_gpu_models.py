@@ -35,6 +35,44 @@ def _to(noise, dev):
     return [(a.to(dev), b.to(dev)) for a, b in noise]
 
 
+def _assert_grads_close(named_ref, named_hip, bar, what):
+    """max |hip - ref| of every parameter gradient against max(the tensor's own largest gradient, 1e-3 of the
+    network's largest): additive terms of the linear critic have an exactly-zero gradient in exact arithmetic
+    (they shift D(real) and D(fake) alike), which is rounding noise on both sides.  Returns the worst ratio."""
+    refs = [(n, p.grad) for n, p in named_ref]
+    top = max(float(g.abs().max()) for _, g in refs if g is not None)
+    worst = 0.0
+    for (n, g), (_, ph) in zip(refs, named_hip):
+        if g is None:
+            assert ph.grad is None or float(ph.grad.abs().max()) <= 1e-6 * top, (what, n)
+            continue
+        hg = ph.grad.cpu() if ph.grad is not None else torch.zeros_like(g)
+        e = float((hg - g).abs().max()) / max(float(g.abs().max()), 1e-3 * top)
+        assert e <= bar, (what, n, e)
+        worst = max(worst, e)
+    return worst
+
+
+def _assert_adam_steps_agree(named_ref, named_hip, before, lr=1e-4):
+    """After ONE Adam step from identical weights: the first step moves every element by -lr * g / (|g| + eps),
+    i.e. by lr against the gradient's sign, so wherever the reference gradient is not rounding noise (>= 1 % of
+    its tensor's max) both sides must have moved the same way, to 5 % of lr."""
+    checked = 0
+    named_ref = list(named_ref)
+    top = max(float(p.grad.abs().max()) for _, p in named_ref if p.grad is not None)
+    for (n, po), (_, ph) in zip(named_ref, named_hip):
+        g = po.grad
+        if g is None or float(g.abs().max()) < 1e-3 * top:     # rounding noise around an exactly-zero gradient
+            continue
+        sig = g.abs() >= 1e-2 * g.abs().max()
+        do, dh = po.detach() - before[n], ph.detach().cpu() - before[n]
+        assert float(do[sig].abs().min()) >= 0.5 * lr, n      # the oracle did step (|g| may be within ~10x of eps)
+        bad = ((do - dh).abs() > 0.05 * lr) & sig
+        assert int(bad.sum()) == 0, (n, int(bad.sum()), int(sig.sum()))
+        checked += int(sig.sum())
+    assert checked > 0
+
+
 def test_state_dict_keys_match_reference_checkpoint_layout(cuda):
     from building_gan_amd import models as hm
     G = hm.Generator(7, 7, 128, 32, 4, 12, cuda)
@@ -77,10 +115,9 @@ def test_discriminator_forward_backward_parity(cuda, preset, ragged):
     torch.testing.assert_close(sh.cpu(), so, rtol=1e-4, atol=1e-4)
     (bo.sum() + 2 * so.sum()).backward()
     (bh.sum() + 2 * sh.sum()).backward()
-    torch.testing.assert_close(lab_h.grad.cpu(), lab_o.grad, rtol=1e-3, atol=1e-4)
-    for (n, po), (_, ph) in zip(Do.named_parameters(), Dh.named_parameters()):
-        scale = float(po.grad.abs().max()) + 1e-6
-        assert float((ph.grad.cpu() - po.grad).abs().max()) <= 2e-3 * scale, n
+    assert float((lab_h.grad.cpu() - lab_o.grad).abs().max()) <= 1e-4 * float(lab_o.grad.abs().max())
+    # measured 3e-5 (fp32 oracle vs HIP, the oracle itself ~1e-5 from float64: test_gpu_sizes.py)
+    _assert_grads_close(Do.named_parameters(), Dh.named_parameters(), 2e-4, "D")
 
 
 def test_gradient_penalty_double_backward_parity(cuda):
@@ -93,15 +130,11 @@ def test_gradient_penalty_double_backward_parity(cuda):
     soft = torch.rand(sz["Nv"], 6).softmax(-1) * (torch.rand(sz["Nv"], 1) > 0.3).float()
     go, _, _ = gp_o(Do, detach_batch(cpu), cpu.voxel_label, soft, u)
     gh, _, _ = gp_h(Dh, detach_batch(gpu), gpu.voxel_label, soft.to(cuda), u.to(cuda))
-    torch.testing.assert_close(gh.cpu(), go, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(gh.cpu(), go, rtol=1e-5, atol=1e-7)
     go.backward()
     gh.backward()
-    for (n, po), (_, ph) in zip(Do.named_parameters(), Dh.named_parameters()):
-        if po.grad is None:
-            assert ph.grad is None or float(ph.grad.abs().max()) == 0.0, n
-            continue
-        scale = float(po.grad.abs().max()) + 1e-6
-        assert float((ph.grad.cpu() - po.grad).abs().max()) <= 5e-3 * scale, n
+    # measured 4e-7 .. 3e-6 against float64 (test_gpu_sizes.py): north_star's 1e-4 with room to spare
+    _assert_grads_close(Do.named_parameters(), Dh.named_parameters(), 1e-4, "penalty")
 
 
 def test_generator_backward_through_discriminator(cuda):
@@ -115,9 +148,8 @@ def test_generator_backward_through_discriminator(cuda):
     lh = VolumetricDesignLoss_G()(Dh(gpu, out_h), gpu, att_h["hard"], mask_h["hard"], 6)[0]
     lh.backward()
     torch.testing.assert_close(lh.cpu(), lo, rtol=1e-4, atol=1e-4)
-    for (n, po), (_, ph) in zip(Go.named_parameters(), Gh.named_parameters()):
-        scale = float(po.grad.abs().max()) + 1e-6
-        assert float((ph.grad.cpu() - po.grad).abs().max()) <= 1e-2 * scale, n
+    # measured 3e-6 (HIP) / 1e-5 (fp32 oracle) against float64 at this size (test_gpu_sizes.py)
+    _assert_grads_close(Go.named_parameters(), Gh.named_parameters(), 1e-4, "G")
 
 
 def test_program_ratio_parity(cuda):
@@ -144,6 +176,7 @@ def test_trainer_matches_oracle_iterations(cuda):
     tr.discriminator.load_state_dict(Do.state_dict())
     og = torch.optim.Adam(Go.parameters(), lr=1e-4, betas=(0.5, 0.999))
     od = torch.optim.Adam(Do.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    before = {n: p.detach().clone() for n, p in list(Do.named_parameters()) + list(Go.named_parameters())}
     torch.manual_seed(21)
     for i in (0, 1):
         u = torch.rand(sz["Nv"], 1)
@@ -158,13 +191,10 @@ def test_trainer_matches_oracle_iterations(cuda):
             # g_loss is evaluated AFTER the discriminator's first Adam step (a +-lr move per weight whose
             # sign is rounding-sensitive where the gradient is ~0), so it only agrees to ~1e-2
             torch.testing.assert_close(sh["g_loss"].cpu().view(-1), so["g_loss"].view(-1), rtol=1e-2, atol=5e-3)
-    # Adam's first steps move every weight by ~lr regardless of gradient scale: compare updates loosely
-    for (n, po), (_, ph) in zip(list(Do.named_parameters()) + list(Go.named_parameters()),
-                                list(tr.discriminator.named_parameters()) + list(tr.generator.named_parameters())):
-        # (an element whose gradient is rounding noise can step +lr on one side and -lr on the other,
-        #  twice: bound the worst case by 4*lr and the typical case by the mean)
-        diff = (ph.detach().cpu() - po.detach()).abs()
-        assert float(diff.max()) <= 4.5e-4, n
+            # both networks have taken exactly one Adam step and the oracle still holds the gradients it stepped on
+            # (the gradients themselves: test_gpu_sizes.py::test_trainer_flat_gradients_match_oracle)
+            _assert_adam_steps_agree(Do.named_parameters(), tr.discriminator.named_parameters(), before)
+            _assert_adam_steps_agree(Go.named_parameters(), tr.generator.named_parameters(), before)
 
 
 def test_graph_capture_replays_and_restores_state(cuda):
@@ -331,12 +361,7 @@ def test_fused_critic_terms_match_separate_passes_and_oracle_gradients(cuda):
     torch.testing.assert_close(pen_h.cpu(), pen_o, rtol=1e-4, atol=1e-6)
     pen_o.backward()
     pen_h.backward()
-    for (n, po), (_, ph) in zip(Do.named_parameters(), Dh.named_parameters()):
-        if po.grad is None:
-            assert ph.grad is None or float(ph.grad.abs().max()) == 0.0, n
-            continue
-        scale = float(po.grad.abs().max()) + 1e-6
-        assert float((ph.grad.cpu() - po.grad).abs().max()) <= 5e-3 * scale, n
+    _assert_grads_close(Do.named_parameters(), Dh.named_parameters(), 1e-4, "penalty (closed form)")
 
 
 @pytest.mark.parametrize("gan_loss", ["NSGAN", "LSGAN", "hinge"])
@@ -357,14 +382,14 @@ def test_trainer_other_objectives_match_oracle(cuda, gan_loss):
     tr.discriminator.load_state_dict(Do.state_dict())
     og = torch.optim.Adam(Go.parameters(), lr=1e-4, betas=(0.5, 0.999))
     od = torch.optim.Adam(Do.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    before = {n: p.detach().clone() for n, p in list(Do.named_parameters()) + list(Go.named_parameters())}
     so = train_iteration(Go, Do, og, od, cpu, detach_batch, 0, pz, vz, noise, None, gan_loss=gan_loss)
     sh = tr.train_iteration(gpu, 0, pz.to(cuda), vz.to(cuda), _to(noise, cuda), None)
     assert "gp" not in sh
     torch.testing.assert_close(sh["d_loss"].cpu(), so["d_loss"], rtol=5e-3, atol=5e-3)
     torch.testing.assert_close(sh["g_loss"].cpu().view(-1), so["g_loss"].view(-1), rtol=1e-2, atol=5e-3)
-    for (n, po), (_, ph) in zip(list(Do.named_parameters()) + list(Go.named_parameters()),
-                                list(tr.discriminator.named_parameters()) + list(tr.generator.named_parameters())):
-        assert float((ph.detach().cpu() - po.detach()).abs().max()) <= 2.5e-4, n     # one Adam step: <= 2 lr
+    _assert_adam_steps_agree(Do.named_parameters(), tr.discriminator.named_parameters(), before)
+    _assert_adam_steps_agree(Go.named_parameters(), tr.generator.named_parameters(), before)
 
 
 def test_fused_attention_forward_equals_unfused(cuda):
