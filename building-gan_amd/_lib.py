@@ -34,6 +34,7 @@ SIGNATURES = {
                           _i64, _i64, _p],
     "bg_segreduce_sum_f32": [_p, _i64, _p, _p, _p, _p, _p, _int, _p, _i32, _i64, _p, _p, _i64, _i64, _i64, _p],
     "bg_segmax_f32": [_p, _i64, _p, _p, _p, _i32, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _p],
+    "bg_segmax_static_f32": [_p, _i64, _p, _p, _p, _i32, _i64, _p, _i64, _p, _i64, _i64, _p],
     "bg_gather_arg_f32": [_p, _i64, _p, _p, _i64, _i64, _i64, _p],
     "bg_scatter_arg_f32": [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "bg_sddmm_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p],

@@ -231,6 +231,7 @@ const char* bg_error_string(int code) {
         case BG_ERR_SHAPE: return "shape not supported by this kernel";
         case BG_ERR_ALIGN: return "pointer or pitch not 16-byte aligned";
         case BG_ERR_LAUNCH: return "HIP launch / enqueue error";
+        case BG_ERR_SCRATCH: return "request exceeds the library's static scratch buffer (use the entry point that takes a workspace)";
         default: return "unknown error";
     }
 }

@@ -2,6 +2,7 @@
 // segment max with arg, arg gather / scatter, sampled dot products.  HBM-bound: 16-byte gathers,
 // one float4 per lane, rows owned by lane groups (no atomics), slot order = COO order.
 #include "common.h"
+#include <mutex>
 #include <stdlib.h>
 
 namespace {
@@ -952,6 +953,46 @@ int bg_segmax_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int3
                                                                                 n_rows, (int)H, out, ldo, arg);
     BG_LAUNCH_CHECK();
     return BG_OK;
+}
+
+// ---------------------------------------------------------------- segment max without a workspace argument
+// The chunk partials of bg_segmax_f32's two-phase form in memory the library owns: one array per GPU (every
+// device that loads this code object holds its own copy at its own address).  In HOST code the array's name is
+// only a handle for hipGetSymbolAddress -- never a device address -- so the kernels get the looked-up pointer.
+static __device__ __align__(256) unsigned char bg_segmax_scratch[8u * BG_SEGMAX_STATIC_ELEMS];
+
+#define BG_MAX_DEVICES 64
+static void* g_segmax_scratch_ptr[BG_MAX_DEVICES];      // per device, filled on that device's first call
+static std::mutex g_segmax_scratch_mutex;
+
+static int segmax_scratch_for_current_device(void** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BG_MAX_DEVICES) return BG_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(g_segmax_scratch_mutex);
+    if (!g_segmax_scratch_ptr[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(bg_segmax_scratch)) != hipSuccess || !p) return BG_ERR_LAUNCH;
+        g_segmax_scratch_ptr[dev] = p;
+    }
+    *out = g_segmax_scratch_ptr[dev];
+    return BG_OK;
+}
+
+int bg_segmax_static_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                         const int32_t* chunk_ptr, int32_t rows_per_chunk, int64_t n_chunks_ub,
+                         float* out, int64_t ldo, int32_t* arg, int64_t n_rows, int64_t H, bgStream stream) {
+    if (n_rows < 0 || H < 0 || n_chunks_ub < 0) return BG_ERR_ARG;
+    if (n_rows == 0 || H == 0) return BG_OK;
+    if (!chunk_ptr) return BG_ERR_ARG;
+    if (n_chunks_ub > BG_SEGMAX_STATIC_ELEMS || n_chunks_ub * H > (int64_t)BG_SEGMAX_STATIC_ELEMS) return BG_ERR_SCRATCH;
+    void* base = nullptr;
+    int rc = segmax_scratch_for_current_device(&base);
+    if (rc != BG_OK) return rc;
+    // nothing has to start at zero: phase 1 writes every partial that phase 2 reads
+    float* pval = reinterpret_cast<float*>(base);
+    int32_t* parg = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(base) + 4u * BG_SEGMAX_STATIC_ELEMS);
+    return bg_segmax_f32(x, ldx, rowptr, col, chunk_ptr, rows_per_chunk, n_chunks_ub, pval, parg, out, ldo, arg,
+                         n_rows, H, stream);
 }
 
 int bg_gather_arg_f32(const float* x, int64_t ldx, const int32_t* arg, float* out, int64_t ldo,

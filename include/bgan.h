@@ -23,6 +23,7 @@ extern "C" {
 #define BG_ERR_SHAPE (-2)    /* shape not supported by the kernel (see each function)   */
 #define BG_ERR_ALIGN (-3)    /* pointer or pitch not aligned as required                */
 #define BG_ERR_LAUNCH (-4)   /* HIP reported a launch / enqueue error                   */
+#define BG_ERR_SCRATCH (-5)  /* request exceeds the library's static scratch buffer     */
 
 typedef void* bgStream;
 
@@ -178,6 +179,19 @@ int bg_segmax_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int3
                   const int32_t* chunk_ptr, int32_t rows_per_chunk, int64_t n_chunks_ub,
                   float* partial_val, int32_t* partial_arg,
                   float* out, int64_t ldo, int32_t* arg, int64_t n_rows, int64_t H, bgStream stream);
+
+/* bg_segmax_f32's two-phase form for callers that cannot allocate (code under hipGraph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): the chunk partials live in a buffer of BG_SEGMAX_STATIC_ELEMS values +
+ * as many arg entries (8 MiB in all) that the library holds in every GPU's memory until the process ends, so the
+ * call takes no workspace and allocates nothing.  NO COUNTERPART IN THE REFERENCE (its pooling allocates inside
+ * torch_scatter on every call).  n_chunks_ub * H > BG_SEGMAX_STATIC_ELEMS returns BG_ERR_SCRATCH; chunk_ptr is
+ * required (the one-launch form of bg_segmax_f32 needs no workspace to begin with).  Every call on a GPU shares
+ * that GPU's buffer: calls that overlap on one GPU (two streams, two threads) race; calls on one stream do not.
+ * The first call on a device looks the buffer's address up (hipGetSymbolAddress): make it outside stream capture. */
+#define BG_SEGMAX_STATIC_ELEMS (1 << 20)
+int bg_segmax_static_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                         const int32_t* chunk_ptr, int32_t rows_per_chunk, int64_t n_chunks_ub,
+                         float* out, int64_t ldo, int32_t* arg, int64_t n_rows, int64_t H, bgStream stream);
 
 /* out[s,h] = arg[s,h] >= 0 ? x[arg[s,h], h] : 0   (gather along the saved arg-max)
  * replaces: the backward of torch_scatter.scatter_max used by global_max_pool's double backward. */
