@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .graph import detach_batch
-from .losses import VolumetricDesignLoss_G
+from .util_graph import get_program_ratio
 from .models import DiscriminatorVoxel, Generator, position_terms
 from .util import softmax_to_hard
 
@@ -134,7 +134,8 @@ def global_counts(batch, group=None):
 class Trainer:
     def __init__(self, device, hidden_dim=128, noise_dim=32, program_layer=4, voxel_layer=12,
                  g_lr=1e-4, d_lr=1e-4, b1=0.5, b2=0.999, gp_lambda=10.0, n_critic_d=1, n_critic_g=5,
-                 gan_loss="WGANGP", max_len=20, group=None, generator=None, discriminator=None):
+                 gan_loss="WGANGP", max_len=20, group=None, generator=None, discriminator=None,
+                 tr_weight=0.0, far_weight=0.0):
         if gan_loss not in ("WGANGP", "NSGAN", "LSGAN", "hinge"):
             raise TypeError("gan_loss is not valid")          # as reference losses.py:35
         self.gan_loss = gan_loss
@@ -151,7 +152,9 @@ class Trainer:
         # the penalty belongs to WGAN-GP only (reference train.py:92-95)
         self.gp_lambda = gp_lambda if gan_loss == "WGANGP" else 0.0
         self.n_critic_d, self.n_critic_g = n_critic_d, n_critic_g
-        self.g_loss_fn = VolumetricDesignLoss_G(gan_loss=gan_loss)
+        # auxiliary generator losses (reference losses.py:65-68, train_args.py:40-42: both default to 0)
+        self.tr_weight, self.far_weight = float(tr_weight), float(far_weight)
+        self.program_ratio_fn = get_program_ratio      # (graph, att, mask, area column) -> (ratio, program weight, FAR)
         self.group = group
         self._graphs = None
         self._cw_cache = None
@@ -333,12 +336,22 @@ class Trainer:
             p.requires_grad = False
         self.opt_g.detach_grads()
         val_b, val_s = self.discriminator(batch, out)
-        # get_program_ratio runs in every G step although its losses have zero weight (losses.py:65)
-        self.g_loss_fn((val_b, val_s), batch, att["hard"], mask["hard"], 6)
         g_loss = self._g_adversarial(val_b, val_s, Bg, Sg)
+        stats = {"g_adv": g_loss.detach()}
+        # get_program_ratio runs in every G step although its losses have zero weight by default (losses.py:65)
+        ratio, _, far = self.program_ratio_fn(batch, att["hard"], mask["hard"], 6)
+        # smooth_l1_loss means over the 6 B class slots / the B graphs (losses.py:66-67), as local sum / global count
+        if self.tr_weight != 0:
+            tr = self.tr_weight * F.smooth_l1_loss(ratio.flatten(), batch.program_target_ratio, reduction="sum") / \
+                (Bg * (ratio.numel() // max(int(batch.FAR.shape[0]), 1)))
+            g_loss, stats["tr_loss"] = g_loss + tr, tr.detach()
+        if self.far_weight != 0:
+            fl = self.far_weight * F.smooth_l1_loss(far.view(far.shape[0]), batch.FAR, reduction="sum") / Bg
+            g_loss, stats["far_loss"] = g_loss + fl, fl.detach()
         g_loss.backward()
         self.opt_g.collect()
-        return {"g_loss": g_loss.detach()}
+        stats["g_loss"] = g_loss.detach()
+        return stats
 
     # ------------------------------------------------------------------ eager iteration
     def train_iteration(self, batch, i: int, program_z=None, voxel_z=None, noise: Optional[Sequence] = None,

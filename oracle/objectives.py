@@ -69,7 +69,7 @@ def compute_gradient_penalty(Dv, batch, label, out, u: Optional[torch.Tensor] = 
 
 def train_iteration(generator, discriminator, opt_g, opt_d, batch, detach_batch, i: int, program_z, voxel_z,
                     noise: Optional[Sequence], u: Optional[torch.Tensor], n_critic_d: int = 1, n_critic_g: int = 5,
-                    gp_lambda: float = 10.0, gan_loss: str = "WGANGP"):
+                    gp_lambda: float = 10.0, gan_loss: str = "WGANGP", tr_weight: float = 0.0, far_weight: float = 0.0):
     """One iteration of reference train.py:73-114 (index ``i`` inside the epoch)."""
     stats = {}
     for p in discriminator.parameters():
@@ -93,7 +93,7 @@ def train_iteration(generator, discriminator, opt_g, opt_d, batch, detach_batch,
     opt_g.zero_grad()
     if i % n_critic_g == 0:
         validity = discriminator(batch, out)
-        g_loss, _, _, _ = g_loss_fn(validity, batch, att["hard"], mask["hard"], 6, gan_loss)
+        g_loss, _, _, _ = g_loss_fn(validity, batch, att["hard"], mask["hard"], 6, gan_loss, tr_weight, far_weight)
         g_loss.backward()
         opt_g.step()
         stats["g_loss"] = g_loss.detach()

@@ -56,8 +56,9 @@ def _slice(full, lo, hi, pz, vz, noise, u):
 def _trainer():
     from building_gan_amd.train import Trainer
     G, D = _nets()
-    tr = Trainer(torch.device("cpu"), noise_dim=8, generator=G, discriminator=D)
-    tr.g_loss_fn = lambda *a, **k: None          # the auxiliary-ratio pipeline needs the HIP plan
+    tr = Trainer(torch.device("cpu"), noise_dim=8, generator=G, discriminator=D, tr_weight=1.0, far_weight=0.5)
+    from oracle.pointer import get_program_ratio
+    tr.program_ratio_fn = get_program_ratio      # the HIP pipeline needs a GPU plan
     return tr
 
 

@@ -186,8 +186,9 @@ def _flat_to_named(opt, module):
             for n, p, off in zip(names, opt.params, opt.offsets)}
 
 
-@pytest.mark.parametrize("preset,graphs", [("small", None), ("dataset", 2)])
-def test_trainer_flat_gradients_match_oracle(cuda, preset, graphs):
+@pytest.mark.parametrize("preset,graphs,aux", [("small", None, (0.0, 0.0)), ("dataset", 2, (0.0, 0.0)),
+                                               ("small", None, (1.0, 1.0))])
+def test_trainer_flat_gradients_match_oracle(cuda, preset, graphs, aux):
     """The composition the iteration tests could not see (fused critic_terms -> CriticLoss -> FlatAdam.collect, and
     the generator phase through the frozen critic): the flat buffers handed to Adam / the all-reduce against the
     oracle's .grad after d_loss.backward() and g_loss.backward() (reference train.py:98-100, 111-113), no
@@ -199,14 +200,14 @@ def test_trainer_flat_gradients_match_oracle(cuda, preset, graphs):
     cpu = make_batch(preset, seed=61, graphs=graphs, ragged=True if preset == "small" else "jitter")
     sz = batch_sizes(cpu)
     Go, Do, _, _ = _nets(cuda, seed=61)
-    tr = Trainer(cuda)
+    tr = Trainer(cuda, tr_weight=aux[0], far_weight=aux[1])       # auxiliary losses: reference losses.py:65-68
     tr.generator.load_state_dict(Go.state_dict())
     tr.discriminator.load_state_dict(Do.state_dict())
     torch.manual_seed(61)
     noise, pz, vz, u = _noise(sz), torch.rand(sz["Np"], 32), torch.rand(sz["Nv"], 32), torch.rand(sz["Nv"], 1)
     # oracle: one iteration with lr = 0 optimizers, so .grad holds what backward() left and no weight moves
     og, od = torch.optim.SGD(Go.parameters(), lr=0.0), torch.optim.SGD(Do.parameters(), lr=0.0)
-    so = train_iteration(Go, Do, og, od, cpu, detach_batch, 0, pz, vz, noise, u)
+    so = train_iteration(Go, Do, og, od, cpu, detach_batch, 0, pz, vz, noise, u, tr_weight=aux[0], far_weight=aux[1])
     gpu = copy.deepcopy(cpu).to(cuda)
     counts = global_counts(gpu)
     gen, sh = tr._phase_d(gpu, counts, True, pz.to(cuda), vz.to(cuda), _to(noise, cuda), u.to(cuda))
@@ -229,12 +230,36 @@ def test_trainer_flat_gradients_match_oracle(cuda, preset, graphs):
         worst[tag] = max(errs.items(), key=lambda kv: kv[1])
         for n, e in errs.items():
             assert e <= TRAINER_GRAD_BAR[tag], (tag, n, e)
-    print("%s: worst flat-gradient error vs the fp32 oracle %s" % (preset, worst))
+    if aux[0]:
+        assert float(sh["tr_loss"]) > 0 and float(sh["far_loss"]) > 0
+    print("%s aux=%s: worst flat-gradient error vs the fp32 oracle %s" % (preset, aux, worst))
 
 
 # measured on MI355X (pytest -s), error / max(tensor's max gradient, 1e-3 of the network's max), against the FP32
 # oracle: see DESIGN.md section 2 for the numbers; the bars are <= 10x the measured values
 TRAINER_GRAD_BAR = {"D": 1e-3, "G": 1e-3}
+
+
+def test_program_ratio_backward_parity(cuda):
+    """get_program_ratio (reference util_graph.py:21-41) differentiated: gradients of a weighted sum of its three
+    outputs with respect to the attention and the mask against the oracle's autograd."""
+    from building_gan_amd.synthetic import batch_sizes, make_batch
+    from building_gan_amd.util_graph import get_program_ratio as h
+    from oracle.pointer import get_program_ratio as o
+    cpu = make_batch("small", seed=15, ragged=True)
+    sz = batch_sizes(cpu)
+    gpu = copy.deepcopy(cpu).to(cuda)
+    torch.manual_seed(15)
+    att, mask = torch.rand(sz["Ec"], 1), torch.rand(sz["Nv"], 1)
+    w = [torch.rand(6 * sz["B"], 1), torch.rand(sz["Np"], 1), torch.rand(sz["B"], 1)]
+    ao, mo = att.clone().requires_grad_(True), mask.clone().requires_grad_(True)
+    ah, mh = att.to(cuda).requires_grad_(True), mask.to(cuda).requires_grad_(True)
+    ro, rh = o(cpu, ao, mo, 6), h(gpu, ah, mh, 6)
+    for a, b in zip(rh, ro):
+        torch.testing.assert_close(a.detach().cpu(), b.detach(), rtol=1e-5, atol=1e-7)
+    sum((r * wi).sum() for r, wi in zip(ro, w)).backward()
+    sum((r * wi.to(cuda)).sum() for r, wi in zip(rh, w)).backward()
+    assert _rel(ah.grad.cpu(), ao.grad) <= 1e-5 and _rel(mh.grad.cpu(), mo.grad) <= 1e-5
 
 
 def _batch64(b):
