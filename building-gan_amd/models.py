@@ -423,6 +423,7 @@ class VoxelGNN_D(nn.Module):
         self.block = VoxelBlock(2 * hidden_dim, if_agg_story_in_update=False)
         self._share_coef = False      # see DiscriminatorVoxel.shared_coefficients
         self._coef_cache = None
+        self.collapse_ok = True       # cleared by DiscriminatorVoxel.guard_collapse when the polynomial form is ill-conditioned
 
     # ---- collapsed evaluation ---------------------------------------------------------------------
     # Neither messageMLP nor updateMLP of the discriminator's block has an activation (reference
@@ -512,6 +513,27 @@ class VoxelGNN_D(nn.Module):
         Ts, Tl = ops.PolyCoef.apply(Wc, X0, E, L).view(L + 1, du, H2).split([ds, dl], dim=1)
         return torch.cat([Ts.reshape(-1, H2), Tl.reshape(-1, H2)], dim=0)
 
+    def collapse_amplification(self, feat, l, plan, pdm4, sample: int = 2048):
+        """How much the collapsed evaluation v_L = [Zs | Zl] W amplifies fp32 rounding on THIS batch with the
+        CURRENT parameters: max over output columns of  max_i (|Z| |W|)_io / max_i |Z W|_io  on a strided sample
+        of the voxel rows -- the classical bound on a product's rounding error is eps * (|Z| |W|), so the
+        collapsed form's error relative to a column's largest activation is ~ eps * this number (device scalar; no
+        host sync).  It grows with ||I + Wa|| ^ L when terms of the polynomial cancel: see DiscriminatorVoxel.guard_collapse."""
+        L = self.layer_num
+        with torch.no_grad():
+            Zs = self._static_powers(plan, feat, pdm4)
+            ds = Zs.shape[1] // (L + 1)
+            dl = (l.shape[1] + 3) // 4 * 4
+            W = self.coefficients(feat.shape[1], ds, dl)
+            Zl = torch.zeros(l.shape[0], L + 1, dl, device=l.device)
+            Zl[:, 0, :l.shape[1]] = l.detach()
+            ops.power_chain_raw(plan.vox_mean, Zl, L, dl, plan.vox_blocks)
+            step = max(1, feat.shape[0] // sample)
+            Z = torch.cat([Zs[::step], Zl.view(Zl.shape[0], -1)[::step]], dim=1).contiguous()
+            v = linear([Z], W, w_t=True)
+            bound = linear([Z.abs()], W.abs().contiguous(), w_t=True)
+            return (bound.amax(0) / v.abs().amax(0).clamp_min(1e-30)).amax()
+
     def forward_collapsed(self, feat, l, plan, pdm4):
         L = self.layer_num
         Zs = self._static_powers(plan, feat, pdm4)
@@ -545,7 +567,7 @@ class VoxelGNN_D(nn.Module):
     def forward(self, v, l, plan):
         pos, v = extract_pos(v)
         pdm4 = _pos_terms(plan, pos)
-        if COLLAPSE_D and COMPOSE_BLOCKS and plan.vox_all_has and self.layer_num > 0:
+        if COLLAPSE_D and self.collapse_ok and COMPOSE_BLOCKS and plan.vox_all_has and self.layer_num > 0:
             return self.forward_collapsed(v, l, plan, pdm4)
         v = run_mlp(self.feature_enc, v)
         v = v + ops.spmm_raw(_level_op(plan, self.pe.shape[0]), self.pe)
@@ -632,7 +654,7 @@ class DiscriminatorVoxel(nn.Module):
         grads[:, 0] / grads[:, 1] are grad_b / grad_s zero-padded to dl columns."""
         plan = build_plan(graph)
         gnn = self.voxelGNN_D
-        if not (COLLAPSE_D and COMPOSE_BLOCKS and plan.vox_all_has and gnn.layer_num > 0):
+        if not (COLLAPSE_D and gnn.collapse_ok and COMPOSE_BLOCKS and plan.vox_all_has and gnn.layer_num > 0):
             return None
         pos, feat = extract_pos(graph.voxel_feature)
         pdm4 = _pos_terms(plan, pos)
@@ -676,13 +698,34 @@ class DiscriminatorVoxel(nn.Module):
         grad_b, _, grad_s, _ = acc.split([n_lab, dl - n_lab, n_lab, dl - n_lab], dim=1)
         return (*out, grad_b, grad_s)
 
+    # fp32 error of the collapsed form relative to a column's largest activation ~ 2^-24 * amplification (measured:
+    # tests/test_gpu_models.py::test_collapsed_discriminator_guard); beyond this bound the polynomial form would lose
+    # more than north_star's 1e-4 and the layer-by-layer stack (ops.AffineStack: the reference's own evaluation order)
+    # takes over until a later check finds the parameters back inside
+    COLLAPSE_AMPLIFICATION_LIMIT = 1e-4 / 2.0 ** -24 / 8.0
+
+    def guard_collapse(self, graph, label=None) -> float:
+        """Runtime guard of the collapsed (polynomial) evaluation: measure its rounding amplification on this batch
+        with the current parameters (one small product on <= 2,048 sampled voxels; ONE host read, so call it every
+        few hundred optimizer steps -- train.Trainer does, `collapse_check_every`) and switch the discriminator
+        between the collapsed form and the layer-by-layer stack accordingly.  Returns the amplification."""
+        plan = build_plan(graph)
+        gnn = self.voxelGNN_D
+        if not (COLLAPSE_D and COMPOSE_BLOCKS and plan.vox_all_has and gnn.layer_num > 0):
+            return 0.0
+        pos, feat = extract_pos(graph.voxel_feature)
+        label = graph.voxel_label if label is None else label
+        amp = float(gnn.collapse_amplification(feat, label, plan, _pos_terms(plan, pos)))
+        gnn.collapse_ok = amp == amp and amp <= self.COLLAPSE_AMPLIFICATION_LIMIT        # NaN -> stack
+        return amp
+
     def prepare(self, graph, n_label: int = NUMBER_OF_CLASS):
         """Inside shared_coefficients(): build what the collapsed passes share and that depends on
         the graph and the parameters only (operator powers of the label-free columns, coefficient
         table), e.g. on a side stream while the generator runs."""
         plan = build_plan(graph)
         gnn = self.voxelGNN_D
-        if not (COLLAPSE_D and COMPOSE_BLOCKS and plan.vox_all_has and gnn.layer_num > 0 and gnn._share_coef):
+        if not (COLLAPSE_D and gnn.collapse_ok and COMPOSE_BLOCKS and plan.vox_all_has and gnn.layer_num > 0 and gnn._share_coef):
             return
         pos, feat = extract_pos(graph.voxel_feature)
         Zs = gnn._static_powers(plan, feat, _pos_terms(plan, pos))

@@ -135,7 +135,7 @@ class Trainer:
     def __init__(self, device, hidden_dim=128, noise_dim=32, program_layer=4, voxel_layer=12,
                  g_lr=1e-4, d_lr=1e-4, b1=0.5, b2=0.999, gp_lambda=10.0, n_critic_d=1, n_critic_g=5,
                  gan_loss="WGANGP", max_len=20, group=None, generator=None, discriminator=None,
-                 tr_weight=0.0, far_weight=0.0):
+                 tr_weight=0.0, far_weight=0.0, collapse_check_every=200):
         if gan_loss not in ("WGANGP", "NSGAN", "LSGAN", "hinge"):
             raise TypeError("gan_loss is not valid")          # as reference losses.py:35
         self.gan_loss = gan_loss
@@ -155,6 +155,10 @@ class Trainer:
         # auxiliary generator losses (reference losses.py:65-68, train_args.py:40-42: both default to 0)
         self.tr_weight, self.far_weight = float(tr_weight), float(far_weight)
         self.program_ratio_fn = get_program_ratio      # (graph, att, mask, area column) -> (ratio, program weight, FAR)
+        # every so many eager iterations the discriminator re-measures the rounding amplification of its collapsed
+        # (polynomial) evaluation under the current parameters and falls back to the layer-by-layer stack when it
+        # would lose more than the fp32 tolerance (models.DiscriminatorVoxel.guard_collapse; one host read)
+        self.collapse_check_every = collapse_check_every
         self.group = group
         self._graphs = None
         self._cw_cache = None
@@ -359,6 +363,9 @@ class Trainer:
         """Iteration ``i`` of an epoch (reference train.py:74-114).  Returns a dict of detached losses."""
         counts = global_counts(batch, self.group)
         do_d = i % self.n_critic_d == 0
+        if (self.collapse_check_every and i % self.collapse_check_every == 0 and hasattr(self.discriminator, "guard_collapse")
+                and batch.voxel_feature.is_cuda and not torch.cuda.is_current_stream_capturing()):
+            self.discriminator.guard_collapse(batch)
         gen, stats = self._phase_d(batch, counts, do_d, program_z, voxel_z, noise, u, g_update=i % self.n_critic_g == 0)
         if do_d:
             self.opt_d.all_reduce(self.group)

@@ -335,6 +335,92 @@ def test_collapsed_discriminator_accuracy_against_fp64(cuda):
     assert errs["collapsed"][0] <= 1e-4 and errs["collapsed"][1] <= 1e-3 and errs["collapsed"][2] <= 2e-3
 
 
+def _highpass_block(D, t):
+    """Blend the discriminator's block towards v <- v - A v (updateMLP = [0 | I], messageMLP = [0 | -I | 0]):
+    v_L = (I - A)^L v_0 is a sum of binomially weighted operator powers that cancel on smooth inputs -- benign layer by
+    layer, ill-conditioned as a polynomial."""
+    blk = D.voxelGNN_D.block
+    H2 = blk.updateMLP[0].weight.shape[0]
+    eye = torch.eye(H2)
+    with torch.no_grad():
+        Wu, Wm = blk.updateMLP[0].weight, blk.messageMLP[0].weight
+        Wu.mul_(1 - t).add_(t * torch.cat([torch.zeros(H2, H2), eye], 1).to(Wu.device))
+        Wm.mul_(1 - t).add_(t * torch.cat([torch.zeros(H2, H2), -eye, torch.zeros(H2, 3)], 1).to(Wm.device))
+        blk.updateMLP[0].bias.mul_(1 - t)
+        blk.messageMLP[0].bias.mul_(1 - t)
+
+
+def test_collapsed_discriminator_guard(cuda):
+    """(i) the collapsed evaluation stays as accurate as the layer-by-layer stack when the
+    block weights grow (x1 .. x8; both measured against the oracle in float64) and the guard leaves it on;
+    (ii) on weights that make the polynomial cancel (a high-pass block) the guard's amplification estimate exceeds
+    its limit, the discriminator switches to the stack, and its result stays within the fp32 tolerance where the
+    forced collapsed form does not; (iii) the Trainer runs the guard and keeps training on the stack."""
+    from building_gan_amd import models as hm
+    from building_gan_amd.plan import build_plan
+    from building_gan_amd.train import Trainer
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("dataset", 33, "jitter", cuda)
+    cpu64 = copy.deepcopy(cpu)
+    cpu64.voxel_feature = cpu64.voxel_feature.double()
+    init = copy.deepcopy(Do.state_dict())
+
+    def errors(Dref):
+        D64 = copy.deepcopy(Dref).double()
+        Dh.load_state_dict(Dref.state_dict())
+        with torch.no_grad():
+            v64 = D64.voxelGNN_D(cpu64.voxel_feature, cpu.voxel_label.double(), cpu.voxel_edge, cpu.voxel_feature_batch,
+                                 cpu.voxel_floor_cluster, cpu.voxel_feature_batch)
+            out = {}
+            for name, flag in (("collapsed", True), ("stack", False)):
+                hm.COLLAPSE_D = flag
+                try:
+                    gpu.__dict__.pop("_bg_plan", None)
+                    Dh.voxelGNN_D.collapse_ok = True
+                    v = Dh.voxelGNN_D(gpu.voxel_feature, gpu.voxel_label, build_plan(gpu)).cpu().double()
+                finally:
+                    hm.COLLAPSE_D = True
+                out[name] = float(((v - v64).abs().amax(0) / v64.abs().amax(0)).max())
+            amp = Dh.guard_collapse(gpu)
+        return out, amp, v64
+
+    for scale in (1, 2, 4, 8):
+        Do.load_state_dict(init)
+        with torch.no_grad():
+            for p in Do.voxelGNN_D.block.parameters():
+                p.mul_(scale)
+        e, amp, _ = errors(Do)
+        print("block weights x%d: amplification %.1f; error / column max vs float64: collapsed %.2e, stack %.2e" %
+              (scale, amp, e["collapsed"], e["stack"]))
+        assert Dh.voxelGNN_D.collapse_ok and amp <= Dh.COLLAPSE_AMPLIFICATION_LIMIT
+        assert e["collapsed"] <= 2e-5 and e["collapsed"] <= 2 * e["stack"]          # measured 1.4e-6 .. 4.3e-6
+    # (ii) a block that makes the polynomial cancel
+    Do.load_state_dict(init)
+    _highpass_block(Do, 1.0)
+    e, amp, v64 = errors(Do)
+    print("high-pass block: amplification %.3e (limit %.1f); error / column max vs float64: collapsed %.2e, stack %.2e" %
+          (amp, Dh.COLLAPSE_AMPLIFICATION_LIMIT, e["collapsed"], e["stack"]))
+    assert amp > Dh.COLLAPSE_AMPLIFICATION_LIMIT and not Dh.voxelGNN_D.collapse_ok
+    assert e["stack"] <= 1e-4 and e["collapsed"] > e["stack"]
+    with torch.no_grad():                                        # guarded: the default path now IS the stack
+        v = Dh.voxelGNN_D(gpu.voxel_feature, gpu.voxel_label, build_plan(gpu)).cpu().double()
+        assert float(((v - v64).abs().amax(0) / v64.abs().amax(0)).max()) <= 1e-4
+        assert Dh.critic_terms(gpu, gpu.voxel_label, gpu.voxel_label) is None     # the fused pass steps aside too
+    # back inside: the guard switches the collapsed form on again
+    Do.load_state_dict(init)
+    Dh.load_state_dict(init)
+    Dh.guard_collapse(gpu)
+    assert Dh.voxelGNN_D.collapse_ok
+    # (iii) the trainer
+    tr = Trainer(cuda, collapse_check_every=2)
+    tr.discriminator.load_state_dict(Do.state_dict())
+    s0 = tr.train_iteration(gpu, 1)
+    assert tr.discriminator.voxelGNN_D.collapse_ok
+    _highpass_block(tr.discriminator, 1.0)
+    s1 = tr.train_iteration(gpu, 2)                              # i % 2 == 0: guard runs, stack takes over
+    assert not tr.discriminator.voxelGNN_D.collapse_ok
+    assert torch.isfinite(s1["d_loss"]).all() and torch.isfinite(tr.opt_d.grad).all()
+
+
 def test_fused_critic_terms_match_separate_passes_and_oracle_gradients(cuda):
     """critic_terms (one pass for D(real), D(fake) and the closed-form penalty gradients) against the
     oracle's three separate passes with torch.autograd.grad (reference losses.py:83-84)."""
