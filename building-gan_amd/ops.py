@@ -914,6 +914,28 @@ class SharedGrads:
 
     def __init__(self):
         self.buf = {}
+        self._armed = False
+
+    def enter(self):
+        """Backward: a node that shares these buffers runs.  Only the first call's node hands the sums to autograd
+        (the calls chain through the voxel features, which makes it the last to run), so whatever a backward pass
+        accumulates must have been handed over when the pass ends -- otherwise weight gradients would be dropped
+        without a word (the chain was cut by a detach, or a backward restricted by ``inputs=`` stopped short of the
+        first call).  A call whose output is not used (the generator's last block call, reference
+        models.py:196-203) simply does not run and contributes nothing, correctly."""
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+
+    def _end_of_backward(self):
+        left = sorted(self.buf)
+        self.buf.clear()
+        self._armed = False
+        if left:
+            raise _lib.BganError("shared weight gradients: this backward pass accumulated " + ", ".join(left) +
+                                 " but never reached the first call's node, which hands them to autograd; the "
+                                 "gradients would have been dropped (set models.SHARE_WEIGHT_GRADS = False for "
+                                 "partial backward passes)")
 
     def slot(self, key, like: torch.Tensor):
         """(buffer, accumulate): the first request of a backward pass creates the buffer (to be overwritten)."""
@@ -968,6 +990,8 @@ class AttentionNode(torch.autograd.Function):
     def backward(ctx, g_soft0, g_hard0, g_soft, g_hard, g_out):
         lib = _lib.load()
         v, x, b, a, Wcat, theta, soft0, soft = ctx.saved_tensors
+        if ctx.shared is not None:
+            ctx.shared.enter()
         plan = ctx.plan
         cv = plan.cross_v
         N, H = v.shape
@@ -1096,6 +1120,8 @@ class GBlock(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         v, gm, y, Wc, Wsb, pdm4 = ctx.saved_tensors
+        if ctx.shared is not None:
+            ctx.shared.enter()
         plan = ctx.plan
         H = v.shape[1]
         g = _f32c(g)

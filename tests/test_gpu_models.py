@@ -601,6 +601,56 @@ def test_shared_weight_gradient_buffers_equal_autograd_sums(cuda):
         assert float((a - b).abs().max()) <= 2e-5 * scale, n
 
 
+def test_shared_weight_gradient_buffers_fail_loudly_on_partial_backward(cuda):
+    """the first call's node hands the shared buffers to autograd.  A second backward over a retained
+    graph and torch.autograd.grad restricted to one parameter must give the same numbers as the plain backward; a
+    backward that stops short of the first call (inputs = an intermediate activation) or a chain cut by a detach
+    must raise instead of dropping the accumulated weight gradients."""
+    from building_gan_amd import models as hm, ops
+    from building_gan_amd._lib import BganError
+    from building_gan_amd.plan import build_plan
+    cpu, gpu, sz, *_ = _setup("small", 56, True, cuda)
+    plan = build_plan(gpu)
+    torch.manual_seed(56)
+    blk = hm.VoxelBlock(128, if_agg_story_in_update=True).to(cuda)
+    pdm4 = hm.position_terms(gpu)
+    v0 = torch.rand(sz["Nv"], 128, device=cuda) * 2 - 1
+    w = torch.rand(sz["Nv"], 128, device=cuda) * 2 - 1
+
+    def chain(cut=False):
+        sg = ops.SharedGrads()
+        comp = blk.compose()
+        v = v0.clone().requires_grad_(True)
+        mids = [v]
+        for i in range(3):
+            v = blk.forward_composed(v, plan, pdm4, comp, (sg, i == 0))
+            if cut and i == 0:
+                v = v.detach().requires_grad_(True)
+            mids.append(v)
+        return (v * w).sum(), mids
+
+    loss, _ = chain()
+    for p in blk.parameters():
+        p.grad = None
+    loss.backward(retain_graph=True)
+    first = [p.grad.clone() for p in blk.parameters()]
+    for p in blk.parameters():
+        p.grad = None
+    loss.backward()                                            # second pass over the retained graph
+    for a, b in zip(first, [p.grad for p in blk.parameters()]):
+        assert torch.equal(a, b)
+    loss, _ = chain()
+    Wm = blk.messageMLP[0].weight
+    (only,) = torch.autograd.grad(loss, [Wm])                  # restricted to one parameter
+    assert torch.equal(only, first[[id(p) for p in blk.parameters()].index(id(Wm))])
+    loss, mids = chain()
+    with pytest.raises(BganError, match="shared weight gradients"):
+        torch.autograd.grad(loss, [mids[2]])                   # stops before the first call's node
+    loss, _ = chain(cut=True)
+    with pytest.raises(BganError, match="shared weight gradients"):
+        loss.backward()                                        # the first call is cut off from the loss
+
+
 def test_coefficient_inputs_by_one_launch_equal_cat_construction(cuda):
     """ops.PolyCoefD (X0 / E written into the recurrence's buffers by bg_d_coef_init_f32, parameter gradients
     read out by bg_d_coef_init_bwd_f32) against the cat / transpose construction feeding ops.PolyCoef: the
