@@ -67,8 +67,28 @@ SIGNATURES = {
                     _p, _p, _i64, _p, _i64, _p],
     "bg_gemm_tn_splitk_f32": [_i64, _i64, _p, _i64, _int, _p, _p, _p, _p, _i64, _p, _i32, _int, _p],
     "bg_colsum_f32": [_p, _i64, _i64, _i64, _p, _i32, _p, _int, _p],
+    "bg_generator_forward_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
     "bg_adam_f32": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i32, _p, _p],
 }
+
+_fp = C.c_void_p      # device pointers travel as integers
+
+
+class GeneratorWeights(C.Structure):
+    """include/bgan.h: bgGeneratorWeights (field order is the ABI)."""
+    _fields_ = [(n, _i64) for n in ("H", "noise_dim", "program_layer", "voxel_layer", "n_class", "max_len")] + \
+               [(n, _fp) for n in ("p_enc_w", "p_enc_b", "p_msg_w", "p_msg_b", "p_upd_w", "p_upd_b", "v_enc_w", "v_enc_b",
+                                   "pe", "Wc")] + [("ldwc", _i64)] + \
+               [(n, _fp) for n in ("bc", "Wsb", "Wcat", "bcat", "nnp_w", "nnp_b", "theta")]
+
+
+class GeneratorPlan(C.Structure):
+    """include/bgan.h: bgGeneratorPlan."""
+    _fields_ = [(n, _i64) for n in ("Np", "Nv", "S", "Ec", "cx_max_len", "vox_all_has")] + \
+               [(n, _fp) for n in ("pp_rowptr", "pp_col", "pp_scale", "prog_has", "vx_rowptr", "vx_col", "vx_count",
+                                   "st_rowptr", "st_col", "st_count", "story_of_voxel", "sb_rowptr", "sb_col", "sb_count",
+                                   "level", "cx_rowptr", "cx_col")]
+
 
 _lib: Optional[C.CDLL] = None
 
@@ -91,6 +111,15 @@ def load() -> C.CDLL:
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.bg_version.restype = C.c_int
+    lib.bg_generator_forward_workspace.restype = C.c_int64
+    lib.bg_generator_forward_workspace.argtypes = [_i64] * 5
+    lib.bg_abi_sizeof.restype = C.c_int64
+    lib.bg_abi_sizeof.argtypes = [C.c_int]
+    for which, st in enumerate((GeneratorWeights, GeneratorPlan)):
+        if lib.bg_abi_sizeof(which) != C.sizeof(st):
+            raise BganError(f"{LIB_PATH} was built from another revision of include/bgan.h ({st.__name__}: "
+                            f"{lib.bg_abi_sizeof(which)} bytes there, {C.sizeof(st)} here): rebuild it "
+                            "(`make -C building-gan_amd/csrc`)")
     lib.bg_error_string.restype = C.c_char_p
     lib.bg_error_string.argtypes = [C.c_int]
     _lib = lib

@@ -38,6 +38,7 @@ FUSE_OUTPUT = True     # construct_output as one launch when no autograd graph i
 FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is being built
 FUSE_POS_TERM = True      # generator: position columns x weight + bias once per forward, the 12 products start from it
 FUSE_COEF_INPUTS = True   # collapsed discriminator: the recurrence's parameter rows by one launch (ops.PolyCoefD)
+FUSE_GENERATOR_FORWARD = True   # graph-free Generator.forward as ONE host call (bg_generator_forward_f32)
 COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
 
 
@@ -593,8 +594,104 @@ class Generator(nn.Module):
         self.programGNN = ProgramGNN(program_input_dim, hidden_dim, noise_dim, program_layer)
         self.voxelGNN = VoxelGNN_G(voxel_input_dim, hidden_dim, 0, voxel_layer, max_len)
 
+    def _forward_one_call(self, graph, plan, program_z, noise, derived):
+        """The graph-free forward through bg_generator_forward_f32: the same launches as the op-by-op path below,
+        issued by one host call.  None when a condition of that entry point does not hold (the caller then runs the
+        op-by-op path)."""
+        from . import _lib
+        import ctypes as C
+        gnn, att, pg = self.voxelGNN, self.voxelGNN.attention, self.programGNN
+        H, L = self.hidden_dim, gnn.layer_num
+        ops_ = plan.ops
+        if not (COMPOSE_BLOCKS and FUSE_STORY_TERM and FUSE_PROGRAM_BLOCK and FUSE_OUTPUT and FUSE_ATTENTION and FUSE_POS_TERM
+                and plan.vox_all_has and 0 < plan.cross_v.max_len <= 64 and H % 64 == 0 and H <= 256 and L >= 1
+                and 0 < plan.Nv <= FUSE_GATHER_STORY_MAX_ROWS and plan.Np > 0 and "story_building_mean" in ops_
+                and "prog_pair" in ops_ and gnn.noise_dim == 0 and gnn.block.if_agg_story_in_update
+                and ops_["flags"]["cross_by_voxel"][1] == 0 and graph.program_class_feature.shape[1] <= 8
+                and plan.ops["max_level"] < gnn.pe.shape[0] and len(pg.enc) == 1 and len(gnn.enc) == 1):
+            return None
+        if derived is None:
+            derived = gnn.derived_weights()
+        Wc, bc, Wsb, Wcat, bcat = derived
+        if Wcat is None or Wc.stride(1) != 1 or not (bc.is_contiguous() and Wsb.is_contiguous() and Wcat.is_contiguous()
+                                                     and bcat.is_contiguous()):
+            return None
+        dev = graph.voxel_feature.device
+        n_cls = graph.program_class_feature.shape[1]
+        pos, v4 = extract_pos(graph.voxel_feature)
+        pdm4 = _pos_terms(plan, pos)
+        program_in = torch.cat([graph.program_class_feature, graph.story_level_feature.view(-1, 1), program_z], dim=-1)
+        if program_in.dtype != torch.float32 or v4.dtype != torch.float32:
+            return None
+        n_calls = 1 + sum(1 for i in range(L) if i % 2 == 0 and i != 0)
+        Nv, Ec = plan.Nv, plan.Ec
+        if noise is None:
+            per = 2 * Nv + (Ec + 3) // 4 * 4
+            flat = torch.empty(n_calls * per, dtype=torch.float32, device=dev).exponential_()
+            base = flat.data_ptr()
+            em_ptrs = [base + 4 * c * per for c in range(n_calls)]
+            ea_ptrs = [base + 4 * (c * per + 2 * Nv) for c in range(n_calls)]
+            keep = flat
+        else:
+            noise = list(noise)
+            if len(noise) < n_calls:
+                return None
+            keep = [(ops._f32c(a).contiguous(), ops._f32c(b.reshape(-1)).contiguous()) for a, b in noise[:n_calls]]
+            if any(tuple(a.shape) != (Nv, 2) or b.numel() != Ec for a, b in keep):
+                raise _lib.BganError("generator: noise must hold one ([Nv, 2], [Ec]) pair per Attention call")
+            em_ptrs, ea_ptrs = [a.data_ptr() for a, _ in keep], [b.data_ptr() for _, b in keep]
+        lib = _lib.load()
+        ps = ops_.get("_generator_plan_struct")
+        if ps is None:
+            pp, vx, st, sb, cx = (ops_["prog_pair"], plan.vox_mean, plan.story_seg, ops_["story_building_mean"], plan.cross_v)
+            P = _lib.ptr
+            ps = _lib.GeneratorPlan(plan.Np, Nv, plan.S, Ec, cx.max_len, 1,
+                                    P(pp.csr.rowptr), P(pp.csr.col), P(pp.row_scale), P(plan.prog_has),
+                                    P(vx.csr.rowptr), P(vx.csr.col), P(vx.row_scale),
+                                    P(st.rowptr), P(st.col), P(st.count), P(plan.story_gather.csr.col),
+                                    P(sb.csr.rowptr), P(sb.csr.col), P(sb.row_scale), P(plan.level),
+                                    P(cx.rowptr), P(cx.col))
+            ops_["_generator_plan_struct"] = ps
+        penc, venc, blk = pg.enc[0], gnn.enc[0], pg.block
+        tensors = [penc.weight, penc.bias, blk.messageMLP[0].weight, blk.messageMLP[0].bias, blk.updateMLP[0].weight,
+                   blk.updateMLP[0].bias, venc.weight, venc.bias, gnn.pe, Wc, bc, Wsb, Wcat, bcat, att.NN_p.weight,
+                   att.NN_p.bias, att.theta]
+        if any(t.dtype != torch.float32 or t.device != dev for t in tensors) or any(
+                not t.is_contiguous() for i, t in enumerate(tensors) if i != 9):
+            return None
+        d = [t.data_ptr() for t in tensors]
+        ws = _lib.GeneratorWeights(H, pg.enc[0].weight.shape[1] - n_cls - 1, pg.layer_num, L, n_cls, gnn.pe.shape[0],
+                                   d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], Wc.stride(0),
+                                   d[10], d[11], d[12], d[13], d[14], d[15], d[16])
+        if program_in.shape[1] != ws.n_class + 1 + ws.noise_dim:
+            return None
+        nws = int(lib.bg_generator_forward_workspace(plan.Np, Nv, plan.S, Ec, H))
+        work = torch.empty(nws, dtype=torch.float32, device=dev)
+        out = torch.empty(Nv, n_cls, dtype=torch.float32, device=dev)
+        soft_out = torch.empty(Nv, n_cls, dtype=torch.float32, device=dev)
+        mask_hard = torch.empty(Nv, 1, dtype=torch.float32, device=dev)
+        mask_soft = torch.empty(Nv, 1, dtype=torch.float32, device=dev)
+        att_hard = torch.empty(Ec, 1, dtype=torch.float32, device=dev)
+        att_soft = torch.empty(Ec, 1, dtype=torch.float32, device=dev)
+        idx = torch.empty(Nv, dtype=torch.int64, device=dev)
+        PA = C.c_void_p * n_calls
+        cls = ops._f32c(graph.program_class_feature).contiguous()
+        rc = lib.bg_generator_forward_f32(C.byref(ws), C.byref(ps), program_in.data_ptr(), v4.data_ptr(), pdm4.data_ptr(),
+                                          cls.data_ptr(), PA(*em_ptrs), PA(*ea_ptrs), n_calls, work.data_ptr(), nws,
+                                          out.data_ptr(), soft_out.data_ptr(), mask_hard.data_ptr(), mask_soft.data_ptr(),
+                                          att_hard.data_ptr(), att_soft.data_ptr(), idx.data_ptr(), _lib.stream())
+        del keep
+        if rc == -2:                      # BG_ERR_SHAPE: not a shape for the one-call path
+            return None
+        _lib.check(rc, "bg_generator_forward_f32")
+        return out, soft_out, {"hard": mask_hard, "soft": mask_soft}, {"hard": att_hard, "soft": att_soft}, idx
+
     def forward(self, graph, program_z, voxel_z, noise: Optional[Sequence] = None, derived=None):
         plan = build_plan(graph)
+        if FUSE_GENERATOR_FORWARD and not torch.is_grad_enabled() and graph.voxel_feature.is_cuda:
+            res = self._forward_one_call(graph, plan, program_z, noise, derived)
+            if res is not None:
+                return res
         x = self.programGNN(graph.program_class_feature, graph.story_level_feature, graph.program_target_ratio,
                             program_z, plan)
         mask, att, _ = self.voxelGNN(x, graph.voxel_feature, voxel_z, plan, noise, derived)

@@ -380,6 +380,34 @@ class Trainer:
                 p.requires_grad = False
         return stats
 
+    # ------------------------------------------------------------------ epochs and checkpoints
+    def save_checkpoint(self, path: str):
+        """The generator's state_dict as the reference writes it (train.py:140-141): plain tensors under the
+        reference's key names (the parameters here are views of one flat buffer; each is copied out so the file does
+        not carry the whole buffer once per key), loadable by inference.load_generator / the reference's
+        inference.py:74-76."""
+        torch.save({k: v.detach().clone().cpu() for k, v in self.generator.state_dict().items()}, path)
+
+    def fit(self, loader, n_epochs: int, model_dir: Optional[str] = None, eval_period: int = 20, on_epoch=None):
+        """The reference's epoch loop (train.py:73-75,133-141): every batch of ``loader`` (any iterable of batches,
+        re-iterated per epoch) goes to the device and through one iteration whose index restarts with the epoch;
+        every ``eval_period``-th epoch the generator is written to ``model_dir/<epoch>.ckpt`` and
+        ``on_epoch(epoch, stats)`` (evaluation, logging) is called.  Returns the last iteration's losses."""
+        import os
+        stats = {}
+        for epoch in range(n_epochs):
+            for i, batch in enumerate(loader):
+                if batch.voxel_feature.device != torch.device(self.device):
+                    batch = batch.to(self.device)
+                stats = self.train_iteration(batch, i)
+            if epoch % eval_period == 0:
+                if model_dir is not None:
+                    os.makedirs(model_dir, exist_ok=True)
+                    self.save_checkpoint(os.path.join(model_dir, "{}.ckpt".format(epoch)))
+                if on_epoch is not None:
+                    on_epoch(epoch, stats)
+        return stats
+
     # ------------------------------------------------------------------ hipGraph iteration
     def capture(self, batch, warmup: int = 2, overlap: bool = False):
         """Capture the iteration for THIS batch (fixed shapes) into hipGraphs.

@@ -407,6 +407,65 @@ int bg_gemm_tn_splitk_f32(int64_t M, int64_t R, const float* A, int64_t lda,
 int bg_colsum_f32(const float* x, int64_t ldx, int64_t M, int64_t N, float* partial, int32_t n_blocks,
                   float* out, int accumulate, bgStream stream);
 
+/* ------------------------------------------------------------------ whole passes -------- */
+
+/* The generator's parameters as a graph-free forward reads them (plain device pointers; all matrices row-major
+ * nn.Linear layout [out, in], contiguous unless a pitch is given).  Wc / bc / Wsb are the composed block weights
+ * and Wcat / bcat the attention's stacked weight (functions of the parameters alone: models.VoxelGNN_G.derived_weights). */
+typedef struct {
+    int64_t H, noise_dim, program_layer, voxel_layer, n_class, max_len;
+    const float *p_enc_w, *p_enc_b;          /* programGNN.enc         [H, n_class + 1 + noise_dim], [H] */
+    const float *p_msg_w, *p_msg_b;          /* programGNN.block.messageMLP  [H, 2H], [H]                */
+    const float *p_upd_w, *p_upd_b;          /* programGNN.block.updateMLP   [H, 3H], [H]                */
+    const float *v_enc_w, *v_enc_b;          /* voxelGNN.enc           [H, 4], [H]                       */
+    const float *pe;                         /* voxelGNN.pe            [max_len, H]                      */
+    const float *Wc; int64_t ldwc;           /* composed block weight  [H, 2H + 4], pitch ldwc           */
+    const float *bc, *Wsb;                   /* [H];  [H, 2H] acting on [story mean | building mean]     */
+    const float *Wcat, *bcat;                /* [H + 4, H], [H + 4]: NN_v | composed 2-row mask decoder  */
+    const float *nnp_w, *nnp_b, *theta;      /* attention.NN_p [H, H], [H];  theta [H]                   */
+} bgGeneratorWeights;
+
+/* The index plan of one batch as that forward reads it (device pointers into the plan built by bg_plan_*). */
+typedef struct {
+    int64_t Np, Nv, S, Ec;
+    int64_t cx_max_len;                                         /* most cross edges of one voxel (1..64 required)   */
+    int64_t vox_all_has;                                        /* != 0: every voxel has an in-edge (required)      */
+    const int32_t *pp_rowptr, *pp_col; const float *pp_scale;   /* program pair operator: 2 Np rows (multipliers)   */
+    const float *prog_has;                                      /* [Np] 1 where a program node has an in-edge       */
+    const int32_t *vx_rowptr, *vx_col; const float *vx_count;   /* voxel edges by target; max(in-degree, 1)         */
+    const int32_t *st_rowptr, *st_col; const float *st_count;   /* voxels by story; max(size, 1)                    */
+    const int32_t *story_of_voxel;                              /* [Nv]                                             */
+    const int32_t *sb_rowptr, *sb_col; const float *sb_count;   /* stories x stories of the same building           */
+    const int32_t *level;                                       /* [Nv] floor level inside the building             */
+    const int32_t *cx_rowptr, *cx_col;                          /* cross edges by voxel (slots in edge order)       */
+} bgGeneratorPlan;
+
+/* sizeof(bgGeneratorWeights) (which = 0) / sizeof(bgGeneratorPlan) (which = 1) as this library was compiled, so a host
+ * binding can refuse a library built from another revision of this header (a layout mismatch hands the kernels
+ * shifted pointers); -1 for an unknown `which`. */
+int64_t bg_abi_sizeof(int which);
+
+/* Floats of workspace bg_generator_forward_f32 needs for these sizes (every piece 256-byte aligned inside it). */
+int64_t bg_generator_forward_workspace(int64_t Np, int64_t Nv, int64_t S, int64_t Ec, int64_t H);
+
+/* One whole graph-free Generator.forward (inference, the critic-only iterations of training) as ONE host call:
+ * the ~70 launches of the program GNN, the voxel encoder, 6 Attention calls, 11 VoxelBlock calls (the 12th block's
+ * result is never read: Model/models.py:196-203,241-250) and the output stage, issued back to back on `stream` --
+ * the same kernels with the same arguments as the op-by-op host path (bit-identical results), without ~1.2 ms of
+ * interpreter time per pass.  program_in = [class one-hot | story level | z] [Np, n_class + 1 + noise_dim];
+ * voxel_in = voxel_feature[:, {0,1,2,6}] [Nv, 4]; pdm4 = bg_pos_terms_f32's result (pad 1); cls = program class
+ * one-hot [Np, n_class]; exp_mask[c] [Nv, 2] / exp_att[c] [Ec] = the Exp(1) noise of Attention call c
+ * (1 + (voxel_layer - 1) / 2 calls).  Outputs as Generator.forward returns them; idx is int64.
+ * Needs: every voxel with an in-edge and 1..64 cross edges, H % 64 == 0, H <= 256, Nv <= 65536, n_class <= 8
+ * (else BG_ERR_SHAPE: run the op-by-op path).
+ * replaces: Generator.forward, Model/models.py:241-250 (with :83-92, :185-203, :104-141) under torch.no_grad(). */
+int bg_generator_forward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan* p,
+                             const float* program_in, const float* voxel_in, const float* pdm4, const float* cls,
+                             const float* const* exp_mask, const float* const* exp_att, int64_t n_calls,
+                             float* workspace, int64_t workspace_floats,
+                             float* out, float* soft_out, float* mask_hard, float* mask_soft,
+                             float* att_hard, float* att_soft, int64_t* idx, bgStream stream);
+
 /* ------------------------------------------------------------------ optimiser ----------- */
 
 /* One Adam step on a flat fp32 buffer (torch.optim.Adam semantics, no weight decay/amsgrad):

@@ -1,0 +1,81 @@
+// TEST INFRASTRUCTURE (CPU): stand-ins for the kernel launchers that csrc/driver.hip calls.  Each records its
+// arguments (pointers as integers) so that tests/test_driver_host.py can check, without a GPU, that every pointer the
+// composite entry points hand to a launcher lies inside a buffer the caller provided and that the extents fit.
+#include <stdint.h>
+#include <string.h>
+#include "../../include/bgan.h"
+
+#define MAX_CALLS 4096
+#define MAX_ARGS 40
+static int64_t g_log[MAX_CALLS][MAX_ARGS];
+static int g_n = 0;
+
+static void rec(int id, const int64_t* a, int n) {
+    if (g_n >= MAX_CALLS) return;
+    g_log[g_n][0] = id;
+    g_log[g_n][1] = n;
+    for (int i = 0; i < n && i + 2 < MAX_ARGS; ++i) g_log[g_n][i + 2] = a[i];
+    ++g_n;
+}
+#define P(x) ((int64_t)(uintptr_t)(x))
+
+extern "C" {
+int stub_count(void) { return g_n; }
+void stub_reset(void) { g_n = 0; }
+const int64_t* stub_call(int i) { return g_log[i]; }
+
+int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg, const float* const* A, const int64_t* lda,
+                const int64_t* Ks, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                const float* row_scale, int act, float slope, const float* residual, int64_t ldr, const float* pre_add,
+                int64_t ldp, const int32_t* pre_add_rows, const float* acc_init, int64_t ld_acc, float* pre_residual_out,
+                int64_t ld_pro, bgStream stream) {
+    int64_t a[] = {transA, transB, M, N, n_seg, P(A[0]), P(A[1]), P(A[2]), P(A[3]), lda[0], lda[1], lda[2], lda[3],
+                   Ks[0], Ks[1], Ks[2], Ks[3], P(B), ldb, P(C), ldc, P(bias), P(row_scale), act, P(residual), ldr,
+                   P(pre_add), ldp, P(pre_add_rows), P(acc_init), ld_acc, P(pre_residual_out), ld_pro};
+    rec(1, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_spmm_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* edge_w,
+                const int32_t* eperm, const float* row_scale, int row_mode, const float* col_scale, int col_mode,
+                float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream) {
+    int64_t a[] = {P(x), ldx, P(rowptr), P(col), P(edge_w), P(eperm), P(row_scale), row_mode, P(col_scale), col_mode,
+                   P(out), ldo, n_rows, H};
+    rec(2, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_spmm_add_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* row_scale,
+                    int row_mode, const float* col_scale, int col_mode, const float* add1, int64_t ld1, const float* add2,
+                    int64_t ld2, const float* gadd, int64_t ldg, const int32_t* grow, const float* gs, int gmode,
+                    float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream) {
+    int64_t a[] = {P(x), ldx, P(rowptr), P(col), P(row_scale), row_mode, P(col_scale), col_mode, P(add1), ld1, P(add2),
+                   ld2, P(gadd), ldg, P(grow), P(gs), gmode, P(out), ldo, n_rows, H};
+    rec(3, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_gather_story_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* row_scale,
+                        int row_mode, float* gm, int64_t ldg, int64_t n_rows, const int32_t* s_rowptr,
+                        const int32_t* s_col, const float* s_count, const float* W, int64_t ldw, int64_t Hout, float* pq,
+                        int64_t ldq, int64_t n_story, int64_t H, bgStream stream) {
+    int64_t a[] = {P(x), ldx, P(rowptr), P(col), P(row_scale), row_mode, P(gm), ldg, n_rows, P(s_rowptr), P(s_col),
+                   P(s_count), P(W), ldw, Hout, P(pq), ldq, n_story, H};
+    rec(4, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_attention_fwd_f32(const float* a_, int64_t lda, const float* logits, int64_t ldl, const float* b, int64_t ldb,
+                         const float* x, int64_t ldx, const float* v, int64_t ldv, const float* theta,
+                         const int32_t* rowptr, const int32_t* col, const float* exp_mask, const float* exp_att, float tau,
+                         float* soft0, float* hard0, float* soft, float* hard, float* out, int64_t ldo, int64_t n_vox,
+                         int64_t H, const float* wd, int64_t ldwd, const float* bd, bgStream stream) {
+    int64_t a[] = {P(a_), lda, P(logits), ldl, P(b), ldb, P(x), ldx, P(v), ldv, P(theta), P(rowptr), P(col), P(exp_mask),
+                   P(exp_att), (int64_t)tau, P(soft0), P(hard0), P(soft), P(hard), P(out), ldo, n_vox, H, P(wd), ldwd, P(bd)};
+    rec(5, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_construct_output_f32(const float* mask_hard, const float* att_hard, const float* att_soft, const int32_t* rowptr,
+                            const int32_t* col, const float* cls, int64_t ldc, int64_t C, float* out, float* soft_out,
+                            int64_t* idx, int64_t n_vox, bgStream stream) {
+    int64_t a[] = {P(mask_hard), P(att_hard), P(att_soft), P(rowptr), P(col), P(cls), ldc, C, P(out), P(soft_out), P(idx), n_vox};
+    rec(6, a, sizeof(a) / 8);
+    return 0;
+}
+}

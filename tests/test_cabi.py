@@ -24,11 +24,15 @@ def test_library_exports_every_declared_symbol():
 
 def test_python_binding_covers_the_header():
     from building_gan_amd import _lib
-    declared = set(_declared()) - {"bg_version", "bg_error_string"}
+    # (functions that do not return an int status are bound by hand in _lib.load())
+    declared = set(_declared()) - {"bg_version", "bg_error_string", "bg_abi_sizeof", "bg_generator_forward_workspace"}
     assert declared == set(_lib.SIGNATURES.keys())
     lib = _lib.load()
     assert lib.bg_version() >= 1
     assert lib.bg_error_string(-2).decode().startswith("shape")
+    # struct layouts of the host binding and of the compiled library agree (load() refuses a mismatch)
+    assert lib.bg_abi_sizeof(0) == ctypes.sizeof(_lib.GeneratorWeights)
+    assert lib.bg_abi_sizeof(1) == ctypes.sizeof(_lib.GeneratorPlan) and lib.bg_abi_sizeof(7) == -1
 
 
 def test_no_cpu_fallback():

@@ -1,0 +1,306 @@
+"""Host logic of csrc/driver.hip (the whole-pass entry points) without a GPU: the file is compiled together with
+stand-ins for the kernel launchers (tests/host/driver_stubs.cpp) that only record their arguments, and the test
+checks that every pointer + extent handed to a launcher lies inside a buffer the caller provided (fake, disjoint
+address ranges: the driver never dereferences device pointers), that the launch sequence is the generator's, and
+that the workspace query covers what the pass carves."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def drv(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    so = str(tmp_path_factory.mktemp("drv") / "libdriver_check.so")
+    subprocess.run([HIPCC, "-O1", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-shared", "-o", so,
+                    os.path.join(ROOT, "building-gan_amd", "csrc", "driver.hip"),
+                    os.path.join(ROOT, "tests", "host", "driver_stubs.cpp")], check=True)
+    lib = C.CDLL(so)
+    lib.stub_call.restype = C.POINTER(C.c_int64)
+    lib.bg_generator_forward_workspace.restype = C.c_int64
+    lib.bg_generator_forward_workspace.argtypes = [C.c_int64] * 5
+    return lib
+
+
+class Ranges:
+    """Fake device buffers: disjoint address intervals."""
+
+    def __init__(self):
+        self.next = 1 << 40
+        self.r = {}
+
+    def new(self, name, nbytes):
+        base = self.next
+        self.next += (nbytes + (1 << 20)) // 256 * 256 + (1 << 20)
+        self.r[name] = (base, nbytes)
+        return base
+
+    def check(self, ptr, nbytes, what):
+        if ptr == 0:
+            raise AssertionError("null pointer: " + what)
+        for name, (b, n) in self.r.items():
+            if b <= ptr < b + max(n, 1):
+                assert ptr + nbytes <= b + n, "%s: %d bytes at %s+%d overrun its %d bytes" % (what, nbytes, name, ptr - b, n)
+                return name
+        raise AssertionError("%s: pointer %#x is in no buffer" % (what, ptr))
+
+
+def _run(lib, Np, Nv, S, Ec, H=128, L=12, PL=4, noise_dim=32, n_cls=6, max_len=20, ldwc=None):
+    import sys
+    sys.path.insert(0, ROOT)
+    from building_gan_amd._lib import GeneratorPlan, GeneratorWeights
+    R = Ranges()
+    f = 4
+    kin = n_cls + 1 + noise_dim
+    ldwc = ldwc or 2 * H + 4
+    w = GeneratorWeights(H, noise_dim, PL, L, n_cls, max_len,
+                         R.new("p_enc_w", H * kin * f), R.new("p_enc_b", H * f), R.new("p_msg_w", H * 2 * H * f),
+                         R.new("p_msg_b", H * f), R.new("p_upd_w", H * 3 * H * f), R.new("p_upd_b", H * f),
+                         R.new("v_enc_w", H * 4 * f), R.new("v_enc_b", H * f), R.new("pe", max_len * H * f),
+                         R.new("Wc", H * ldwc * f), ldwc, R.new("bc", H * f), R.new("Wsb", H * 2 * H * f),
+                         R.new("Wcat", (H + 4) * H * f), R.new("bcat", (H + 4) * f), R.new("nnp_w", H * H * f),
+                         R.new("nnp_b", H * f), R.new("theta", H * f))
+    nnz_pp, Ev, nnz_sb = 7 * Np, 6 * Nv, 3 * S
+    p = GeneratorPlan(Np, Nv, S, Ec, 4, 1,
+                      R.new("pp_rowptr", (2 * Np + 1) * 4), R.new("pp_col", nnz_pp * 4), R.new("pp_scale", 2 * Np * f),
+                      R.new("prog_has", Np * f), R.new("vx_rowptr", (Nv + 1) * 4), R.new("vx_col", Ev * 4),
+                      R.new("vx_count", Nv * f), R.new("st_rowptr", (S + 1) * 4), R.new("st_col", Nv * 4),
+                      R.new("st_count", S * f), R.new("story_of_voxel", Nv * 4), R.new("sb_rowptr", (S + 1) * 4),
+                      R.new("sb_col", nnz_sb * 4), R.new("sb_count", S * f), R.new("level", Nv * 4),
+                      R.new("cx_rowptr", (Nv + 1) * 4), R.new("cx_col", Ec * 4))
+    n_calls = 1 + (L - 1) // 2
+    PA = C.c_void_p * n_calls
+    em = PA(*[R.new("exp_mask%d" % c, Nv * 2 * f) for c in range(n_calls)])
+    ea = PA(*[R.new("exp_att%d" % c, Ec * f) for c in range(n_calls)])
+    nws = lib.bg_generator_forward_workspace(Np, Nv, S, Ec, H)
+    args = [C.byref(w), C.byref(p), R.new("program_in", Np * kin * f), R.new("voxel_in", Nv * 4 * f),
+            R.new("pdm4", Nv * 4 * f), R.new("cls", Np * n_cls * f), em, ea, n_calls, R.new("workspace", nws * f), nws,
+            R.new("out", Nv * n_cls * f), R.new("soft_out", Nv * n_cls * f), R.new("mask_hard", Nv * f),
+            R.new("mask_soft", Nv * f), R.new("att_hard", Ec * f), R.new("att_soft", Ec * f), R.new("idx", Nv * 8), None]
+    lib.bg_generator_forward_f32.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_void_p, C.c_int64] + [C.c_void_p] * 8
+    lib.stub_reset()
+    rc = lib.bg_generator_forward_f32(*args)
+    calls = []
+    for i in range(lib.stub_count()):
+        c = lib.stub_call(i)
+        calls.append((c[0], [c[2 + k] for k in range(c[1])]))
+    return rc, calls, R
+
+
+def _check_calls(calls, R, H):
+    f = 4
+    written = []
+    for ci, (kind, a) in enumerate(calls):
+        tag = "call %d kind %d" % (ci, kind)
+        if kind == 1:       # gemm
+            (tA, tB, M, N, n_seg), A, lda, Ks = a[0:5], a[5:9], a[9:13], a[13:17]
+            B, ldb, Cp, ldc, bias, rs, act, res, ldr, pre, ldp, rows, acc, ldacc, pro, ldpro = a[17:33]
+            assert tA == 0 and tB == 1
+            K = 0
+            for s in range(n_seg):
+                assert lda[s] >= Ks[s]
+                R.check(A[s], ((M - 1) * lda[s] + Ks[s]) * f, tag + " A%d" % s)
+                K += Ks[s]
+            assert ldb >= K
+            R.check(B, ((N - 1) * ldb + K) * f, tag + " B")
+            written.append((R.check(Cp, ((M - 1) * ldc + N) * f, tag + " C"), Cp))
+            if bias:
+                R.check(bias, N * f, tag + " bias")
+            if rs:
+                R.check(rs, M * f, tag + " row_scale")
+            if res:
+                R.check(res, ((M - 1) * ldr + N) * f, tag + " residual")
+                assert res != Cp
+            if pre:
+                R.check(pre, N * f, tag + " pre_add")
+                assert ldp >= N
+            if rows:
+                R.check(rows, M * 4, tag + " pre_rows")
+            if acc:
+                R.check(acc, ((M - 1) * ldacc + N) * f, tag + " acc_init")
+            for s in range(n_seg):
+                assert A[s] != Cp, tag + ": in-place product"
+        elif kind == 2:     # spmm
+            x, ldx, rp, col, ew, ep, rsc, rm, csc, cm, out, ldo, n_rows, Hh = a
+            R.check(x, Hh * f, tag + " x")
+            R.check(rp, (n_rows + 1) * 4, tag + " rowptr")
+            R.check(out, ((n_rows - 1) * ldo + Hh) * f, tag + " out")
+            if rm:
+                R.check(rsc, n_rows * f, tag + " row_scale")
+            assert x != out
+        elif kind == 3:     # spmm_add
+            x, ldx, rp, col, rsc, rm, csc, cm, a1, ld1, a2, ld2, ga, ldg, grow, gs, gm_, out, ldo, n_rows, Hh = a
+            R.check(x, ((n_rows - 1) * ldx + Hh) * f, tag + " x")           # square here: stories x stories
+            R.check(rp, (n_rows + 1) * 4, tag + " rowptr")
+            R.check(a1, ((n_rows - 1) * ld1 + Hh) * f, tag + " add1")
+            R.check(out, ((n_rows - 1) * ldo + Hh) * f, tag + " out")
+            R.check(rsc, n_rows * f, tag + " row_scale")
+        elif kind == 4:     # gather_story
+            x, ldx, rp, col, rsc, rm, gm, ldg, n_rows, srp, scol, scount, W, ldw, Hout, pq, ldq, n_story, Hh = a
+            R.check(x, ((n_rows - 1) * ldx + Hh) * f, tag + " x")
+            R.check(rp, (n_rows + 1) * 4, tag + " rowptr")
+            R.check(rsc, n_rows * f, tag + " count")
+            R.check(gm, ((n_rows - 1) * ldg + Hh) * f, tag + " gm")
+            R.check(srp, (n_story + 1) * 4, tag + " story rowptr")
+            R.check(scol, n_rows * 4, tag + " story col")
+            R.check(scount, n_story * f, tag + " story count")
+            R.check(W, ((Hout - 1) * ldw + 2 * Hh) * f, tag + " Wsb")
+            R.check(pq, ((n_story - 1) * ldq + 2 * Hout) * f, tag + " pq")
+            assert x != gm
+        elif kind == 5:     # attention
+            (a_, lda, lg, ldl, b, ldb, x, ldx, v, ldv, th, rp, col, em, ea, tau, s0, h0, so, ha, out, ldo, n, Hh, wd, ldwd, bd) = a
+            assert tau == -1 and lg == 0
+            R.check(a_, ((n - 1) * lda + Hh) * f, tag + " a")
+            R.check(b, Hh * f, tag + " b")
+            R.check(x, Hh * f, tag + " x")
+            R.check(v, ((n - 1) * ldv + Hh) * f, tag + " v")
+            R.check(th, Hh * f, tag + " theta")
+            R.check(rp, (n + 1) * 4, tag + " rowptr")
+            assert R.check(em, n * 2 * f, tag + " exp_mask").startswith("exp_mask")
+            assert R.check(ea, f, tag + " exp_att").startswith("exp_att")
+            for ptr_, nm in ((s0, "soft0"), (h0, "hard0")):
+                R.check(ptr_, n * f, tag + " " + nm)
+            R.check(out, ((n - 1) * ldo + Hh) * f, tag + " out")
+            R.check(wd, (ldwd + Hh) * f, tag + " wd")
+            R.check(bd, 2 * f, tag + " bd")
+            assert out != v and out != a_
+        elif kind == 6:
+            mh, ah, asf, rp, col, cls, ldc, Cn, out, so, idx, n = a
+            assert R.check(mh, n * f, "mask_hard") == "mask_hard" and R.check(ah, f, "att_hard") == "att_hard"
+            assert R.check(asf, f, "att_soft") == "att_soft" and R.check(idx, n * 8, "idx") == "idx"
+            assert R.check(out, n * Cn * f, "out") == "out" and R.check(so, n * Cn * f, "soft_out") == "soft_out"
+            R.check(cls, Cn * f, "cls")
+
+
+def test_generator_forward_host_sequence_and_extents(drv):
+    for (Np, Nv, S, Ec) in ((320, 11520, 80, 46080), (7, 7, 5, 11), (33, 1001, 9, 3999)):
+        rc, calls, R = _run(drv, Np, Nv, S, Ec)
+        assert rc == 0
+        kinds = [k for k, _ in calls]
+        # encoder + 4 x (pair aggregation, message, update) | voxel encoder, NN_p | attention = product + fused call
+        expect = [1] + [2, 1, 1] * 4 + [1, 1] + [1, 5] + [1]
+        for i in range(11):
+            expect += [4, 3, 1] + ([1, 5] if (i % 2 == 0 and i != 0) else [])
+        expect += [6]
+        assert kinds == expect
+        _check_calls(calls, R, 128)
+        # the last attention call writes the caller's outputs, earlier ones the workspace
+        att = [a for k, a in calls if k == 5]
+        assert len(att) == 6
+        for c, a in enumerate(att):
+            names = [R.check(a[16], 4, "s0"), R.check(a[17], 4, "h0"), R.check(a[18], 4, "soft"), R.check(a[19], 4, "hard")]
+            assert names == (["mask_soft", "mask_hard", "att_soft", "att_hard"] if c == 5 else ["workspace"] * 4)
+            assert R.check(a[13], 4, "em") == "exp_mask%d" % c and R.check(a[14], 4, "ea") == "exp_att%d" % c
+
+
+def test_generator_forward_host_argument_errors(drv):
+    rc, _, _ = _run(drv, 320, 70000, 80, 46080)
+    assert rc == -2                                   # more voxels than the fused gather + story launch takes
+    rc, _, _ = _run(drv, 320, 11520, 80, 46080, H=96)
+    assert rc == -2
+    rc, calls, R = _run(drv, 16, 64, 4, 256, L=2, PL=1)      # two layers: one attention call, no block is read
+    assert rc == 0 and [k for k, _ in calls] == [1, 2, 1, 1, 1, 1, 1, 5, 1, 6]
+
+
+def test_generator_python_binding_hands_the_right_buffers_to_the_driver(drv, monkeypatch):
+    """models.Generator._forward_one_call on CPU tensors with the stand-in library: the structs it fills and the
+    pointers it passes must make every launcher argument fall inside the tensor it is meant to be (checked against
+    the real tensors' address ranges)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    from building_gan_amd import _lib, models as hm
+    from building_gan_amd.plan import Csr, GraphPlan, LinOp, SCALE_DIV, SCALE_MUL
+    from building_gan_amd.synthetic import batch_sizes, make_batch
+    drv.bg_generator_forward_f32.argtypes = _lib.SIGNATURES["bg_generator_forward_f32"]      # as _lib.load() sets them
+    drv.bg_generator_forward_f32.restype = C.c_int
+    monkeypatch.setattr(_lib, "load", lambda: drv)
+    monkeypatch.setattr(_lib, "stream", lambda: None)
+    batch = make_batch("small", seed=2, ragged=True)
+    sz = batch_sizes(batch)
+    Np, Nv, S, Ec, B = sz["Np"], sz["Nv"], sz["S"], sz["Ec"], sz["B"]
+    i32 = lambda n: torch.zeros(n, dtype=torch.int32)
+    f32 = lambda *n: torch.zeros(*n, dtype=torch.float32)
+    plan = GraphPlan(B=B, S=S, Np=Np, Nv=Nv, Ep=sz["Ep"], Ev=sz["Ev"], Ec=Ec, device=torch.device("cpu"))
+    o = plan.ops
+    nnz_pp = sz["Ep"] + 3 * Np
+    o["prog_pair"] = LinOp(Csr(i32(2 * Np + 1), i32(nnz_pp), None, 2 * Np, Np, nnz_pp), f32(2 * Np), SCALE_MUL)
+    o["prog_has"] = f32(Np, 1)
+    o["vox_mean"] = LinOp(Csr(i32(Nv + 1), i32(sz["Ev"]), None, Nv, Nv, sz["Ev"]), f32(Nv), SCALE_DIV)
+    o["story_seg"] = Csr(i32(S + 1), i32(Nv), None, S, Nv, Nv, count=f32(S))
+    o["story_building_mean"] = LinOp(Csr(i32(S + 1), i32(4 * S), None, S, S, 4 * S, count=f32(S)), f32(S), SCALE_DIV)
+    o["story_gather"] = LinOp(Csr(i32(Nv + 1), i32(Nv), None, Nv, S, Nv))
+    o["level"] = i32(Nv)
+    cv = Csr(i32(Nv + 1), i32(Ec), None, Nv, Np, Ec)
+    cv.max_len = 6
+    o["cross_v"] = cv
+    o["flags"] = {"cross_by_voxel": (0, 0, 0, 0)}
+    o["max_level"], o["vox_all_has"] = 2, True
+    o["pdm4"] = f32(Nv, 4)
+    torch.manual_seed(0)
+    G = hm.Generator(7, 7, 128, 32, 4, 12)
+    pz = torch.rand(Np, 32)
+    drv.stub_reset()
+    H = 128
+    derived = [torch.rand(H, 2 * H + 4), torch.rand(H), torch.rand(H, 2 * H), torch.rand(H + 4, H), torch.rand(H + 4)]
+    with torch.no_grad():
+        res = G._forward_one_call(batch, plan, pz, None, derived)
+    assert res is not None
+    out, soft_out, mask, att, idx = res
+    assert out.shape == (Nv, 6) and mask["hard"].shape == (Nv, 1) and att["soft"].shape == (Ec, 1) and idx.dtype == torch.int64
+    calls = []
+    for i in range(drv.stub_count()):
+        c = drv.stub_call(i)
+        calls.append((c[0], [c[2 + k] for k in range(c[1])]))
+
+    def inside(ptr, nbytes, t, what):
+        assert t.data_ptr() <= ptr and ptr + nbytes <= t.data_ptr() + t.numel() * t.element_size(), what
+
+    gnn, pg = G.voxelGNN, G.programGNN
+    gem = [a for k, a in calls if k == 1]
+    # program encoder: A = [class | level | z], B = enc weight, bias
+    a = gem[0]
+    assert (a[2], a[3], a[13]) == (Np, 128, 39) and a[17] == pg.enc[0].weight.data_ptr() and a[21] == pg.enc[0].bias.data_ptr()
+    # message / update products of the program block
+    assert gem[1][17] == pg.block.messageMLP[0].weight.data_ptr() and gem[1][22] == o["prog_has"].data_ptr()
+    assert gem[2][17] == pg.block.updateMLP[0].weight.data_ptr() and gem[2][23] == 1
+    # voxel encoder with pe[level] in the epilogue
+    a = gem[9]
+    assert (a[2], a[13]) == (Nv, 4) and a[17] == gnn.enc[0].weight.data_ptr() and a[26] == gnn.pe.data_ptr()
+    assert a[28] == o["level"].data_ptr()
+    assert gem[10][17] == gnn.attention.NN_p.weight.data_ptr()
+    at = [a for k, a in calls if k == 5]
+    sp = [a for k, a in calls if k == 2][0]
+    assert sp[2] == o["prog_pair"].csr.rowptr.data_ptr() and sp[6] == o["prog_pair"].row_scale.data_ptr() and sp[12] == 2 * Np
+    gs = [a for k, a in calls if k == 4][0]
+    assert gs[2] == o["vox_mean"].csr.rowptr.data_ptr() and gs[3] == o["vox_mean"].csr.col.data_ptr()
+    assert gs[4] == o["vox_mean"].row_scale.data_ptr() and gs[5] == SCALE_DIV and gs[8] == Nv and gs[17] == S
+    assert gs[9] == o["story_seg"].rowptr.data_ptr() and gs[10] == o["story_seg"].col.data_ptr()
+    assert gs[11] == o["story_seg"].count.data_ptr()
+    sa = [a for k, a in calls if k == 3][0]
+    sb = o["story_building_mean"]
+    assert sa[2] == sb.csr.rowptr.data_ptr() and sa[3] == sb.csr.col.data_ptr() and sa[4] == sb.row_scale.data_ptr()
+    blk = [a for a in gem if a[29] != 0][0]                       # the block product starts from the position term
+    assert blk[28] == o["story_gather"].csr.col.data_ptr() and blk[4] == 2 and blk[23] == 1
+    assert blk[17] == derived[0].data_ptr() and blk[18] == 2 * H + 4
+    posb = [a for a in gem if a[13] == 4 and a[17] == derived[0].data_ptr() + 4 * 2 * H][0]
+    assert posb[21] == derived[1].data_ptr() and posb[5] == o["pdm4"].data_ptr()
+    assert gs[12] == derived[2].data_ptr()
+    assert at[0][24] == derived[3].data_ptr() + 4 * H * H and at[0][26] == derived[4].data_ptr() + 4 * H
+    assert at[0][11] == cv.rowptr.data_ptr() and at[0][12] == cv.col.data_ptr() and at[0][10] == gnn.attention.theta.data_ptr()
+    inside(at[-1][16], 4 * Nv, mask["soft"], "mask soft")
+    inside(at[-1][17], 4 * Nv, mask["hard"], "mask hard")
+    inside(at[-1][18], 4 * Ec, att["soft"], "att soft")
+    inside(at[-1][19], 4 * Ec, att["hard"], "att hard")
+    co = [a for k, a in calls if k == 6][0]
+    inside(co[8], 4 * Nv * 6, out, "out")
+    inside(co[9], 4 * Nv * 6, soft_out, "soft_out")
+    inside(co[10], 8 * Nv, idx, "idx")
+    assert co[3] == cv.rowptr.data_ptr() and co[4] == cv.col.data_ptr() and co[11] == Nv

@@ -74,6 +74,36 @@ def test_large_building_needs_a_longer_position_table(cuda):
     assert int(idx[nv:].min()) >= lo and int(idx[nv:].max()) < hi      # second copy points into its own program nodes
 
 
+def test_trained_generator_round_trips_through_a_checkpoint(cuda, tmp_path):
+    """Trainer.fit (the reference's epoch loop + checkpoint writer, train.py:73-75,133-141) -> <epoch>.ckpt ->
+    inference.load_generator (weights_only=True): the reloaded generator reproduces the trained one bit for bit,
+    although the trained parameters are views of the optimizer's flat buffer."""
+    import os
+    from building_gan_amd.inference import load_generator
+    from building_gan_amd.synthetic import batch_sizes, make_batch
+    from building_gan_amd.train import Trainer
+    loader = [make_batch("small", seed=s, ragged=True) for s in (5, 6)]
+    torch.manual_seed(0)
+    tr = Trainer(cuda)
+    before = tr.opt_g.flat.clone()
+    stats = tr.fit(loader, 2, model_dir=str(tmp_path), eval_period=1)
+    assert torch.isfinite(stats["d_loss"]).all() and not torch.equal(tr.opt_g.flat, before)
+    assert sorted(os.listdir(tmp_path)) == ["0.ckpt", "1.ckpt"]
+    state = torch.load(str(tmp_path / "1.ckpt"), weights_only=True)
+    assert set(state) == set(tr.generator.state_dict()) and all(v.is_contiguous() for v in state.values())
+    assert sum(v.numel() for k, v in state.items() if k != "voxelGNN.pe") == 228418
+    gen = load_generator(str(tmp_path / "1.ckpt"), cuda)
+    batch = make_batch("small", seed=7, ragged=True).to(cuda)
+    sz = batch_sizes(batch)
+    noise = [(torch.empty(sz["Nv"], 2, device=cuda).exponential_(), torch.empty(sz["Ec"], device=cuda).exponential_())
+             for _ in range(6)]
+    pz = torch.rand(sz["Np"], 32, device=cuda)
+    with torch.no_grad():
+        a = tr.generator(batch, pz, None, noise)
+        b = gen(batch, pz, None, noise)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[4], b[4])
+
+
 def test_inference_driver_with_released_weights(cuda, tmp_path):
     """checkpoint file -> generator (strict=False) -> raw JSON designs -> result JSONs + 5 variations."""
     import json

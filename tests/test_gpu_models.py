@@ -499,6 +499,39 @@ def test_fused_attention_forward_equals_unfused(cuda):
         torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("preset,ragged", [("small", True), ("dataset", "jitter")])
+def test_generator_forward_in_one_host_call_equals_op_by_op_path(cuda, preset, ragged):
+    """bg_generator_forward_f32 (the whole graph-free forward issued by one C call) against the op-by-op host path:
+    the same kernels with the same arguments, so every output must agree bit for bit -- with explicit noise, with
+    noise drawn inside (same generator seed), and with the kept derived weights the trainer passes in."""
+    from building_gan_amd import models as hm
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup(preset, 57, ragged, cuda)
+    nz, pzd = _to(noise, cuda), pz.to(cuda)
+    with torch.no_grad():
+        derived = [t.clone() for t in Gh.voxelGNN.derived_weights()]
+    res = {}
+    for fused in (True, False):
+        hm.FUSE_GENERATOR_FORWARD = fused
+        try:
+            with torch.no_grad():
+                a = Gh(gpu, pzd, None, nz)
+                torch.manual_seed(5)
+                b = Gh(gpu, pzd, None, None)
+                c = Gh(gpu, pzd, None, nz, derived)
+            res[fused] = (a, b, c)
+        finally:
+            hm.FUSE_GENERATOR_FORWARD = True
+    for ra, rb in zip(res[True], res[False]):
+        out_a, soft_a, mask_a, att_a, idx_a = ra
+        out_b, soft_b, mask_b, att_b, idx_b = rb
+        assert torch.equal(idx_a, idx_b) and idx_a.dtype == torch.int64
+        assert torch.equal(out_a, out_b) and torch.equal(soft_a, soft_b)
+        for k in ("hard", "soft"):
+            assert mask_a[k].shape == mask_b[k].shape and att_a[k].shape == att_b[k].shape
+            assert torch.equal(mask_a[k], mask_b[k]) and torch.equal(att_a[k], att_b[k])
+    assert not torch.equal(res[True][0][3]["soft"], res[True][1][3]["soft"])          # other noise, other pointer weights
+
+
 def test_generator_block_node_equals_op_by_op_path(cuda):
     """ops.GBlock (one autograd node, hand-written backward) against the op-by-op composed block on identical
     weights and inputs: output and every gradient (input, messageMLP, updateMLP) to fp32 rounding."""
