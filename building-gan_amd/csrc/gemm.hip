@@ -369,6 +369,179 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row-panel GEMM for a narrow output (N = 128) with K-contiguous operands (A [M,K], nn.Linear weight W [128,K]):
+// one workgroup owns 16*TMT rows x all 128 columns, so the whole product is <= 256 panels -- ONE per CU, no
+// second round of workgroups (the 64x64-tile kernel runs M = 11,520 as 360 tiles = 1.4 rounds on 256 CUs and is
+// bound by that quantisation).  v_mfma_f32_16x16x4_f32: a wave owns 32 columns (2 column tiles) x all
+// TMT row tiles = 2*TMT independent accumulators (the 40-cycle dependent latency is covered with 6-8 in
+// flight at a 32-cycle issue interval).  K runs in 64-deep steps through a double-buffered LDS image
+// [row][64+4] (pitch 68 = 4 mod 64 dwords: the 16 lanes of a ds_read_b128 group hit 16 distinct 4-bank
+// slots); one b128 read gives a lane the operands of four MFMAs: MFMA j of a 16-deep group multiplies
+// k = 16g + 4*(lane>>4) + j on both operands (a permutation of k the operands share).  Global -> registers
+// -> LDS staging of step s+1 overlaps the MFMAs of step s.  Same epilogue terms as k_gemm.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int TMT, int NJ>
+__global__ __launch_bounds__(256) void k_gemm_panel(GemmArgs g) {
+    constexpr int BK = 64, PITCH = BK + 4, PM = 16 * TMT, BN = 64 * NJ;      // a wave owns 16 NJ columns
+    constexpr int A_SZ = PM * PITCH, B_SZ = BN * PITCH;
+    constexpr int NA = PM * BK / 4 / 256, NB = BN * BK / 4 / 256;       // float4 per thread per step: TMT, 4 NJ
+    constexpr int CP = BN + 4;                                           // pitch of the result image
+    constexpr int NC = PM * BN / 4 / 256;                                // result float4 per thread: TMT NJ
+    constexpr int RL = BN / 4;                                           // lanes per result row
+    extern __shared__ __attribute__((aligned(16))) float smem[];         // 2 * (A_SZ + B_SZ) floats
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * PM;
+    const int n0 = blockIdx.y * BN;
+
+    f32x4 acc[TMT][NJ];
+#pragma unroll
+    for (int i = 0; i < TMT; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][j][q] = 0.f;
+
+    // staging pointers: thread f (+256 i) moves the 16-byte chunk kv = f % 16 of row f / 16
+    const float* pa[NA]; const float* pb[NB];
+    float4 ra[NA], rb[NB];
+    int seg = 0; int64_t k0 = 0, koff = 0;
+    auto point = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = threadIdx.x + 256 * i;
+            int64_t gr = m0 + f / 16;
+            gr = gr < g.M ? gr : g.M - 1;                                 // clamped rows feed results never stored
+            pa[i] = g.A[seg] + gr * g.lda[seg] + 4 * (f % 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = threadIdx.x + 256 * i;
+            pb[i] = g.B + (int64_t)(n0 + f / 16) * g.ldb + koff + 4 * (f % 16);
+        }
+    };
+    auto fetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { ra[i] = bg_ld4(pa[i]); pa[i] += BK; }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { rb[i] = bg_ld4(pb[i]); pb[i] += BK; }
+        k0 += BK;
+        if (k0 >= g.Ks[seg] && seg + 1 < g.n_seg) { koff += g.Ks[seg]; ++seg; k0 = 0; point(); }
+    };
+    auto stash = [&](float* As) {
+        float* Bs = As + A_SZ;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { const int f = threadIdx.x + 256 * i; bg_st4(As + (f / 16) * PITCH + 4 * (f % 16), ra[i]); }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { const int f = threadIdx.x + 256 * i; bg_st4(Bs + (f / 16) * PITCH + 4 * (f % 16), rb[i]); }
+    };
+
+    // epilogue operands: thread f (+256 i) finishes the 16-byte chunk c4 = f % 32 of panel row f / 32 (a row = 32
+    // lanes = one 512-byte line: every load and store of the epilogue is a full-row float4 access).  They are
+    // requested while the LAST K step multiplies, so their latency hides behind its MFMAs.
+    const int c4 = threadIdx.x % RL;
+    float4 e_acc[NC], e_pre[NC], e_res[NC];
+    float e_rs[NC];
+    int64_t e_row[NC];
+    auto prefetch_epilogue = [&]() {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int64_t row = m0 + (threadIdx.x + 256 * i) / RL;
+            e_row[i] = row < g.M ? row : g.M - 1;
+        }
+        if (g.pre_add) {
+            int64_t pr[NC];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) pr[i] = g.pre_rows ? (int64_t)g.pre_rows[e_row[i]] : e_row[i];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) e_pre[i] = bg_ld4(g.pre_add + pr[i] * g.ldp + n0 + 4 * c4);
+        }
+        if (g.acc0) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) e_acc[i] = bg_ld4(g.acc0 + e_row[i] * g.ld0 + n0 + 4 * c4);
+        }
+        if (g.residual) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) e_res[i] = bg_ld4(g.residual + e_row[i] * g.ldr + n0 + 4 * c4);
+        }
+        if (g.row_scale) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) e_rs[i] = g.row_scale[e_row[i]];
+        }
+    };
+
+    point();
+    fetch();
+    stash(smem);
+    __syncthreads();
+    const int steps = g.total_steps;
+    for (int step = 0; step < steps; ++step) {
+        const float* As = smem + (step & 1) * (A_SZ + B_SZ);
+        const float* Bs = As + A_SZ;
+        const bool more = step + 1 < steps;
+        if (more) fetch(); else prefetch_epilogue();
+#pragma unroll
+        for (int kg = 0; kg < BK / 16; ++kg) {
+            float4 af[TMT], bf[NJ];
+#pragma unroll
+            for (int i = 0; i < TMT; ++i) af[i] = bg_ld4(As + (16 * i + r) * PITCH + 16 * kg + 4 * kq);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[j] = bg_ld4(Bs + (16 * NJ * wave + 16 * j + r) * PITCH + 16 * kg + 4 * kq);
+#pragma unroll
+            for (int i = 0; i < TMT; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TMT; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TMT; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TMT; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+            // half way through the step's MFMAs the next step's operands have arrived: their LDS writes are issued
+            // here, between MFMAs that keep the matrix pipe busy, instead of after the last one
+            if (kg == BK / 32 - 1 && more) stash(smem + ((step + 1) & 1) * (A_SZ + B_SZ));
+        }
+        __syncthreads();
+    }
+
+    // the panel's result through LDS (lane holds column (lane & 15), rows 4*(lane>>4) + q of each 16x16 tile), then
+    // row-major float4 work: v = act(rs * (acc0 + sum + bias) + pre_add[pr(row)]) (+ residual)
+    float* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < TMT; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Cs[(16 * i + 4 * kq + q) * CP + 16 * NJ * wave + 16 * j + r] = acc[i][j][q];
+    __syncthreads();
+    const float4 bv = g.bias ? bg_ld4(g.bias + n0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int prow = (threadIdx.x + 256 * i) / RL;
+        if (m0 + prow >= g.M) continue;
+        float4 v = bg_ld4(Cs + prow * CP + 4 * c4);
+        if (g.acc0) v = bg_add4(v, e_acc[i]);
+        v = bg_add4(v, bv);
+        if (g.row_scale) v = bg_scale4(e_rs[i], v);
+        if (g.pre_add) v = bg_add4(v, e_pre[i]);
+        if (g.act == BG_ACT_LEAKY) {
+            v.x = v.x > 0.f ? v.x : v.x * g.slope; v.y = v.y > 0.f ? v.y : v.y * g.slope;
+            v.z = v.z > 0.f ? v.z : v.z * g.slope; v.w = v.w > 0.f ? v.w : v.w * g.slope;
+        }
+        if (g.C2) bg_st4(g.C2 + e_row[i] * g.ldc2 + n0 + 4 * c4, v);
+        if (g.residual) v = bg_add4(v, e_res[i]);
+        bg_st4(g.C + e_row[i] * g.ldc + n0 + 4 * c4, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // 64x64-tile GEMM for K-contiguous A (vector path): operand tiles go global -> LDS by LDS-DMA
 // (global_load_lds_dwordx4, no staging registers) through a ring of STAGES buffers, so STAGES-1
 // K steps of loads are in flight while one is multiplied.  At the 1-3 workgroups per CU that the
@@ -738,6 +911,45 @@ int launch_gemm(int transA, int transB, bool vec, GemmArgs g, int splits, hipStr
     return BG_ERR_ARG;
 }
 
+// tuning hook: BG_GEMM_PANEL=0 keeps the tile kernels for the narrow (N = 128) products
+int panel_mode() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char* e = getenv("BG_GEMM_PANEL");
+        cached = e ? (atoi(e) != 0) : 1;
+    }
+    return cached;
+}
+
+template <int TMT, int NJ>
+int launch_gemm_panel(GemmArgs g, hipStream_t s) {
+    constexpr size_t lds_bytes = 2 * (size_t)(16 * TMT + 64 * NJ) * (64 + 4) * sizeof(float);
+    auto kern = k_gemm_panel<TMT, NJ>;
+    static bool raised[BG_MAX_DEVICES] = {};
+    int dev = 0;
+    BG_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= BG_MAX_DEVICES) return BG_ERR_ARG;
+    if (!raised[dev]) {       // above the 64 KB static limit: opt in once per device
+        BG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        raised[dev] = true;
+    }
+    const int64_t panels = (g.M + 16 * TMT - 1) / (16 * TMT);
+    kern<<<dim3((unsigned)panels, (unsigned)(128 / (64 * NJ))), 256, lds_bytes, s>>>(g);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+// tuning hook: BG_GEMM_PANEL_NJ=2 gives a panel workgroup all 128 columns (one workgroup per CU); the default 1 splits
+// the columns over two workgroups that share a CU, so one's prologue / epilogue overlaps the other's MFMAs
+int panel_nj() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char* e = getenv("BG_GEMM_PANEL_NJ");
+        cached = (e && atoi(e) == 2) ? 2 : 1;
+    }
+    return cached;
+}
+
 // tuning hook: BG_GEMM_DMA=0 keeps the register-staged kernel for every shape; 2..4 force a ring depth
 int dma_mode() {
     static int cached = -1;
@@ -896,6 +1108,31 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
     g.residual = residual; g.ldr = ldr; g.M = M; g.N = N;
     g.total_steps = steps; g.steps_per_split = steps; g.partial = nullptr;
     hipStream_t st = (hipStream_t)stream;
+    // narrow output, K-contiguous operands, a few thousand rows: one row panel per CU (k_gemm_panel)
+    if (tile_override() == 0 && panel_mode() && !transA && transB && vec && N == 128 && M >= 2048 && M <= 64 * 256 &&
+        !bk_override()) {
+        bool whole = true;
+        int64_t psteps = 0;
+        for (int s = 0; s < n_seg; ++s) { whole = whole && Ks[s] > 0 && Ks[s] % 64 == 0; psteps += Ks[s] / 64; }
+        // its epilogue moves whole rows as float4: every epilogue operand 16-byte aligned with a pitch % 4 == 0
+        auto al = [](const void* p, int64_t ld) { return !p || (bg_aligned16(p) && ld % 4 == 0); };
+        whole = whole && al(C, ldc) && al(residual, ldr) && al(pre_add, ldp) && al(acc_init, ld_acc) &&
+                al(pre_residual_out, ld_pro) && al(bias, 0);
+        if (whole) {
+            g.total_steps = (int)psteps; g.steps_per_split = (int)psteps;
+            int64_t t = (M + 16 * 256 - 1) / (16 * 256);                 // 16-row tiles per panel so that panels <= 256
+            { static int force = -1; if (force < 0) { const char* e = getenv("BG_GEMM_PANEL_T"); force = e ? atoi(e) : 0; }
+              if (force >= 2 && force <= 4) t = force; }
+            if (panel_nj() == 2) {
+                if (t <= 2) return launch_gemm_panel<2, 2>(g, st);
+                if (t == 3) return launch_gemm_panel<3, 2>(g, st);
+                return launch_gemm_panel<4, 2>(g, st);
+            }
+            if (t <= 2) return launch_gemm_panel<2, 1>(g, st);
+            if (t == 3) return launch_gemm_panel<3, 1>(g, st);
+            return launch_gemm_panel<4, 1>(g, st);
+        }
+    }
     // few tiles and a moderate K: one 32x32 tile per workgroup, K split over its waves (needs the
     // 16-byte path on A; B is read by 16-byte chunks when K-contiguous, by dwords otherwise)
     if (tile_override() == 0 && !transA && vec && skinny_mode() && Ktot <= 4096 && !acc_init && !pre_residual_out &&

@@ -186,7 +186,7 @@ def test_gemm_layouts(cuda, ta, tb):
     assert torch.equal(out, Bm)
 
 
-@pytest.mark.parametrize("M,N,K", [(11520, 128, 256), (300, 70, 36), (64, 64, 8)])
+@pytest.mark.parametrize("M,N,K", [(11520, 128, 256), (2050, 128, 64), (300, 70, 36), (64, 64, 8)])
 def test_gemm_accumulator_start(cuda, M, N, K):
     """bg_gemm_f32's acc_init: the product starts from a given [M, N] matrix (before bias / activation /
     residual), against the fp64 statement; ragged edge tiles included."""
@@ -439,6 +439,9 @@ def test_one_launch_segment_sum_and_max(cuda):
                                             (500, 256, [256, 256], True),     # skinny kernel, 8 waves
                                             (500, 256, [512], False),         # skinny kernel, B stored [K, N]
                                             (11520, 128, [128, 128, 4], True),  # 64x64 register-staged kernel
+                                            (11520, 128, [128, 128], True),     # row-panel kernel, 48-row panels (one per CU)
+                                            (3001, 128, [64, 192], True),       # row-panel kernel, 32-row panels, ragged last panel
+                                            (12577, 128, [128], True),          # row-panel kernel, 64-row panels
                                             (9000, 260, [128], False),        # same, B stored [K, N]
                                             (40000, 128, [128, 128, 4], True),  # LDS-DMA ring kernel (>= 512 tiles)
                                             (33000, 104, [256], False)])      # LDS-DMA ring kernel, B stored [K, N]

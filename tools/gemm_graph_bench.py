@@ -22,9 +22,10 @@ def timeit(fn):
     for _ in range(10): g.replay()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / 200 * 1e3
-def nt(name, M, N, Ks, pre=False, leaky=False, bias=False, res=False, gather=False):
+def nt(name, M, N, Ks, pre=False, leaky=False, bias=False, res=False, gather=False, acc=False):
     xs = [R(M, k) for k in Ks]; W = R(N, sum(Ks))
     kw = {}
+    if acc: kw["acc_init"] = R(M, N)
     if pre: kw["pre_add"] = R(M, N)
     if gather:
         kw["pre_add"] = R(80, N); kw["pre_rows"] = (torch.arange(M, device=dev) // 144).to(torch.int32)
@@ -39,6 +40,9 @@ nt("G block K=128+128+4 bias+gather+leaky+res", M, 128, [128, 128, 4], leaky=Tru
 nt("G block K=128+128+4 plain", M, 128, [128, 128, 4])
 nt("G block K=128+128 plain", M, 128, [128, 128])
 nt("G block K=128+128 bias+gather+leaky+res", M, 128, [128, 128], leaky=True, bias=True, res=True, gather=True)
+nt("G block K=128+128 acc_init+gather+leaky+res (the step's)", M, 128, [128, 128], leaky=True, res=True, gather=True, acc=True)
+for m in (10130, 11299, 12576):
+    nt("same, M=%d" % m, m, 128, [128, 128], leaky=True, res=True, gather=True, acc=True)
 nt("NN_v K=128 bias", M, 128, [128], bias=True)
 nt("D final N=256 K=416", M, 256, [416])
 nt("D label N=256 K=104 pre", M, 256, [104], pre=True)
