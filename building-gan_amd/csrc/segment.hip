@@ -97,6 +97,76 @@ __global__ __launch_bounds__(256) void k_spmm_vec(SpmmArgs a) {
     spmm_vec_body<LPR, GENERAL>(a, xcd_remap(blockIdx.x, gridDim.x));
 }
 
+// The plain gather-sum (no edge weights, no column scale) with its memory round trips batched: a lane group owns R
+// consecutive rows and issues, for all of them at once, the row pointers, then up to D column indices per row, then
+// the gathers of every slot -- three dependent round trips per R rows where the loop above pays one per slot group
+// (index, then row, then the next slot ..).  Sums run in slot order (bit-identical to the loop); slots past D
+// (rows longer than D) continue in the loop form.
+template <int LPR, int R>
+__global__ __launch_bounds__(256) void k_spmm_batched(SpmmArgs a) {
+    constexpr int RPW = 64 / LPR, D = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR;
+    const int64_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row0 = ((blk * (blockDim.x >> 6) + wave) * RPW + lane / LPR) * R;
+    if (row0 >= a.n_rows || sub >= a.H4) return;
+    int32_t rp[R + 1];
+#pragma unroll
+    for (int i = 0; i <= R; ++i) rp[i] = a.rowptr[row0 + i < a.n_rows ? row0 + i : a.n_rows];
+    int32_t c[R][D];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int s = 0; s < D; ++s) c[r][s] = rp[r] + s < rp[r + 1] ? a.col[rp[r] + s] : -1;
+    const float* xb = a.x + 4 * sub;
+    float4 v[R][D];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+            if (c[r][s] >= 0) v[r][s] = bg_ld4(xb + (int64_t)c[r][s] * a.ldx);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r;
+        if (row >= a.n_rows) break;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+            if (c[r][s] >= 0) acc = bg_add4(acc, v[r][s]);
+        for (int32_t k = rp[r] + D; k < rp[r + 1]; ++k) acc = bg_add4(acc, bg_ld4(xb + (int64_t)a.col[k] * a.ldx));
+        if (a.row_mode) {
+            const float sc = a.row_scale[row];
+            acc.x = apply_scale(acc.x, sc, a.row_mode); acc.y = apply_scale(acc.y, sc, a.row_mode);
+            acc.z = apply_scale(acc.z, sc, a.row_mode); acc.w = apply_scale(acc.w, sc, a.row_mode);
+        }
+        if (a.add1) acc = bg_add4(acc, bg_ld4(a.add1 + row * a.ld1 + 4 * sub));
+        if (a.add2) acc = bg_add4(acc, bg_ld4(a.add2 + row * a.ld2 + 4 * sub));
+        if (a.nt_store) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f o = {acc.x, acc.y, acc.z, acc.w};
+            __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(a.out + row * a.ldo + 4 * sub));
+        } else {
+            bg_st4(a.out + row * a.ldo + 4 * sub, acc);
+        }
+    }
+}
+
+template <int R>
+int launch_spmm_batched(const SpmmArgs& a, hipStream_t s) {
+    int lpr = 1;
+    while (lpr < a.H4) lpr <<= 1;
+    const int gpb = 4 * (64 / lpr);                                   // lane groups per 256-thread workgroup
+    const int grid = bg_grid_for((a.n_rows + R - 1) / R, gpb, 0x7fffffff);
+    switch (lpr) {
+        case 16: k_spmm_batched<16, R><<<grid, 256, 0, s>>>(a); break;
+        case 32: k_spmm_batched<32, R><<<grid, 256, 0, s>>>(a); break;
+        case 64: k_spmm_batched<64, R><<<grid, 256, 0, s>>>(a); break;
+        default: return BG_ERR_SHAPE;
+    }
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
 // scalar path: one thread per (row, channel)
 __global__ void k_spmm_scalar(SpmmArgs a, int H) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,7 +223,7 @@ int spmm_dispatch(SpmmArgs a, int64_t H, hipStream_t s) {
     }
     const bool general = !a.col || a.edge_w || a.col_mode;
     {
-        static const int64_t nt_bytes = [] { const char* e = getenv("BG_SPMM_NT_MB"); return (int64_t)(e ? atoi(e) : 128) << 20; }();
+        static const int64_t nt_bytes = [] { const char* e = getenv("BG_SPMM_NT_MB"); return (int64_t)(e ? atoi(e) : 64) << 20; }();
         a.nt_store = nt_bytes > 0 && a.n_rows * H * 4 >= nt_bytes;
     }
     for (int64_t h0 = 0; h0 < H; h0 += 256) {   // panels of 64 float4 columns
@@ -163,7 +233,15 @@ int spmm_dispatch(SpmmArgs a, int64_t H, hipStream_t s) {
         if (a.add2) p.add2 = a.add2 + h0;
         if (a.gadd) p.gadd = a.gadd + h0;
         p.H4 = (int)((H - h0 < 256 ? H - h0 : 256) / 4);
-        int rc = general ? launch_spmm_vec<true>(p, s) : launch_spmm_vec<false>(p, s);
+        int rc;
+        // large plain gather-sums: the batched form (all of a row's indices, then all of its gathers, in flight at
+        // once): 70.9 -> 64.7 us at 10^6 edges streaming from HBM, unchanged when the operand sits in the Infinity
+        // Cache; BG_SPMM_BATCH=0 keeps the loop form for A/B runs
+        static const int batch_rows = [] { const char* e = getenv("BG_SPMM_BATCH"); return e ? atoi(e) : 1; }();
+        if (!general && !p.gadd && p.H4 >= 16 && batch_rows > 0 && p.n_rows >= 4096)
+            rc = batch_rows == 1 ? launch_spmm_batched<1>(p, s) : (batch_rows == 2 ? launch_spmm_batched<2>(p, s) : launch_spmm_batched<4>(p, s));
+        else
+            rc = general ? launch_spmm_vec<true>(p, s) : launch_spmm_vec<false>(p, s);
         if (rc != BG_OK) return rc;
     }
     return BG_OK;

@@ -39,7 +39,7 @@ def test_gather_mean_bit_exact_at_million_edges(cuda, H):
     ref = scatter_mean(x.index_select(0, cpu.voxel_edge[0]), cpu.voxel_edge[1], sz["Nv"])
     out = ops.spmm_raw(plan.vox_mean, x.to(cuda))
     if H == 256:
-        assert out.numel() * 4 >= 128 << 20            # the non-temporal-store branch of k_spmm_vec
+        assert out.numel() * 4 >= 64 << 20             # the non-temporal-store branch of the gather kernels
     assert torch.equal(out.cpu(), ref)
     # the transposed operator (the backward of the same layer) against the dense identity <A x, y> = <x, A^T y>
     y = torch.rand(sz["Nv"], H) * 2 - 1
