@@ -68,6 +68,8 @@ SIGNATURES = {
     "bg_gemm_tn_splitk_f32": [_i64, _i64, _p, _i64, _int, _p, _p, _p, _p, _i64, _p, _i32, _int, _p],
     "bg_colsum_f32": [_p, _i64, _i64, _i64, _p, _i32, _p, _int, _p],
     "bg_generator_forward_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
+    "bg_d_coef_forward_f32": [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _p],
+    "bg_d_coef_backward_f32": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "bg_adam_f32": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i32, _p, _p],
 }
 
@@ -113,6 +115,8 @@ def load() -> C.CDLL:
     lib.bg_version.restype = C.c_int
     lib.bg_generator_forward_workspace.restype = C.c_int64
     lib.bg_generator_forward_workspace.argtypes = [_i64] * 5
+    lib.bg_d_coef_backward_workspace.restype = C.c_int64
+    lib.bg_d_coef_backward_workspace.argtypes = [_i64] * 4
     lib.bg_abi_sizeof.restype = C.c_int64
     lib.bg_abi_sizeof.argtypes = [C.c_int]
     for which, st in enumerate((GeneratorWeights, GeneratorPlan)):

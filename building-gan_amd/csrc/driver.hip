@@ -159,3 +159,75 @@ extern "C" int bg_generator_forward_f32(const bgGeneratorWeights* w, const bgGen
     return bg_construct_output_f32(mask_hard, att_hard, att_soft, p->cx_rowptr, p->cx_col, cls, w->n_class, w->n_class,
                                    out, soft_out, idx, Nv, s);
 }
+
+// ---------------------------------------------------------------- collapsed discriminator: coefficient recurrence
+namespace {
+int64_t coef_splits(int64_t M, int64_t R) {          // as ops.gemm_tn_raw: M x (M | M) output, reduction R
+    const int64_t tiles = ((M + 63) / 64) * 2 * ((M + 63) / 64);
+    const int64_t steps = (R + 31) / 32;
+    int64_t sp = (512 + tiles - 1) / tiles;
+    if (sp > steps) sp = steps;
+    if (sp > 256) sp = 256;
+    return sp < 1 ? 1 : sp;
+}
+}  // namespace
+
+extern "C" int bg_d_coef_forward_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b,
+                                     const float* pe, const float* Wc, int64_t ldw, const float* bc, int64_t H,
+                                     int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L,
+                                     float* xall, float* efull, bgStream s) {
+    if (!fe_w || !fe_b || !le_w || !le_b || !pe || !Wc || !bc || !xall || !efull) return BG_ERR_ARG;
+    if (H <= 0 || L < 0 || ds < nf + ML + 5 || dl < nl || ldw < 4 * H + 4) return BG_ERR_ARG;
+    const int64_t H2 = 2 * H, du = ds + dl, N = (L + 1) * du, S = N + du;
+    hipStream_t st = (hipStream_t)s;
+    BG_HIP(hipMemsetAsync(xall, 0, sizeof(float) * (size_t)((L + 1) * S * H2), st));
+    BG_HIP(hipMemsetAsync(efull, 0, sizeof(float) * (size_t)(N * H2), st));
+    BG_TRY(bg_d_coef_init_f32(fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, H, nf, nl, ML, ds, dl, xall + du * H2, efull, s));
+    for (int64_t m = 0; m < L; ++m) {
+        const int64_t rows = N < (m + 2) * du ? N : (m + 2) * du;       // blocks above m+1 are still zero
+        float* cur = xall + m * S * H2;
+        const float* A[4] = {cur + du * H2, cur, nullptr, nullptr};
+        const int64_t ld[4] = {H2, H2, 0, 0}, Ks[4] = {H2, H2, 0, 0};
+        BG_TRY(bg_gemm_f32(0, 1, rows, H2, 2, A, ld, Ks, Wc, ldw, xall + (m + 1) * S * H2 + du * H2, H2, nullptr, nullptr,
+                           BG_ACT_NONE, 0.01f, cur + du * H2, H2, efull, H2, nullptr, nullptr, 0, nullptr, 0, s));
+    }
+    return BG_OK;
+}
+
+extern "C" int64_t bg_d_coef_backward_workspace(int64_t H, int64_t ds, int64_t dl, int64_t L) {
+    if (H <= 0 || ds < 0 || dl < 0 || L < 0) return -1;
+    const int64_t H2 = 2 * H, du = ds + dl, S = (L + 2) * du;
+    return coef_splits(H2, L * S) * H2 * 2 * H2;
+}
+
+extern "C" int bg_d_coef_backward_f32(const float* g, const float* xall, const float* Wc, int64_t ldw, int64_t H,
+                                      int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L,
+                                      float* gall, float* wab, float* partial, float* gW, float* g_bc, float* g_fe_w,
+                                      float* g_fe_b, float* g_le_w, float* g_le_b, bgStream s) {
+    if (!g || !xall || !Wc || !gall || !wab || !partial || !gW || !g_bc || !g_fe_w || !g_fe_b || !g_le_w || !g_le_b)
+        return BG_ERR_ARG;
+    if (H <= 0 || L < 1 || ldw < 4 * H + 4) return BG_ERR_ARG;
+    const int64_t H2 = 2 * H, du = ds + dl, N = (L + 1) * du, S = N + du;
+    hipStream_t st = (hipStream_t)s;
+    // G^m at rows [0, N) of slab m, du zero rows below it (the shift-up view reads them)
+    BG_HIP(hipMemsetAsync(gall, 0, sizeof(float) * (size_t)((L + 1) * S * H2), st));
+    BG_HIP(hipMemcpyAsync(gall + L * S * H2, g, sizeof(float) * (size_t)(N * H2), hipMemcpyDeviceToDevice, st));
+    // Wab = [Wc[:, :2H]; Wc[:, 2H:4H]]  ([4H, 2H]): G Wa + shiftup(G) Wb
+    BG_HIP(hipMemcpy2DAsync(wab, sizeof(float) * H2, Wc, sizeof(float) * ldw, sizeof(float) * H2, H2, hipMemcpyDeviceToDevice, st));
+    BG_HIP(hipMemcpy2DAsync(wab + H2 * H2, sizeof(float) * H2, Wc + H2, sizeof(float) * ldw, sizeof(float) * H2, H2,
+                            hipMemcpyDeviceToDevice, st));
+    for (int64_t m = L - 1; m >= 0; --m) {
+        const float* nxt = gall + (m + 1) * S * H2;
+        const float* A[4] = {nxt, nxt + du * H2, nullptr, nullptr};
+        const int64_t ld[4] = {H2, H2, 0, 0}, Ks[4] = {H2, H2, 0, 0};
+        BG_TRY(bg_gemm_f32(0, 0, N, H2, 2, A, ld, Ks, wab, H2, gall + m * S * H2, H2, nullptr, nullptr, BG_ACT_NONE, 0.01f,
+                           nxt, H2, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
+    }
+    // dWc[:, :4H] = sum_m G^{m+1 T} [X^m | shift(X^m)]: one long reduction over the stacked slabs
+    const float* B[4] = {xall + du * H2, xall, nullptr, nullptr};
+    const int64_t ldb[4] = {H2, H2, 0, 0}, Ns[4] = {H2, H2, 0, 0};
+    BG_TRY(bg_gemm_tn_splitk_f32(H2, L * S, gall + S * H2, H2, 2, B, ldb, Ns, gW, 2 * H2 + 4, partial,
+                                 (int32_t)coef_splits(H2, L * S), 0, s));
+    return bg_d_coef_init_bwd_f32(gall, S * H2, L, H, nf, nl, ML, ds, dl, g_fe_w, g_fe_b, g_le_w, g_le_b, gW + 2 * H2,
+                                  2 * H2 + 4, g_bc, s);
+}

@@ -18,6 +18,7 @@ from ._lib import check, ptr, stream
 from .plan import Csr, LinOp, SCALE_NONE
 
 ACT_NONE, ACT_LEAKY = 0, 1
+FUSE_COEF_RECURRENCE = True      # PolyCoefD: the coefficient recurrence and its backward as one host call each
 
 _INPUT_GRADS_ONLY = False
 _NO_GRAD_CALL = False      # set by linear(): the call was made under torch.no_grad()
@@ -1509,19 +1510,28 @@ class PolyCoefD(torch.autograd.Function):
         N = (L + 1) * du
         S = N + du
         dev = Wc.device
-        buf = torch.zeros((L + 1) * S * H2 + N * H2, dtype=torch.float32, device=dev)     # one fill for both
-        Xall = buf[:(L + 1) * S * H2].view(L + 1, S, H2)
-        Efull = buf[(L + 1) * S * H2:].view(N, H2)
         Wc2, args = _f32c(Wc), [_f32c(t).contiguous() for t in (fe_w, fe_b, le_w, le_b, pe, bc)]
-        check(lib.bg_d_coef_init_f32(ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(args[4]), ptr(Wc2),
-                                     _ld(Wc2), ptr(args[5]), H, nf, nl, ML, ds, dl, ptr(Xall[0, du:2 * du]),
-                                     ptr(Efull[:du]), stream()), "bg_d_coef_init_f32")
-        W2 = Wc2[:, :2 * H2]
-        for m in range(L):
-            rows = min(N, (m + 2) * du)               # blocks above m+1 are still zero
-            cur = Xall[m]
-            gemm_raw([cur[du:du + rows], cur[:rows]], W2, False, True, residual=cur[du:du + rows],
-                     pre_add=Efull[:rows], out=Xall[m + 1, du:du + rows])
+        if FUSE_COEF_RECURRENCE:
+            # clear + parameter rows + the L products in one host call (shapes depend on the parameters alone)
+            buf = torch.empty((L + 1) * S * H2 + N * H2, dtype=torch.float32, device=dev)
+            Xall = buf[:(L + 1) * S * H2].view(L + 1, S, H2)
+            Efull = buf[(L + 1) * S * H2:].view(N, H2)
+            check(lib.bg_d_coef_forward_f32(ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(args[4]), ptr(Wc2),
+                                            _ld(Wc2), ptr(args[5]), H, nf, nl, ML, ds, dl, L, ptr(Xall), ptr(Efull),
+                                            stream()), "bg_d_coef_forward_f32")
+        else:
+            buf = torch.zeros((L + 1) * S * H2 + N * H2, dtype=torch.float32, device=dev)     # one fill for both
+            Xall = buf[:(L + 1) * S * H2].view(L + 1, S, H2)
+            Efull = buf[(L + 1) * S * H2:].view(N, H2)
+            check(lib.bg_d_coef_init_f32(ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(args[4]), ptr(Wc2),
+                                         _ld(Wc2), ptr(args[5]), H, nf, nl, ML, ds, dl, ptr(Xall[0, du:2 * du]),
+                                         ptr(Efull[:du]), stream()), "bg_d_coef_init_f32")
+            W2 = Wc2[:, :2 * H2]
+            for m in range(L):
+                rows = min(N, (m + 2) * du)               # blocks above m+1 are still zero
+                cur = Xall[m]
+                gemm_raw([cur[du:du + rows], cur[:rows]], W2, False, True, residual=cur[du:du + rows],
+                         pre_add=Efull[:rows], out=Xall[m + 1, du:du + rows])
         ctx.dims = (L, du, ds, dl, H, nf, nl, ML)
         ctx.save_for_backward(Xall, Wc2)
         return Xall[L, du:]
@@ -1536,21 +1546,31 @@ class PolyCoefD(torch.autograd.Function):
         N = (L + 1) * du
         S = N + du
         dev = g.device
+        gW = torch.empty(H2, 2 * H2 + 4, dtype=torch.float32, device=dev)
+        g_fe_w = torch.empty(H, nf, dtype=torch.float32, device=dev)
+        g_le_w = torch.empty(H, nl, dtype=torch.float32, device=dev)
+        g_fe_b = torch.empty(H, dtype=torch.float32, device=dev)
+        g_le_b = torch.empty(H, dtype=torch.float32, device=dev)
+        g_bc = torch.empty(H2, dtype=torch.float32, device=dev)
+        if FUSE_COEF_RECURRENCE and L >= 1 and Wc.stride(1) == 1:
+            g2 = _f32c(g).contiguous()
+            nws = int(lib.bg_d_coef_backward_workspace(H, ds, dl, L))
+            work = torch.empty((L + 1) * S * H2 + 2 * H2 * H2 + nws, dtype=torch.float32, device=dev)
+            Gall, Wab, partial = work[:(L + 1) * S * H2], work[(L + 1) * S * H2:(L + 1) * S * H2 + 2 * H2 * H2], \
+                work[(L + 1) * S * H2 + 2 * H2 * H2:]
+            check(lib.bg_d_coef_backward_f32(ptr(g2), ptr(Xall), ptr(Wc), _ld(Wc), H, nf, nl, ML, ds, dl, L, ptr(Gall),
+                                             ptr(Wab), ptr(partial), ptr(gW), ptr(g_bc), ptr(g_fe_w), ptr(g_fe_b),
+                                             ptr(g_le_w), ptr(g_le_b), stream()), "bg_d_coef_backward_f32")
+            return gW, g_bc, g_fe_w, g_fe_b, g_le_w, g_le_b, None, None, None, None
         Gall = torch.zeros(L + 1, S, H2, dtype=torch.float32, device=dev)
         Gall[L, :N].copy_(g)
         Wab = torch.cat([Wc[:, :H2], Wc[:, H2:2 * H2]], dim=0)       # [2*H2, H2]: G Wa + shiftup(G) Wb
         for m in range(L - 1, -1, -1):
             nxt = Gall[m + 1]
             gemm_raw([nxt[:N], nxt[du:du + N]], Wab, False, False, residual=nxt[:N], out=Gall[m, :N])
-        gW = torch.empty(H2, 2 * H2 + 4, dtype=torch.float32, device=dev)
         Gf = Gall[1:L + 1].reshape(L * S, H2)
         Xf = Xall.view((L + 1) * S, H2)
         gemm_tn_raw(Gf, [Xf[du:du + L * S], Xf[:L * S]], out=gW[:, :2 * H2])
-        g_fe_w = torch.empty(H, nf, dtype=torch.float32, device=dev)
-        g_le_w = torch.empty(H, nl, dtype=torch.float32, device=dev)
-        g_fe_b = torch.empty(H, dtype=torch.float32, device=dev)
-        g_le_b = torch.empty(H, dtype=torch.float32, device=dev)
-        g_bc = torch.empty(H2, dtype=torch.float32, device=dev)
         check(lib.bg_d_coef_init_bwd_f32(ptr(Gall), S * H2, L, H, nf, nl, ML, ds, dl, ptr(g_fe_w), ptr(g_fe_b),
                                          ptr(g_le_w), ptr(g_le_b), gW.data_ptr() + 4 * 2 * H2, 2 * H2 + 4, ptr(g_bc),
                                          stream()), "bg_d_coef_init_bwd_f32")

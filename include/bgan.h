@@ -466,6 +466,23 @@ int bg_generator_forward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan*
                              float* out, float* soft_out, float* mask_hard, float* mask_soft,
                              float* att_hard, float* att_soft, int64_t* idx, bgStream stream);
 
+/* The collapsed discriminator's coefficient recurrence (ops.PolyCoefD; a function of the parameters alone, so its
+ * shapes never depend on the batch) as ONE host call each way.  du = ds + dl, N = (L+1) du, slab S = N + du rows.
+ * forward: xall [(L+1) S, 2H] and efull [N, 2H] are cleared here, bg_d_coef_init_f32 writes the parameter rows, then
+ *   L two-segment products X^{m+1} = X^m + [X^m | shift(X^m)] Wc[:, :4H]^T + E.  The result X^L is xall's last slab
+ *   from row du on.
+ * backward: g [N, 2H] (contiguous) = d/d X^L.  gall [(L+1) S, 2H], wab [4H, 2H] and partial (floats: see
+ *   bg_d_coef_backward_workspace) are workspaces; writes gW [2H, 4H+4] (pitch 4H+4) and the encoders' gradients.
+ * replaces: the same 15 / 18 launches issued one by one from the host.                                  */
+int bg_d_coef_forward_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b, const float* pe,
+                          const float* Wc, int64_t ldw, const float* bc, int64_t H, int64_t nf, int64_t nl, int64_t ML,
+                          int64_t ds, int64_t dl, int64_t L, float* xall, float* efull, bgStream stream);
+int64_t bg_d_coef_backward_workspace(int64_t H, int64_t ds, int64_t dl, int64_t L);   /* floats of `partial` */
+int bg_d_coef_backward_f32(const float* g, const float* xall, const float* Wc, int64_t ldw, int64_t H, int64_t nf,
+                           int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L, float* gall, float* wab,
+                           float* partial, float* gW, float* g_bc, float* g_fe_w, float* g_fe_b, float* g_le_w,
+                           float* g_le_b, bgStream stream);
+
 /* ------------------------------------------------------------------ optimiser ----------- */
 
 /* One Adam step on a flat fp32 buffer (torch.optim.Adam semantics, no weight decay/amsgrad):

@@ -71,6 +71,12 @@ int bg_attention_fwd_f32(const float* a_, int64_t lda, const float* logits, int6
     rec(5, a, sizeof(a) / 8);
     return 0;
 }
+int bg_d_coef_init_f32(const float*, const float*, const float*, const float*, const float*, const float*, int64_t,
+                       const float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, float*, float*, bgStream) { return 0; }
+int bg_d_coef_init_bwd_f32(const float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, float*,
+                           float*, float*, float*, float*, int64_t, float*, bgStream) { return 0; }
+int bg_gemm_tn_splitk_f32(int64_t, int64_t, const float*, int64_t, int, const float* const*, const int64_t*,
+                          const int64_t*, float*, int64_t, float*, int32_t, int, bgStream) { return 0; }
 int bg_construct_output_f32(const float* mask_hard, const float* att_hard, const float* att_soft, const int32_t* rowptr,
                             const int32_t* col, const float* cls, int64_t ldc, int64_t C, float* out, float* soft_out,
                             int64_t* idx, int64_t n_vox, bgStream stream) {

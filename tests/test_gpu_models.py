@@ -713,6 +713,30 @@ def test_coefficient_inputs_by_one_launch_equal_cat_construction(cuda):
         assert float((a - r).abs().max()) <= 2e-5 * scale, n
 
 
+def test_coefficient_recurrence_in_one_host_call_equals_separate_launches(cuda):
+    """ops.FUSE_COEF_RECURRENCE (bg_d_coef_forward_f32 / bg_d_coef_backward_f32: the recurrence's launches issued by
+    one C call each way) against the same launches issued one by one from the host: the collapsed weight, the
+    critic's outputs and every discriminator gradient bit for bit."""
+    from building_gan_amd import ops
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 58, True, cuda)
+    res = {}
+    for fused in (True, False):
+        ops.FUSE_COEF_RECURRENCE = fused
+        try:
+            for p in Dh.parameters():
+                p.grad = None
+            W = Dh.voxelGNN_D.coefficients(gpu.voxel_feature.shape[1] - 3, 32, 8)
+            lab = gpu.voxel_label.clone().requires_grad_(True)
+            b, s = Dh(gpu, lab)
+            (b.sum() + 2 * s.sum()).backward()
+            res[fused] = [W.detach().clone(), b.detach(), s.detach(), lab.grad] + [p.grad.clone() for p in Dh.parameters()]
+        finally:
+            ops.FUSE_COEF_RECURRENCE = True
+    names = ["W", "b", "s", "dlabel"] + [n for n, _ in Dh.named_parameters()]
+    for n, a, r in zip(names, res[True], res[False]):
+        assert torch.equal(a, r), n
+
+
 def test_attention_backward_head_one_launch_equals_separate_launches(cuda):
     """bg_attention_bwd_head_f32 (the head of ops.AttentionNode's backward in one launch) against the same node
     with the head as its seven separate launches: every gradient to fp32 rounding, with all five outputs used
