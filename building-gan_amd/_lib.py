@@ -71,9 +71,12 @@ SIGNATURES = {
     "bg_d_coef_forward_f32": [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _p],
     "bg_d_coef_backward_f32": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "bg_adam_f32": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i32, _p, _p],
+    "bg_plan_layout": [_p, _p, _p, _p],
+    "bg_plan_build": [_p, _p, _p, _p],
 }
 
 _fp = C.c_void_p      # device pointers travel as integers
+BG_OK, BG_ERR_ARG, BG_ERR_SHAPE, BG_ERR_ALIGN, BG_ERR_LAUNCH, BG_ERR_SCRATCH = 0, -1, -2, -3, -4, -5      # include/bgan.h
 
 
 class GeneratorWeights(C.Structure):
@@ -91,6 +94,24 @@ class GeneratorPlan(C.Structure):
                                    "st_rowptr", "st_col", "st_count", "story_of_voxel", "sb_rowptr", "sb_col", "sb_count",
                                    "level", "cx_rowptr", "cx_col")]
 
+
+class PlanIn(C.Structure):
+    """include/bgan.h: bgPlanIn."""
+    _fields_ = [(n, _i64) for n in ("Np", "Nv", "Ep", "Ev", "Ec", "B", "S", "n_slot")] + \
+               [(n, _fp) for n in ("pe_src", "pe_dst", "ve_src", "ve_dst", "cep", "cev", "vfc", "vbi", "pcc", "slot_graph",
+                                   "target_ratio")] + [("chunk_rows", _i32 * 4)]
+
+
+# include/bgan.h: the BGP_* / BGS_* enums (order is the ABI; tests/test_cabi.py checks them against the header)
+PLAN_I32 = ("PF_ROWPTR", "PF_COL", "PF_PERM", "PR_ROWPTR", "PR_COL", "PR_PERM", "SLOT_ROWPTR", "SLOT_COL", "SLOT_PERM",
+            "SG_ROWPTR", "SG_COL", "SG_PERM", "VFW_ROWPTR", "VFW_COL", "VFW_PERM", "VRV_ROWPTR", "VRV_COL", "VRV_PERM",
+            "ST_ROWPTR", "ST_COL", "ST_PERM", "ST_CHUNK", "GR_ROWPTR", "GR_COL", "GR_PERM", "GR_CHUNK",
+            "SGR_ROWPTR", "SGR_COL", "SGR_PERM", "SGR_CHUNK", "CV_ROWPTR", "CV_COL", "CV_PERM", "CP_ROWPTR", "CP_COL",
+            "CP_PERM", "CP_CHUNK", "ARANGE", "PCC32", "SLOTGRAPH32", "VFC32", "VBI32", "STORYGRAPH32", "CEV32", "CEP32",
+            "FIRST", "LEVEL", "SS_ROWPTR", "SS_COL", "PP_ROWPTR", "PP_COL", "FLAGS", "STATS", "CURSOR", "STORYGRAPH64")
+PLAN_F32 = ("PF_COUNT", "SLOT_COUNT", "VFW_COUNT", "ST_COUNT", "SGR_COUNT", "SS_COUNT", "PP_SCALE", "VOX_HAS", "PROG_HAS")
+PLAN_STATS = ("MAX_LEVEL", "MIN_VDEG", "MIN_PDEG", "MIN_CROSS", "MIN_STORY", "MAXLEN_ST", "MAXLEN_GR", "MAXLEN_SGR",
+              "MAXLEN_CP", "MAXLEN_CV", "NNZ_SS", "N_LEAVING", "BLK_NNZ", "VOX_MAX_DEG", "NNZ_SLOT")
 
 _lib: Optional[C.CDLL] = None
 
@@ -119,7 +140,7 @@ def load() -> C.CDLL:
     lib.bg_d_coef_backward_workspace.argtypes = [_i64] * 4
     lib.bg_abi_sizeof.restype = C.c_int64
     lib.bg_abi_sizeof.argtypes = [C.c_int]
-    for which, st in enumerate((GeneratorWeights, GeneratorPlan)):
+    for which, st in enumerate((GeneratorWeights, GeneratorPlan, PlanIn)):
         if lib.bg_abi_sizeof(which) != C.sizeof(st):
             raise BganError(f"{LIB_PATH} was built from another revision of include/bgan.h ({st.__name__}: "
                             f"{lib.bg_abi_sizeof(which)} bytes there, {C.sizeof(st)} here): rebuild it "

@@ -72,6 +72,7 @@ extern "C" int64_t bg_abi_sizeof(int which) {
     switch (which) {
         case 0: return (int64_t)sizeof(bgGeneratorWeights);
         case 1: return (int64_t)sizeof(bgGeneratorPlan);
+        case 2: return (int64_t)sizeof(bgPlanIn);
         default: return -1;
     }
 }

@@ -15,8 +15,8 @@ namespace {
 constexpr int kSmallRow = 16;
 constexpr int kLdsRow = 4096;
 
-__global__ void k_hist(const int64_t* __restrict__ key, int64_t E, int64_t N,
-                       int32_t* __restrict__ count, int32_t* __restrict__ flags) {
+__device__ __forceinline__ void d_hist(const int64_t* __restrict__ key, int64_t E, int64_t N,
+                                       int32_t* __restrict__ count, int32_t* __restrict__ flags) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t base = (int64_t)blockIdx.x * blockDim.x;
     for (; base < E; base += stride) {            // workgroup-uniform trip count
@@ -36,8 +36,13 @@ __global__ void k_hist(const int64_t* __restrict__ key, int64_t E, int64_t N,
     }
 }
 
-// In-place inclusive scan of a[0..n) by ONE workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void k_scan_inplace(int32_t* __restrict__ a, int64_t n) {
+__global__ void k_hist(const int64_t* __restrict__ key, int64_t E, int64_t N,
+                       int32_t* __restrict__ count, int32_t* __restrict__ flags) {
+    d_hist(key, E, N, count, flags);
+}
+
+// In-place inclusive scan of a[0..n) by ONE workgroup of 1024 threads (copy != NULL: a second copy of the result).
+__device__ __forceinline__ void d_scan_inplace(int32_t* __restrict__ a, int64_t n, int32_t* __restrict__ copy) {
     __shared__ int32_t part[1024];
     const int t = threadIdx.x;
     const int64_t per = (n + 1023) / 1024;
@@ -57,12 +62,15 @@ __global__ __launch_bounds__(1024) void k_scan_inplace(int32_t* __restrict__ a, 
     for (int64_t i = b; i < e; ++i) {
         run += a[i];
         a[i] = run;
+        if (copy) copy[i] = run;
     }
 }
 
-__global__ void k_place(const int64_t* __restrict__ key, int64_t E, int64_t N,
-                        int32_t* __restrict__ cursor, int32_t* __restrict__ perm,
-                        const int32_t* __restrict__ flags) {
+__global__ __launch_bounds__(1024) void k_scan_inplace(int32_t* __restrict__ a, int64_t n) { d_scan_inplace(a, n, nullptr); }
+
+__device__ __forceinline__ void d_place(const int64_t* __restrict__ key, int64_t E, int64_t N,
+                                        int32_t* __restrict__ cursor, int32_t* __restrict__ perm,
+                                        const int32_t* __restrict__ flags) {
     const bool sorted = flags[2] == 0 && flags[0] == 0;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride) {
@@ -72,6 +80,12 @@ __global__ void k_place(const int64_t* __restrict__ key, int64_t E, int64_t N,
         int32_t pos = atomicAdd(&cursor[k], 1);
         perm[pos] = (int32_t)e;
     }
+}
+
+__global__ void k_place(const int64_t* __restrict__ key, int64_t E, int64_t N,
+                        int32_t* __restrict__ cursor, int32_t* __restrict__ perm,
+                        const int32_t* __restrict__ flags) {
+    d_place(key, E, N, cursor, perm, flags);
 }
 
 // all-ascending bitonic network on p[0..n): valid for any n (partners beyond n are +inf)
@@ -101,8 +115,8 @@ __device__ void block_bitonic(int32_t* p, int n) {
 }
 
 // one thread per row: short rows are sorted here, long rows go to the work list (worklist[0..))
-__global__ void k_rowsort_short(const int32_t* __restrict__ rowptr, int64_t N, int32_t* __restrict__ perm,
-                                int32_t* __restrict__ flags, int32_t* __restrict__ worklist) {
+__device__ __forceinline__ void d_rowsort_short(const int32_t* __restrict__ rowptr, int64_t N, int32_t* __restrict__ perm,
+                                                int32_t* __restrict__ flags, int32_t* __restrict__ worklist) {
     if (flags[2] == 0 && flags[0] == 0) return;
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= N) return;
@@ -121,10 +135,14 @@ __global__ void k_rowsort_short(const int32_t* __restrict__ rowptr, int64_t N, i
     }
 }
 
+__global__ void k_rowsort_short(const int32_t* __restrict__ rowptr, int64_t N, int32_t* __restrict__ perm,
+                                int32_t* __restrict__ flags, int32_t* __restrict__ worklist) {
+    d_rowsort_short(rowptr, N, perm, flags, worklist);
+}
+
 // workgroups walk the work list; one row at a time per workgroup (LDS when it fits)
-__global__ __launch_bounds__(256) void k_rowsort_long(const int32_t* __restrict__ rowptr, int32_t* __restrict__ perm,
-                                                      const int32_t* __restrict__ flags,
-                                                      const int32_t* __restrict__ worklist) {
+__device__ __forceinline__ void d_rowsort_long(const int32_t* __restrict__ rowptr, int32_t* __restrict__ perm,
+                                               const int32_t* __restrict__ flags, const int32_t* __restrict__ worklist) {
     __shared__ int32_t buf[kLdsRow];
     const int n = flags[3];
     for (int w = blockIdx.x; w < n; w += gridDim.x) {      // workgroup-uniform
@@ -143,16 +161,59 @@ __global__ __launch_bounds__(256) void k_rowsort_long(const int32_t* __restrict_
     }
 }
 
-__global__ void k_fill_col(const int64_t* __restrict__ other, const int32_t* __restrict__ perm, int64_t E,
-                           int32_t* __restrict__ col, int32_t* __restrict__ flags) {
+__global__ __launch_bounds__(256) void k_rowsort_long(const int32_t* __restrict__ rowptr, int32_t* __restrict__ perm,
+                                                      const int32_t* __restrict__ flags,
+                                                      const int32_t* __restrict__ worklist) {
+    d_rowsort_long(rowptr, perm, flags, worklist);
+}
+
+__device__ __forceinline__ void d_fill_col(const int64_t* __restrict__ other, const int32_t* __restrict__ perm, int64_t E,
+                                           int32_t* __restrict__ col, int32_t* __restrict__ flags) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int moved = 0;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < E; k += stride) {
         int32_t p = perm[k];
-        col[k] = (int32_t)other[p];
+        col[k] = other ? (int32_t)other[p] : p;
         moved += (p != (int32_t)k);
     }
     if (moved) atomicAdd(&flags[1], moved);
+}
+
+__global__ void k_fill_col(const int64_t* __restrict__ other, const int32_t* __restrict__ perm, int64_t E,
+                           int32_t* __restrict__ col, int32_t* __restrict__ flags) {
+    d_fill_col(other, perm, E, col, flags);
+}
+
+// ---- the same six steps for up to kMaxBuilds CSR builds at once: blockIdx.y = the build
+constexpr int kMaxBuilds = 11;
+struct CsrJob { const int64_t* key; const int64_t* other; int64_t E, N; int32_t *rowptr, *col, *perm, *cursor, *flags; };
+struct CsrJobs { CsrJob j[kMaxBuilds]; };
+
+__global__ void k_hist_b(CsrJobs J, int32_t* __restrict__ stats) {
+    if (stats && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 32)
+        stats[threadIdx.x] = (threadIdx.x >= 1 && threadIdx.x <= 4) ? 0x7fffffff : 0;       // 1..4 are minima
+    const CsrJob& j = J.j[blockIdx.y];
+    d_hist(j.key, j.E, j.N, j.rowptr, j.flags);
+}
+__global__ __launch_bounds__(1024) void k_scan_b(CsrJobs J) {
+    const CsrJob& j = J.j[blockIdx.x];
+    d_scan_inplace(j.rowptr, j.N + 1, j.cursor);
+}
+__global__ void k_place_b(CsrJobs J) {
+    const CsrJob& j = J.j[blockIdx.y];
+    d_place(j.key, j.E, j.N, j.cursor, j.perm, j.flags);
+}
+__global__ void k_rowsort_short_b(CsrJobs J) {
+    const CsrJob& j = J.j[blockIdx.y];
+    d_rowsort_short(j.rowptr, j.N, j.perm, j.flags, j.cursor);
+}
+__global__ __launch_bounds__(256) void k_rowsort_long_b(CsrJobs J) {
+    const CsrJob& j = J.j[blockIdx.y];
+    d_rowsort_long(j.rowptr, j.perm, j.flags, j.cursor);
+}
+__global__ void k_fill_col_b(CsrJobs J) {
+    const CsrJob& j = J.j[blockIdx.y];
+    d_fill_col(j.other, j.perm, j.E, j.col, j.flags);
 }
 
 __global__ void k_segptr(const int64_t* __restrict__ seg, int64_t n, int64_t nseg,
@@ -218,6 +279,161 @@ __global__ void k_chunk_counts(const int32_t* __restrict__ rowptr, int64_t n, in
     chunk_ptr[i + 1] = (d + R - 1) / R;
 }
 
+
+// ---------------------------------------------------------------- whole-plan build (bg_plan_build): small helpers
+// graph of every story = graph of (any) member voxel (avg_pool_x's batch[perm]); all members agree.  Also fills the
+// per-graph first-floor table with +inf for the floor-level pass that follows.
+__global__ void k_story_graph(const int64_t* __restrict__ vfc, const int64_t* __restrict__ vbi, int64_t n, int64_t S,
+                              int64_t* __restrict__ sg64, int32_t* __restrict__ sg32, int32_t* __restrict__ first, int64_t B) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) first[i] = 0x7fffffff;
+    if (i >= n) return;
+    const int64_t s = vfc[i];
+    if (s < 0 || s >= S) return;
+    if (i > 0 && vfc[i - 1] == s) return;              // one writer per run of a story's voxels
+    sg64[s] = vbi[i];
+    sg32[s] = (int32_t)vbi[i];
+}
+
+// Every elementwise table and statistic that depends only on the finished CSRs, as ONE launch: blockIdx.y = the job.
+enum { MJ_I64_I32, MJ_ARANGE, MJ_HAS, MJ_COUNTS, MJ_ROWLEN, MJ_LEAVING, MJ_BLKNNZ, MJ_CHUNKCNT, MJ_MAXI32 };
+struct MiscJob { const void* a; const void* b; const void* c; void* out; int64_t n; int32_t kind, p0, p1, pad; };
+constexpr int kMaxMisc = 32;
+struct MiscJobs { MiscJob j[kMaxMisc]; };
+
+__global__ void k_plan_misc(MiscJobs J) {
+    const MiscJob& j = J.j[blockIdx.y];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int64_t)blockIdx.x * blockDim.x >= j.n + (j.kind == MJ_CHUNKCNT ? 1 : 0)) return;      // workgroup-uniform
+    const bool live = i < j.n;
+    const int32_t* rp = static_cast<const int32_t*>(j.a);
+    switch (j.kind) {
+        case MJ_I64_I32: if (live) static_cast<int32_t*>(j.out)[i] = (int32_t) static_cast<const int64_t*>(j.a)[i]; break;
+        case MJ_ARANGE: if (live) static_cast<int32_t*>(j.out)[i] = (int32_t)i; break;
+        case MJ_HAS: if (live) static_cast<float*>(j.out)[i] = rp[i + 1] > rp[i] ? 1.f : 0.f; break;
+        case MJ_COUNTS: if (live) { const int d = rp[i + 1] - rp[i]; static_cast<float*>(j.out)[i] = (float)(d > 1 ? d : 1); } break;
+        case MJ_CHUNKCNT: {
+            int32_t* cp = static_cast<int32_t*>(j.out);
+            if (i == 0) cp[0] = 0;
+            if (live) cp[i + 1] = (rp[i + 1] - rp[i] + j.p0 - 1) / j.p0;
+        } break;
+        case MJ_ROWLEN: {                              // min / max row length into stats[p0] / stats[p1] (-1: skip)
+            int d_min = 0x7fffffff, d_max = 0;
+            if (live) { const int d = rp[i + 1] - rp[i]; d_min = d; d_max = d; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                d_min = min(d_min, __shfl_xor(d_min, off, 64));
+                d_max = max(d_max, __shfl_xor(d_max, off, 64));
+            }
+            int32_t* stats = static_cast<int32_t*>(j.out);
+            if ((threadIdx.x & 63) == 0) {
+                if (j.p0 >= 0 && d_min != 0x7fffffff) atomicMin(&stats[j.p0], d_min);
+                if (j.p1 >= 0) atomicMax(&stats[j.p1], d_max);
+            }
+        } break;
+        case MJ_MAXI32: {
+            int m = live ? rp[i] : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+            if ((threadIdx.x & 63) == 0) atomicMax(static_cast<int32_t*>(j.out), m);
+        } break;
+        case MJ_LEAVING: {                             // edges whose ends lie in different graphs (p0 = number of voxels)
+            int bad = 0;
+            if (live) {
+                const int64_t u = static_cast<const int64_t*>(j.a)[i], v = static_cast<const int64_t*>(j.b)[i];
+                const int64_t* vbi = static_cast<const int64_t*>(j.c);
+                bad = (u >= 0 && u < j.p0 && v >= 0 && v < j.p0) ? (vbi[u] != vbi[v]) : 0;
+            }
+            bad = (int)__popcll(__ballot(bad));
+            if ((threadIdx.x & 63) == 0 && bad) atomicAdd(static_cast<int32_t*>(j.out), bad);
+        } break;
+        case MJ_BLKNNZ: {                              // per graph, the edges between its first and last voxel row (max)
+            const int32_t* gr = static_cast<const int32_t*>(j.b);
+            if (live) atomicMax(static_cast<int32_t*>(j.out), rp[gr[i + 1]] - rp[gr[i]]);
+        } break;
+    }
+}
+
+struct ScanJobs { int32_t* a[4]; int64_t n[4]; };
+__global__ __launch_bounds__(1024) void k_scan_jobs(ScanJobs J) { d_scan_inplace(J.a[blockIdx.x], J.n[blockIdx.x], nullptr); }
+
+// exclusive scan of deg(i), i < n, by ONE workgroup: out[0] = base, out[i+1] = base + deg(0) + .. + deg(i)
+template <typename F>
+__device__ void wg_scan(F deg, int n, int32_t base, int32_t* out, int32_t* total) {
+    __shared__ int32_t part[1024];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int per = (n + nt - 1) / nt;
+    const int b = t * per, e = min(b + per, n);
+    int32_t s = 0;
+    for (int i = b; i < e; ++i) s += deg(i);
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {
+        int32_t v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int32_t run = base + part[t] - s;
+    if (t == 0) out[0] = base;
+    for (int i = b; i < e; ++i) { run += deg(i); out[i + 1] = run; }
+    if (t == nt - 1 && total) *total = part[t];
+    __syncthreads();
+}
+
+// stories x stories: row s lists the stories of s's graph (in the graph's CSR order), count = their number
+__device__ __forceinline__ void d_build_ss(const int32_t* __restrict__ sgr_rowptr, const int32_t* __restrict__ sgr_col,
+                                                   const int32_t* __restrict__ story_graph, int S, int B,
+                                                   int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                                   float* __restrict__ count, int32_t* __restrict__ nnz_out) {
+    // a graph id out of range (reported through the story-by-graph flags) gives an empty row, never a stray read
+    auto deg = [&](int s) { const int g = story_graph[s]; return (g < 0 || g >= B) ? 0 : sgr_rowptr[g + 1] - sgr_rowptr[g]; };
+    wg_scan(deg, S, 0, rowptr, nnz_out);
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        const int g = story_graph[s];
+        if (g < 0 || g >= B) { count[s] = 0.f; continue; }
+        const int b = sgr_rowptr[g], d = sgr_rowptr[g + 1] - b, o = rowptr[s];
+        count[s] = (float)d;
+        for (int w = 0; w < d; ++w) col[o + w] = sgr_col[b + w];
+    }
+}
+
+// both aggregations of a ProgramBlock as one operator with 2 Np rows: rows [0, Np) = in-edge mean (multiplier
+// 1 / max(deg, 1)); rows [Np, 2 Np) = the nodes of row i's class slot, multiplier target ratio / slot size
+__device__ __forceinline__ void d_build_pp(const int32_t* __restrict__ pf_rowptr, const int32_t* __restrict__ pf_col,
+                                                   const float* __restrict__ pf_count, const int32_t* __restrict__ slot_rowptr,
+                                                   const int32_t* __restrict__ slot_col, const float* __restrict__ slot_count,
+                                                   const int32_t* __restrict__ pcc, const float* __restrict__ ratio, int Np, int Ep,
+                                                   int n_slot, int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                                   float* __restrict__ scale, int32_t* __restrict__ nnz_out) {
+    auto deg = [&](int i) { const int k = pcc[i]; return (k < 0 || k >= n_slot) ? 0 : slot_rowptr[k + 1] - slot_rowptr[k]; };
+    wg_scan(deg, Np, Ep, rowptr + Np, nnz_out);          // rowptr[Np] = Ep = pf_rowptr[Np]
+    for (int i = threadIdx.x; i < Np; i += blockDim.x) {
+        rowptr[i] = pf_rowptr[i];
+        scale[i] = __fdiv_rn(1.0f, pf_count[i]);
+        const int k = pcc[i];
+        if (k < 0 || k >= n_slot) { scale[Np + i] = 0.f; continue; }
+        const int b = slot_rowptr[k], d = slot_rowptr[k + 1] - b, o = rowptr[Np + i];
+        scale[Np + i] = __fdiv_rn(ratio[k], slot_count[k]);
+        for (int w = 0; w < d; ++w) col[o + w] = slot_col[b + w];
+    }
+    for (int e = threadIdx.x; e < Ep; e += blockDim.x) col[e] = pf_col[e];
+}
+
+struct DerivedArgs {
+    const int32_t *sgr_rowptr, *sgr_col, *story_graph; int S, B; int32_t *ss_rowptr, *ss_col; float* ss_count; int32_t* nnz_ss;
+    const int32_t *pf_rowptr, *pf_col; const float* pf_count; const int32_t *slot_rowptr, *slot_col; const float* slot_count;
+    const int32_t* pcc; const float* ratio; int Np, Ep, n_slot; int32_t *pp_rowptr, *pp_col; float* pp_scale; int32_t* nnz_slot;
+};
+// workgroup 0: stories x stories; workgroup 1: the ProgramBlock pair operator
+__global__ __launch_bounds__(1024) void k_build_derived(DerivedArgs a) {
+    if (blockIdx.x == 0)
+        d_build_ss(a.sgr_rowptr, a.sgr_col, a.story_graph, a.S, a.B, a.ss_rowptr, a.ss_col, a.ss_count, a.nnz_ss);
+    else
+        d_build_pp(a.pf_rowptr, a.pf_col, a.pf_count, a.slot_rowptr, a.slot_col, a.slot_count, a.pcc, a.ratio, a.Np, a.Ep,
+                   a.n_slot, a.pp_rowptr, a.pp_col, a.pp_scale, a.nnz_slot);
+}
+
 }  // namespace
 
 extern "C" {
@@ -240,7 +456,7 @@ int bg_plan_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N,
                 int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* cursor, int32_t* flags,
                 bgStream stream) {
     if (E < 0 || N < 0 || !rowptr || !cursor || !flags) return BG_ERR_ARG;
-    if (E > 0 && (!key || !other || !col || !perm)) return BG_ERR_ARG;
+    if (E > 0 && (!key || !col || !perm)) return BG_ERR_ARG;        /* other == NULL: slot k points at row perm[k] */
     if (E >= (int64_t)1 << 31 || N >= ((int64_t)1 << 31) - 1) return BG_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     BG_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (N + 1), s));
@@ -308,6 +524,196 @@ int bg_plan_chunks(const int32_t* rowptr, int64_t n_rows, int32_t rows_per_chunk
     k_chunk_counts<<<bg_grid_for(n_rows + 1, 256), 256, 0, s>>>(rowptr, n_rows, rows_per_chunk, chunk_ptr);
     BG_LAUNCH_CHECK();
     k_scan_inplace<<<1, 1024, 0, s>>>(chunk_ptr, n_rows + 1);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+// ---------------------------------------------------------------- the whole plan in one call
+namespace {
+struct PlanLayout { int64_t oi[BGP_N_I32]; int64_t of[BGP_N_F32]; int64_t ni, nf, zero_end; int64_t cursor_off[kMaxBuilds]; };
+
+inline int64_t pad64(int64_t n) { return (n + 63) / 64 * 64; }
+
+// rows of the 11 builds, in flag order: pf, pr, slot, sg, vfw, vrv, st, gr, sgr, cv, cp
+inline void build_rows(const bgPlanIn& p, int64_t* N) {
+    const int64_t r[kMaxBuilds] = {p.Np, p.Np, p.n_slot, p.B, p.Nv, p.Nv, p.S, p.B, p.B, p.Nv, p.Np};
+    for (int i = 0; i < kMaxBuilds; ++i) N[i] = r[i];
+}
+
+int plan_layout(const bgPlanIn& p, PlanLayout& L) {
+    if (p.Np <= 0 || p.Nv <= 0 || p.Ep < 0 || p.Ev <= 0 || p.Ec <= 0 || p.B <= 0 || p.S <= 0 || p.n_slot <= 0) return BG_ERR_SHAPE;
+    if (p.S * p.S > (1 << 22) || p.Np * p.Np > (1 << 22)) return BG_ERR_SHAPE;
+    if (p.Ev >= ((int64_t)1 << 30) || p.Ec >= ((int64_t)1 << 30) || p.Nv >= ((int64_t)1 << 30)) return BG_ERR_SHAPE;
+    int64_t len[BGP_N_I32];
+    const int64_t Np = p.Np, Nv = p.Nv, Ep = p.Ep, Ev = p.Ev, Ec = p.Ec, B = p.B, S = p.S, ns = p.n_slot;
+    int64_t mx = Np > ns ? Np : ns; mx = mx > Nv ? mx : Nv; mx = mx > S ? mx : S; mx = mx > Ec ? mx : Ec; mx = mx > B ? mx : B;
+    len[BGP_PF_ROWPTR] = Np + 1; len[BGP_PF_COL] = Ep; len[BGP_PF_PERM] = Ep;
+    len[BGP_PR_ROWPTR] = Np + 1; len[BGP_PR_COL] = Ep; len[BGP_PR_PERM] = Ep;
+    len[BGP_SLOT_ROWPTR] = ns + 1; len[BGP_SLOT_COL] = Np; len[BGP_SLOT_PERM] = Np;
+    len[BGP_SG_ROWPTR] = B + 1; len[BGP_SG_COL] = ns; len[BGP_SG_PERM] = ns;
+    len[BGP_VFW_ROWPTR] = Nv + 1; len[BGP_VFW_COL] = Ev; len[BGP_VFW_PERM] = Ev;
+    len[BGP_VRV_ROWPTR] = Nv + 1; len[BGP_VRV_COL] = Ev; len[BGP_VRV_PERM] = Ev;
+    len[BGP_ST_ROWPTR] = S + 1; len[BGP_ST_COL] = Nv; len[BGP_ST_PERM] = Nv; len[BGP_ST_CHUNK] = S + 1;
+    len[BGP_GR_ROWPTR] = B + 1; len[BGP_GR_COL] = Nv; len[BGP_GR_PERM] = Nv; len[BGP_GR_CHUNK] = B + 1;
+    len[BGP_SGR_ROWPTR] = B + 1; len[BGP_SGR_COL] = S; len[BGP_SGR_PERM] = S; len[BGP_SGR_CHUNK] = B + 1;
+    len[BGP_CV_ROWPTR] = Nv + 1; len[BGP_CV_COL] = Ec; len[BGP_CV_PERM] = Ec;
+    len[BGP_CP_ROWPTR] = Np + 1; len[BGP_CP_COL] = Ec; len[BGP_CP_PERM] = Ec; len[BGP_CP_CHUNK] = Np + 1;
+    len[BGP_ARANGE] = mx + 1;
+    len[BGP_PCC32] = Np; len[BGP_SLOTGRAPH32] = ns; len[BGP_VFC32] = Nv; len[BGP_VBI32] = Nv; len[BGP_STORYGRAPH32] = S;
+    len[BGP_CEV32] = Ec; len[BGP_CEP32] = Ec;
+    len[BGP_FIRST] = B; len[BGP_LEVEL] = Nv;
+    len[BGP_SS_ROWPTR] = S + 1; len[BGP_SS_COL] = S * S;
+    len[BGP_PP_ROWPTR] = 2 * Np + 1; len[BGP_PP_COL] = Ep + Np * Np;
+    len[BGP_FLAGS] = kMaxBuilds * 4; len[BGP_STATS] = 32;
+    int64_t N[kMaxBuilds];
+    build_rows(p, N);
+    int64_t cur = 0;
+    for (int i = 0; i < kMaxBuilds; ++i) { L.cursor_off[i] = cur; cur += pad64(N[i] + 1); }
+    len[BGP_CURSOR] = cur;
+    len[BGP_STORYGRAPH64] = 2 * S;
+    // the pieces that must start at zero come first and are cleared by one memset; FLAGS and STATS stay adjacent
+    // (the caller reads both back with one copy)
+    static const int zeroed[] = {BGP_PF_ROWPTR, BGP_PR_ROWPTR, BGP_SLOT_ROWPTR, BGP_SG_ROWPTR, BGP_VFW_ROWPTR, BGP_VRV_ROWPTR,
+                                 BGP_ST_ROWPTR, BGP_GR_ROWPTR, BGP_SGR_ROWPTR, BGP_CV_ROWPTR, BGP_CP_ROWPTR,
+                                 BGP_STORYGRAPH32, BGP_STORYGRAPH64, BGP_FLAGS, BGP_STATS};
+    bool placed[BGP_N_I32] = {};
+    int64_t o = 0;
+    for (int k : zeroed) { L.oi[k] = o; o += pad64(len[k]); placed[k] = true; }
+    L.zero_end = L.oi[BGP_STATS];
+    for (int i = 0; i < BGP_N_I32; ++i)
+        if (!placed[i]) { L.oi[i] = o; o += pad64(len[i]); }
+    L.ni = o;
+    const int64_t lf[BGP_N_F32] = {Np, ns, Nv, S, B, S, 2 * Np, Nv, Np};
+    o = 0;
+    for (int i = 0; i < BGP_N_F32; ++i) { L.of[i] = o; o += pad64(lf[i]); }
+    L.nf = o;
+    return BG_OK;
+}
+}  // namespace
+
+int bg_plan_layout(const bgPlanIn* in, int64_t* offs_i32, int64_t* offs_f32, int64_t* total) {
+    if (!in || !offs_i32 || !offs_f32 || !total) return BG_ERR_ARG;
+    PlanLayout L;
+    int rc = plan_layout(*in, L);
+    if (rc != BG_OK) return rc;
+    for (int i = 0; i < BGP_N_I32; ++i) offs_i32[i] = L.oi[i];
+    for (int i = 0; i < BGP_N_F32; ++i) offs_f32[i] = L.of[i];
+    total[0] = L.ni; total[1] = L.nf;
+    return BG_OK;
+}
+
+int bg_plan_build(const bgPlanIn* in, int32_t* ai, float* af, bgStream stream) {
+    if (!in || !ai || !af) return BG_ERR_ARG;
+    const bgPlanIn& p = *in;
+    if (!p.pe_src || !p.pe_dst || !p.ve_src || !p.ve_dst || !p.cep || !p.cev || !p.vfc || !p.vbi || !p.pcc || !p.slot_graph ||
+        !p.target_ratio) return BG_ERR_ARG;
+    for (int i = 0; i < 3; ++i) if (p.chunk_rows[i] <= 0) return BG_ERR_ARG;
+    if (p.chunk_rows[3] < 0) return BG_ERR_ARG;
+    if (!bg_aligned16(ai)) return BG_ERR_ALIGN;
+    PlanLayout L;
+    int rc = plan_layout(p, L);
+    if (rc != BG_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    auto I = [&](int k) { return ai + L.oi[k]; };
+    auto F = [&](int k) { return af + L.of[k]; };
+    int32_t* flags = I(BGP_FLAGS);
+    int32_t* stats = I(BGP_STATS);
+    int64_t* sg64 = reinterpret_cast<int64_t*>(I(BGP_STORYGRAPH64));
+    const int64_t Np = p.Np, Nv = p.Nv, Ep = p.Ep, Ev = p.Ev, Ec = p.Ec, B = p.B, S = p.S, ns = p.n_slot;
+    auto g1 = [](int64_t n) { return bg_grid_for(n, 256); };
+
+    // 1. everything that starts at zero (row pointers, story -> graph tables, flags)
+    BG_HIP(hipMemsetAsync(ai, 0, sizeof(int32_t) * L.zero_end, s));
+    // 2. story -> graph (the key of build 8) and the first-floor table
+    k_story_graph<<<g1(Nv > B ? Nv : B), 256, 0, s>>>(p.vfc, p.vbi, Nv, S, sg64, I(BGP_STORYGRAPH32), I(BGP_FIRST), B);
+    BG_LAUNCH_CHECK();
+    // 3. the eleven CSR builds in lockstep: six launches, blockIdx.y = the build
+    CsrJobs J;
+    const int64_t* keys[kMaxBuilds] = {p.pe_dst, p.pe_src, p.pcc, p.slot_graph, p.ve_dst, p.ve_src, p.vfc, p.vbi, sg64, p.cev, p.cep};
+    const int64_t* others[kMaxBuilds] = {p.pe_src, p.pe_dst, nullptr, nullptr, p.ve_src, p.ve_dst, nullptr, nullptr, nullptr, p.cep, p.cev};
+    const int64_t Es[kMaxBuilds] = {Ep, Ep, Np, ns, Ev, Ev, Nv, Nv, S, Ec, Ec};
+    const int rps[kMaxBuilds] = {BGP_PF_ROWPTR, BGP_PR_ROWPTR, BGP_SLOT_ROWPTR, BGP_SG_ROWPTR, BGP_VFW_ROWPTR, BGP_VRV_ROWPTR,
+                                 BGP_ST_ROWPTR, BGP_GR_ROWPTR, BGP_SGR_ROWPTR, BGP_CV_ROWPTR, BGP_CP_ROWPTR};
+    const int cols[kMaxBuilds] = {BGP_PF_COL, BGP_PR_COL, BGP_SLOT_COL, BGP_SG_COL, BGP_VFW_COL, BGP_VRV_COL, BGP_ST_COL, BGP_GR_COL,
+                                  BGP_SGR_COL, BGP_CV_COL, BGP_CP_COL};
+    int64_t Ns[kMaxBuilds];
+    build_rows(p, Ns);
+    int64_t e_max = 1, n_max = 1;
+    for (int i = 0; i < kMaxBuilds; ++i) {
+        J.j[i] = CsrJob{keys[i], others[i], Es[i], Ns[i], I(rps[i]), I(cols[i]), I(cols[i] + 1), I(BGP_CURSOR) + L.cursor_off[i],
+                        flags + 4 * i};
+        e_max = Es[i] > e_max ? Es[i] : e_max;
+        n_max = Ns[i] > n_max ? Ns[i] : n_max;
+    }
+    const dim3 ge(bg_grid_for(e_max, 256, 2048), kMaxBuilds), gn(g1(n_max), kMaxBuilds);
+    k_hist_b<<<ge, 256, 0, s>>>(J, stats);
+    k_scan_b<<<kMaxBuilds, 1024, 0, s>>>(J);
+    k_place_b<<<ge, 256, 0, s>>>(J);
+    k_rowsort_short_b<<<gn, 256, 0, s>>>(J);
+    k_rowsort_long_b<<<dim3(128, kMaxBuilds), 256, 0, s>>>(J);
+    k_fill_col_b<<<ge, 256, 0, s>>>(J);
+    BG_LAUNCH_CHECK();
+    // 4. floor level of every voxel inside its own building
+    k_floor_min<<<g1(Nv), 256, 0, s>>>(p.vfc, p.vbi, Nv, B, I(BGP_FIRST));
+    k_floor_level<<<g1(Nv), 256, 0, s>>>(p.vfc, p.vbi, Nv, B, I(BGP_FIRST), I(BGP_LEVEL));
+    BG_LAUNCH_CHECK();
+    // 5. int32 copies, counts, chunk counts, statistics: one launch
+    MiscJobs M;
+    int nm = 0;
+    int64_t m_max = 1;
+    auto job = [&](int kind, const void* a, const void* b, const void* c, void* out, int64_t n, int p0 = 0, int p1 = 0) {
+        M.j[nm++] = MiscJob{a, b, c, out, n, kind, p0, p1, 0};
+        m_max = n + 1 > m_max ? n + 1 : m_max;
+    };
+    int64_t mx = Np > ns ? Np : ns; mx = mx > Nv ? mx : Nv; mx = mx > S ? mx : S; mx = mx > Ec ? mx : Ec; mx = mx > B ? mx : B;
+    job(MJ_ARANGE, nullptr, nullptr, nullptr, I(BGP_ARANGE), mx + 1);
+    job(MJ_I64_I32, p.pcc, nullptr, nullptr, I(BGP_PCC32), Np);
+    job(MJ_I64_I32, p.slot_graph, nullptr, nullptr, I(BGP_SLOTGRAPH32), ns);
+    job(MJ_I64_I32, p.vfc, nullptr, nullptr, I(BGP_VFC32), Nv);
+    job(MJ_I64_I32, p.vbi, nullptr, nullptr, I(BGP_VBI32), Nv);
+    job(MJ_I64_I32, p.cev, nullptr, nullptr, I(BGP_CEV32), Ec);
+    job(MJ_I64_I32, p.cep, nullptr, nullptr, I(BGP_CEP32), Ec);
+    job(MJ_COUNTS, I(BGP_PF_ROWPTR), nullptr, nullptr, F(BGP_PF_COUNT), Np);
+    job(MJ_COUNTS, I(BGP_SLOT_ROWPTR), nullptr, nullptr, F(BGP_SLOT_COUNT), ns);
+    job(MJ_COUNTS, I(BGP_VFW_ROWPTR), nullptr, nullptr, F(BGP_VFW_COUNT), Nv);
+    job(MJ_COUNTS, I(BGP_ST_ROWPTR), nullptr, nullptr, F(BGP_ST_COUNT), S);
+    job(MJ_COUNTS, I(BGP_SGR_ROWPTR), nullptr, nullptr, F(BGP_SGR_COUNT), B);
+    job(MJ_HAS, I(BGP_VFW_ROWPTR), nullptr, nullptr, F(BGP_VOX_HAS), Nv);
+    job(MJ_HAS, I(BGP_PF_ROWPTR), nullptr, nullptr, F(BGP_PROG_HAS), Np);
+    job(MJ_CHUNKCNT, I(BGP_ST_ROWPTR), nullptr, nullptr, I(BGP_ST_CHUNK), S, p.chunk_rows[0]);
+    job(MJ_CHUNKCNT, I(BGP_GR_ROWPTR), nullptr, nullptr, I(BGP_GR_CHUNK), B, p.chunk_rows[1]);
+    job(MJ_CHUNKCNT, I(BGP_SGR_ROWPTR), nullptr, nullptr, I(BGP_SGR_CHUNK), B, p.chunk_rows[2]);
+    if (p.chunk_rows[3] > 0) job(MJ_CHUNKCNT, I(BGP_CP_ROWPTR), nullptr, nullptr, I(BGP_CP_CHUNK), Np, p.chunk_rows[3]);
+    job(MJ_MAXI32, I(BGP_LEVEL), nullptr, nullptr, stats + BGS_MAX_LEVEL, Nv);
+    job(MJ_ROWLEN, I(BGP_VFW_ROWPTR), nullptr, nullptr, stats, Nv, BGS_MIN_VDEG, BGS_VOX_MAX_DEG);
+    job(MJ_ROWLEN, I(BGP_VRV_ROWPTR), nullptr, nullptr, stats, Nv, -1, BGS_VOX_MAX_DEG);
+    job(MJ_ROWLEN, I(BGP_PF_ROWPTR), nullptr, nullptr, stats, Np, BGS_MIN_PDEG, -1);
+    job(MJ_ROWLEN, I(BGP_CV_ROWPTR), nullptr, nullptr, stats, Nv, BGS_MIN_CROSS, BGS_MAXLEN_CV);
+    job(MJ_ROWLEN, I(BGP_ST_ROWPTR), nullptr, nullptr, stats, S, BGS_MIN_STORY, BGS_MAXLEN_ST);
+    job(MJ_ROWLEN, I(BGP_GR_ROWPTR), nullptr, nullptr, stats, B, -1, BGS_MAXLEN_GR);
+    job(MJ_ROWLEN, I(BGP_SGR_ROWPTR), nullptr, nullptr, stats, B, -1, BGS_MAXLEN_SGR);
+    job(MJ_ROWLEN, I(BGP_CP_ROWPTR), nullptr, nullptr, stats, Np, -1, BGS_MAXLEN_CP);
+    job(MJ_LEAVING, p.ve_src, p.ve_dst, p.vbi, stats + BGS_N_LEAVING, Ev, (int)Nv);
+    job(MJ_BLKNNZ, I(BGP_VFW_ROWPTR), I(BGP_GR_ROWPTR), nullptr, stats + BGS_BLK_NNZ, B);
+    static_assert(kMaxMisc >= 29, "job table");
+    k_plan_misc<<<dim3(g1(m_max), nm), 256, 0, s>>>(M);
+    BG_LAUNCH_CHECK();
+    // 6. chunk tables: scans of the chunk counts
+    ScanJobs SJ;
+    int nsj = 0;
+    SJ.a[nsj] = I(BGP_ST_CHUNK); SJ.n[nsj++] = S + 1;
+    SJ.a[nsj] = I(BGP_GR_CHUNK); SJ.n[nsj++] = B + 1;
+    SJ.a[nsj] = I(BGP_SGR_CHUNK); SJ.n[nsj++] = B + 1;
+    if (p.chunk_rows[3] > 0) { SJ.a[nsj] = I(BGP_CP_CHUNK); SJ.n[nsj++] = Np + 1; }
+    for (int i = nsj; i < 4; ++i) { SJ.a[i] = nullptr; SJ.n[i] = 0; }
+    k_scan_jobs<<<nsj, 1024, 0, s>>>(SJ);
+    // 7. the two derived operators
+    DerivedArgs D{I(BGP_SGR_ROWPTR), I(BGP_SGR_COL), I(BGP_STORYGRAPH32), (int)S, (int)B, I(BGP_SS_ROWPTR), I(BGP_SS_COL),
+                  F(BGP_SS_COUNT), stats + BGS_NNZ_SS,
+                  I(BGP_PF_ROWPTR), I(BGP_PF_COL), F(BGP_PF_COUNT), I(BGP_SLOT_ROWPTR), I(BGP_SLOT_COL), F(BGP_SLOT_COUNT),
+                  I(BGP_PCC32), p.target_ratio, (int)Np, (int)Ep, (int)ns, I(BGP_PP_ROWPTR), I(BGP_PP_COL), F(BGP_PP_SCALE),
+                  stats + BGS_NNZ_SLOT};
+    k_build_derived<<<2, 1024, 0, s>>>(D);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

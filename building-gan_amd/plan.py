@@ -8,7 +8,9 @@ torch_geometric call (index_select + scatter pairs, ``torch.unique`` in avg_pool
 """
 from __future__ import annotations
 
+import ctypes as C
 import dataclasses
+import os
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -176,11 +178,173 @@ def _max_plus_one(t: torch.Tensor) -> int:
     return int(t.max().item()) + 1 if t.numel() else 0
 
 
+ONE_CALL_BUILD = os.environ.get("BG_PLAN_ONE_CALL", "1") != "0"     # bg_plan_build; "0": piece by piece
+_I32 = {n: i for i, n in enumerate(_lib.PLAN_I32)}
+_F32 = {n: i for i, n in enumerate(_lib.PLAN_F32)}
+_STAT = {n: i for i, n in enumerate(_lib.PLAN_STATS)}
+_CSR_NAMES = ("program_by_target", "program_by_source", "class_slot", "slot_by_graph", "voxel_by_target", "voxel_by_source",
+              "voxel_by_story", "voxel_by_graph", "story_by_graph", "cross_by_voxel", "cross_by_program")
+
+
+def _chunk_rows(nnz, n_rows):
+    avg = nnz / max(n_rows, 1)
+    return 64 if avg <= 2048 else (256 if avg <= 32768 else 1024)
+
+
+def _check_and_publish(graph, p, flags, min_cross):
+    for name, fl in flags.items():
+        if fl[0]:
+            raise _lib.BganError(f"plan '{name}': {fl[0]} index values out of range")
+    p.ops["flags"] = flags
+    if flags["cross_by_voxel"][1] != 0:
+        raise _lib.BganError("cross_edge_voxel_index_select must be non-decreasing (reference "
+                             "GraphConstructor.py:81-88 builds it voxel-major)")
+    if p.Nv > 0 and min_cross <= 0:
+        raise _lib.BganError("every voxel needs at least one cross edge (reference util.py:24-25 indexes the "
+                             "arg-max of each voxel segment)")
+    if hasattr(graph, "__dict__"):
+        graph.__dict__["_bg_plan"] = p
+    return p
+
+
+def _build_plan_one_call(graph, S) -> Optional[GraphPlan]:
+    """The whole plan by bg_plan_build (include/bgan.h): two arenas, one host call, one read-back.  Returns None for
+    batches it is not laid out for (empty pieces, operators with long rows where the piece-by-piece path would add
+    chunk tables, derived operators above 2^22 slots): those take the piece-by-piece path below, which builds the
+    same plan."""
+    vf = graph.voxel_feature
+    dev = vf.device
+    pe, ve = graph.program_edge, graph.voxel_edge
+    cep, cev = graph.cross_edge_program_index_select, graph.cross_edge_voxel_index_select
+    vfc, vbi, pcc = graph.voxel_floor_cluster, graph.voxel_feature_batch, graph.program_class_cluster
+    slot_graph, ratio = graph.program_target_ratio_batch, graph.program_target_ratio
+    Np, Nv, B, n_slot = int(graph.program_class_feature.shape[0]), int(vf.shape[0]), int(graph.FAR.shape[0]), int(ratio.shape[0])
+    Ep, Ev, Ec = int(pe.shape[1]), int(ve.shape[1]), int(cev.numel())
+    if min(Np, Nv, Ev, Ec, B, S, n_slot) <= 0:
+        return None
+    # the piece-by-piece path adds chunk tables to any of these once its rows average more than LONG_ROW slots
+    for nnz, rows in ((Ep, Np), (Np, n_slot), (n_slot, B), (Ev, Nv), (S, B), (Ec, Nv)):
+        if nnz > LONG_ROW * rows:
+            return None
+    tensors = (pe, ve, cep, cev, vfc, vbi, pcc, slot_graph)
+    if any(t.dtype != torch.int64 or not t.is_contiguous() for t in tensors) or ratio.dtype != torch.float32 \
+            or not ratio.is_contiguous():
+        return None
+    lib = _lib.load()
+    cp_R = _chunk_rows(Ec, Np) if Ec > LONG_ROW * Np else 0
+    R = (_chunk_rows(Nv, S), _chunk_rows(Nv, B), _chunk_rows(S, B), cp_R)
+    pin = _lib.PlanIn(Np, Nv, Ep, Ev, Ec, B, S, n_slot, pe.data_ptr(), pe.data_ptr() + 8 * Ep, ve.data_ptr(),
+                      ve.data_ptr() + 8 * Ev, cep.data_ptr(), cev.data_ptr(), vfc.data_ptr(), vbi.data_ptr(), pcc.data_ptr(),
+                      slot_graph.data_ptr(), ratio.data_ptr(), (C.c_int32 * 4)(*R))
+    oi, of, tot = (C.c_int64 * len(_I32))(), (C.c_int64 * len(_F32))(), (C.c_int64 * 2)()
+    rc = lib.bg_plan_layout(C.byref(pin), oi, of, tot)
+    if rc == _lib.BG_ERR_SHAPE:
+        return None
+    check(rc, "bg_plan_layout")
+    ai = torch.empty(tot[0], dtype=torch.int32, device=dev)
+    af = torch.empty(tot[1], dtype=torch.float32, device=dev)
+    check(lib.bg_plan_build(C.byref(pin), ai.data_ptr(), af.data_ptr(), stream()), "bg_plan_build")
+    host = ai[oi[_I32["FLAGS"]]: oi[_I32["STATS"]] + len(_STAT)].tolist()         # the one synchronisation
+    flags = {nm: tuple(host[4 * i: 4 * i + 4]) for i, nm in enumerate(_CSR_NAMES)}
+    st_off = oi[_I32["STATS"]] - oi[_I32["FLAGS"]]
+    stat = {n: host[st_off + i] for n, i in _STAT.items()}
+
+    def I(name, n):
+        o = oi[_I32[name]]
+        return ai[o: o + n]
+
+    def F(name, n):
+        o = of[_F32[name]]
+        return af[o: o + n]
+
+    def csr(pre, n_rows, n_cols, nnz, count=None):
+        return Csr(I(pre + "_ROWPTR", n_rows + 1), I(pre + "_COL", nnz), I(pre + "_PERM", nnz), n_rows, n_cols, nnz,
+                   count=None if count is None else F(count, n_rows))
+
+    def chunked(c, pre, Rc, max_len):
+        c.chunk_ptr, c.rows_per_chunk, c.n_chunks_ub, c.max_len = I(pre + "_CHUNK", c.n_rows + 1), Rc, c.nnz // Rc + c.n_rows, max_len
+
+    def gather(name, n, n_cols):
+        return Csr(I("ARANGE", n + 1), I(name, n), None, n, n_cols, n)
+
+    p = GraphPlan(B=B, S=S, Np=Np, Nv=Nv, Ep=Ep, Ev=Ev, Ec=Ec, device=dev)
+    o = p.ops
+    o["_arenas"] = (ai, af)
+    pf, pr = csr("PF", Np, Np, Ep, "PF_COUNT"), csr("PR", Np, Np, Ep)
+    o["prog_mean"] = LinOp.pair(pf, pr, pf.count, SCALE_DIV)
+    slot = csr("SLOT", n_slot, Np, Np, "SLOT_COUNT")
+    slot_gather = gather("PCC32", Np, n_slot)
+    o["slot_mean"] = LinOp.pair(slot, slot_gather, slot.count, SCALE_DIV)
+    o["slot_sum"] = LinOp.pair(slot, slot_gather)
+    o["slot_gather"] = o["slot_sum"].T
+    sg = csr("SG", B, n_slot, n_slot)
+    o["slot_graph_sum"] = LinOp.pair(sg, gather("SLOTGRAPH32", n_slot, B))
+    o["slot_graph_gather"] = o["slot_graph_sum"].T
+    vfw, vrv = csr("VFW", Nv, Nv, Ev, "VFW_COUNT"), csr("VRV", Nv, Nv, Ev)
+    o["vox_mean"] = LinOp.pair(vfw, vrv, vfw.count, SCALE_DIV)
+    st = csr("ST", S, Nv, Nv, "ST_COUNT")
+    chunked(st, "ST", R[0], stat["MAXLEN_ST"])
+    st_gather = gather("VFC32", Nv, S)
+    o["story_mean"] = LinOp.pair(st, st_gather, st.count, SCALE_DIV)
+    o["story_gather"] = LinOp.pair(st_gather, st)
+    gr = csr("GR", B, Nv, Nv)
+    chunked(gr, "GR", R[1], stat["MAXLEN_GR"])
+    gr_gather = gather("VBI32", Nv, B)
+    o["graph_gather"] = LinOp.pair(gr_gather, gr)
+    st.seg_of, gr.seg_of = st_gather.col, gr_gather.col
+    o["story_seg"], o["graph_seg"] = st, gr
+    sgr = csr("SGR", B, S, S, "SGR_COUNT")
+    sgr_seg = dataclasses.replace(sgr)
+    chunked(sgr_seg, "SGR", R[2], stat["MAXLEN_SGR"])
+    sgr_seg.seg_of = I("STORYGRAPH32", S)
+    o["story_graph_seg"] = sgr_seg
+    sgr_gather = gather("STORYGRAPH32", S, B)
+    o["graph_of_story_mean"] = LinOp.pair(sgr, sgr_gather, sgr.count, SCALE_DIV)
+    o["story_graph_gather"] = LinOp.pair(sgr_gather, sgr)
+    o["level"] = I("LEVEL", Nv)
+    cv, cp = csr("CV", Nv, Np, Ec), csr("CP", Np, Nv, Ec)
+    cv.max_len = stat["MAXLEN_CV"]
+    if cp_R:
+        chunked(cp, "CP", cp_R, stat["MAXLEN_CP"])
+    o["cross_v"], o["cross_p"] = cv, cp
+    o["cross_v_sum"] = LinOp.pair(cv, cp)
+    edge_by_voxel = Csr(cv.rowptr, cv.perm, None, Nv, Ec, Ec)
+    edge_by_program = Csr(cp.rowptr, cp.perm, None, Np, Ec, Ec, chunk_ptr=cp.chunk_ptr, rows_per_chunk=cp.rows_per_chunk,
+                          n_chunks_ub=cp.n_chunks_ub, max_len=cp.max_len)
+    o["edge_voxel_gather"] = LinOp.pair(gather("CEV32", Ec, Nv), edge_by_voxel)
+    o["edge_program_gather"] = LinOp.pair(gather("CEP32", Ec, Np), edge_by_program)
+    nnz_ss, nnz_slot = stat["NNZ_SS"], stat["NNZ_SLOT"]
+    if nnz_ss > 0:
+        ss = Csr(I("SS_ROWPTR", S + 1), I("SS_COL", nnz_ss), None, S, S, nnz_ss, count=F("SS_COUNT", S))
+        o["story_building_mean"] = LinOp(ss, ss.count, SCALE_DIV)
+    o["prog_pair"] = LinOp(Csr(I("PP_ROWPTR", 2 * Np + 1), I("PP_COL", Ep + nnz_slot), None, 2 * Np, Np, Ep + nnz_slot),
+                           F("PP_SCALE", 2 * Np), SCALE_MUL)
+    if flags["voxel_by_graph"][2] == 0 and stat["N_LEAVING"] == 0:
+        o["vox_blocks"] = VoxelBlocks(gr.rowptr, B, gr.max_len, stat["BLK_NNZ"], stat["VOX_MAX_DEG"])
+    else:
+        o["vox_blocks"] = None
+    o["max_level"] = stat["MAX_LEVEL"]
+    o["vox_all_has"], o["prog_all_has"] = stat["MIN_VDEG"] > 0, stat["MIN_PDEG"] > 0
+    o["stories_all_nonempty"] = stat["MIN_STORY"] > 0
+    o["vox_has"] = F("VOX_HAS", Nv).view(-1, 1)
+    o["prog_has"] = F("PROG_HAS", Np).view(-1, 1)
+    return _check_and_publish(graph, p, flags, stat["MIN_CROSS"])
+
+
 def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     """Build (or fetch the cached) plan for a batch that exposes the row-a0 attributes."""
     cached = graph.__dict__.get("_bg_plan") if hasattr(graph, "__dict__") else None
     if cached is not None:
         return cached
+    if ONE_CALL_BUILD:
+        _lib.require_device(graph.voxel_feature, "build_plan")
+        S1 = num_stories if num_stories is not None else getattr(graph, "num_stories", None)
+        if S1 is None:
+            S1 = _max_plus_one(graph.voxel_floor_cluster)
+        made = _build_plan_one_call(graph, int(S1))
+        if made is not None:
+            return made
+        num_stories = int(S1)
     vf = graph.voxel_feature
     _lib.require_device(vf, "build_plan")
     dev = vf.device
@@ -325,20 +489,7 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     o["max_level"] = int(max_level)
     o["vox_all_has"], o["prog_all_has"] = min_vdeg > 0, min_pdeg > 0
     o["stories_all_nonempty"] = min_story > 0       # then max over a graph = max over its stories' maxima
-    for name, fl in flags.items():
-        bad = fl[0]
-        if bad:
-            raise _lib.BganError(f"plan '{name}': {bad} index values out of range")
-    p.ops["flags"] = flags
-    if flags["cross_by_voxel"][1] != 0:
-        raise _lib.BganError("cross_edge_voxel_index_select must be non-decreasing (reference "
-                             "GraphConstructor.py:81-88 builds it voxel-major)")
-    if Nv > 0 and min_cross <= 0:
-        raise _lib.BganError("every voxel needs at least one cross edge (reference util.py:24-25 indexes the "
-                             "arg-max of each voxel segment)")
     has = (vfw.rowptr[1:] > vfw.rowptr[:-1]).to(torch.float32).view(-1, 1)
     o["vox_has"] = has
     o["prog_has"] = (pf.rowptr[1:] > pf.rowptr[:-1]).to(torch.float32).view(-1, 1)
-    if hasattr(graph, "__dict__"):
-        graph.__dict__["_bg_plan"] = p
-    return p
+    return _check_and_publish(graph, p, flags, min_cross)

@@ -63,6 +63,54 @@ int bg_plan_counts(const int32_t* rowptr, int64_t n_rows, float* count, bgStream
 int bg_plan_chunks(const int32_t* rowptr, int64_t n_rows, int32_t rows_per_chunk,
                    int32_t* chunk_ptr, bgStream stream);
 
+/* ---- the whole index plan of a batch in one host call ------------------------------------------------------
+ * Inputs: the batch's int64 index vectors as the reference's layout holds them (row a0 of SURVEY.md section 8).  */
+typedef struct {
+    int64_t Np, Nv, Ep, Ev, Ec, B, S, n_slot;
+    const int64_t *pe_src, *pe_dst;          /* program_edge[0], program_edge[1]                 [Ep] */
+    const int64_t *ve_src, *ve_dst;          /* voxel_edge[0], voxel_edge[1]                     [Ev] */
+    const int64_t *cep, *cev;                /* cross_edge_{program,voxel}_index_select          [Ec] */
+    const int64_t *vfc, *vbi;                /* voxel_floor_cluster, voxel_feature_batch         [Nv] */
+    const int64_t *pcc;                      /* program_class_cluster                            [Np] */
+    const int64_t *slot_graph;               /* program_target_ratio_batch                       [n_slot] */
+    const float* target_ratio;               /* program_target_ratio                             [n_slot] */
+    int32_t chunk_rows[4];                   /* rows per chunk of: story, graph, story-by-graph, cross-by-program (0: none) */
+} bgPlanIn;
+
+/* Pieces of the plan inside the two arenas (element offsets, every piece 256-byte aligned).  int32 pieces: */
+enum {
+    BGP_PF_ROWPTR, BGP_PF_COL, BGP_PF_PERM, BGP_PR_ROWPTR, BGP_PR_COL, BGP_PR_PERM,          /* program edges by target / source */
+    BGP_SLOT_ROWPTR, BGP_SLOT_COL, BGP_SLOT_PERM, BGP_SG_ROWPTR, BGP_SG_COL, BGP_SG_PERM,    /* nodes by class slot, slots by graph */
+    BGP_VFW_ROWPTR, BGP_VFW_COL, BGP_VFW_PERM, BGP_VRV_ROWPTR, BGP_VRV_COL, BGP_VRV_PERM,    /* voxel edges by target / source */
+    BGP_ST_ROWPTR, BGP_ST_COL, BGP_ST_PERM, BGP_ST_CHUNK,                                    /* voxels by story */
+    BGP_GR_ROWPTR, BGP_GR_COL, BGP_GR_PERM, BGP_GR_CHUNK,                                    /* voxels by graph */
+    BGP_SGR_ROWPTR, BGP_SGR_COL, BGP_SGR_PERM, BGP_SGR_CHUNK,                                /* stories by graph */
+    BGP_CV_ROWPTR, BGP_CV_COL, BGP_CV_PERM, BGP_CP_ROWPTR, BGP_CP_COL, BGP_CP_PERM, BGP_CP_CHUNK,   /* cross edges by voxel / program */
+    BGP_ARANGE, BGP_PCC32, BGP_SLOTGRAPH32, BGP_VFC32, BGP_VBI32, BGP_STORYGRAPH32, BGP_CEV32, BGP_CEP32,
+    BGP_FIRST, BGP_LEVEL, BGP_SS_ROWPTR, BGP_SS_COL, BGP_PP_ROWPTR, BGP_PP_COL, BGP_FLAGS, BGP_STATS, BGP_CURSOR,
+    BGP_STORYGRAPH64,                                                                        /* (int64: two int32 slots per entry) */
+    BGP_N_I32
+};
+/* float pieces: */
+enum { BGP_PF_COUNT, BGP_SLOT_COUNT, BGP_VFW_COUNT, BGP_ST_COUNT, BGP_SGR_COUNT, BGP_SS_COUNT, BGP_PP_SCALE, BGP_VOX_HAS,
+       BGP_PROG_HAS, BGP_N_F32 };
+/* BGP_FLAGS: 11 x 4 validity flags, one quadruple per CSR in the order pf, pr, slot, sg, vfw, vrv, st, gr, sgr, cv, cp
+ * (meaning as bg_plan_csr).  BGP_STATS (int32): */
+enum { BGS_MAX_LEVEL, BGS_MIN_VDEG, BGS_MIN_PDEG, BGS_MIN_CROSS, BGS_MIN_STORY, BGS_MAXLEN_ST, BGS_MAXLEN_GR, BGS_MAXLEN_SGR,
+       BGS_MAXLEN_CP, BGS_MAXLEN_CV, BGS_NNZ_SS, BGS_N_LEAVING, BGS_BLK_NNZ, BGS_VOX_MAX_DEG, BGS_NNZ_SLOT, BGS_N };
+
+/* Element offsets of every piece (offs_i32[BGP_N_I32], offs_f32[BGP_N_F32]) and the arena sizes (total[0] int32
+ * elements, total[1] floats) for these sizes.  BG_ERR_SHAPE when S * S or Np * Np exceeds 2^22 (the two derived
+ * operators are laid out for their upper bound) or a size is zero: build the plan piece by piece instead.          */
+int bg_plan_layout(const bgPlanIn* in, int64_t* offs_i32, int64_t* offs_f32, int64_t* total);
+
+/* Every CSR, segment table, chunk table, floor level, derived operator and statistic of a batch's plan (what
+ * building-gan_amd/plan.py otherwise assembles from ~25 bg_plan_* calls and ~100 host-issued tensor operations) by
+ * ONE host call: ~90 launches issued back to back, no synchronisation; the caller reads BGP_FLAGS / BGP_STATS back
+ * once.  arena_i32 must be 16-byte aligned.
+ * replaces: the COO bookkeeping of every torch_scatter / torch_geometric call of a pass (see bg_plan_csr).          */
+int bg_plan_build(const bgPlanIn* in, int32_t* arena_i32, float* arena_f32, bgStream stream);
+
 /* ------------------------------------------------------------------ segment kernels ----- */
 
 /* Scale modes for bg_spmm_f32 / bg_segreduce_f32 */

@@ -61,6 +61,70 @@ def test_plans_bit_exact(cuda, preset, ragged):
         assert csr.n_chunks_ub >= cptr[-1]
 
 
+def _same(a, b, path, seen):
+    """Field-by-field, bit-for-bit equality of two plans' pieces."""
+    import dataclasses
+    from building_gan_amd.plan import LinOp
+    if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+        assert isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor), path
+        assert a.dtype == b.dtype and a.shape == b.shape, (path, a.dtype, b.dtype, a.shape, b.shape)
+        assert torch.equal(a, b), path
+        assert a.is_contiguous() and a.data_ptr() % 16 == 0 or a.numel() == 0, path
+    elif dataclasses.is_dataclass(a):
+        assert type(a) is type(b), path
+        for f in dataclasses.fields(a):
+            _same(getattr(a, f.name), getattr(b, f.name), f"{path}.{f.name}", seen)
+    elif isinstance(a, LinOp):
+        if id(a) in seen:
+            return
+        seen.add(id(a))
+        assert isinstance(b, LinOp) and a.row_mode == b.row_mode and a.col_mode == b.col_mode, path
+        for f in ("csr", "row_scale", "col_scale", "T"):
+            _same(getattr(a, f), getattr(b, f), f"{path}.{f}", seen)
+    elif isinstance(a, dict):
+        assert set(a) == set(b), (path, set(a) ^ set(b))
+        for k in a:
+            _same(a[k], b[k], f"{path}[{k}]", seen)
+    else:
+        assert a == b, (path, a, b)
+
+
+@pytest.mark.parametrize("preset,ragged,seed", [("tiny", False, 0), ("small", True, 1), ("small", "jitter", 2),
+                                                ("small", "jitter", 5), ("dataset", False, 3)])
+def test_plan_in_one_host_call_equals_piece_by_piece_build(cuda, preset, ragged, seed, monkeypatch):
+    """bg_plan_build (one host call, ~90 launches, no torch ops) makes the plan build_plan otherwise assembles from
+    bg_plan_* calls and tensor operations: every index vector, table, count, flag and statistic, bit for bit."""
+    from building_gan_amd import plan as P
+    g = _batch(preset, seed, ragged).to(cuda)
+    monkeypatch.setattr(P, "ONE_CALL_BUILD", True)
+    fast = P.build_plan(g)
+    assert "_arenas" in fast.ops, "the one-call path declined this batch"
+    g.__dict__.pop("_bg_plan")
+    monkeypatch.setattr(P, "ONE_CALL_BUILD", False)
+    slow = P.build_plan(g)
+    assert "_arenas" not in slow.ops
+    a = {k: v for k, v in fast.ops.items() if k != "_arenas"}
+    _same(a, dict(slow.ops), "plan", set())
+    for f in ("B", "S", "Np", "Nv", "Ep", "Ev", "Ec"):
+        assert getattr(fast, f) == getattr(slow, f)
+
+
+def test_plan_in_one_host_call_reports_bad_indices(cuda, monkeypatch):
+    """Out-of-range ids in any index vector end in the plan's error, not in a stray access."""
+    from building_gan_amd import _lib, plan as P
+    monkeypatch.setattr(P, "ONE_CALL_BUILD", True)
+    for field, value in (("voxel_feature_batch", 10 ** 6), ("program_class_cluster", -3), ("voxel_floor_cluster", 10 ** 7),
+                         ("cross_edge_program_index_select", 10 ** 8), ("program_target_ratio_batch", 99)):
+        g = _batch("small", 4, True).to(cuda)
+        S = int(g.voxel_floor_cluster.max()) + 1
+        t = getattr(g, field).clone()
+        t[t.numel() // 2] = value
+        setattr(g, field, t)
+        with pytest.raises(_lib.BganError):
+            P.build_plan(g, num_stories=S)
+    torch.cuda.synchronize()
+
+
 def test_plan_unsorted_random_keys(cuda):
     """Random (unsorted, skewed) keys incl. empty rows and one very long row (> LDS sort size)."""
     from building_gan_amd.plan import _Builder
