@@ -138,8 +138,8 @@ def roofline_dominant_gemm(dev, batch, plan, hidden=128):
     ms = event_time_ms(g.replay, 10) / 20
     flops = 2.0 * Nv * (2 * H) * H
     ach = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "generator block Linear, M=%d N=%d K=%d from the position + bias term, "
-                      "fused gather + LeakyReLU + residual epilogue" % (Nv, H, 2 * H),
+    return {"kernel": "k_gemm_panel (16x16x4 f32 MFMA, 48-row x 64-column workgroups): generator block Linear, M=%d N=%d "
+                      "K=%d from the position + bias term, fused gather + LeakyReLU + residual epilogue" % (Nv, H, 2 * H),
             "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_generator_block"),
             "traffic_source": TRAFFIC_FILE,

@@ -3,8 +3,7 @@ over tools/roofline_kernels.py -> JSON read by bench.py.  FETCH_SIZE is doubled 
 requests at 64 bytes, MI355X_MICROARCH.md); both counters are in KiB."""
 import csv, glob, json, sys, collections
 fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
-KEYS = {"gemm_generator_block": "k_gemm<64, 64, 64, true, true, true, false>", "spmm_H128": "k_spmm_vec<32, false>",
-        "spmm_H256": "k_spmm_vec<64, false>"}
+KEYS = {"gemm_generator_block": "k_gemm_panel<", "spmm_H128": "k_spmm_batched<32,", "spmm_H256": "k_spmm_batched<64,"}
 def mean(d, counter):
     acc = collections.defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -17,6 +16,8 @@ def mean(d, counter):
     return {k: sum(v[2:]) / len(v[2:]) for k, v in acc.items() if len(v) > 2}
 fe, wr = mean(fetch_dir, "FETCH_SIZE"), mean(write_dir, "WRITE_SIZE")
 res = {k: round((2 * fe[k] + wr.get(k, 0.0)) * 1024) for k in fe}
-res["_note"] = "bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes over tools/roofline_kernels.py"
+res["_fetch_KiB"], res["_write_KiB"] = fe, wr
+res["_note"] = ("bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes over tools/roofline_kernels.py "
+                "(gather-mean: rotating over 4 operand / result pairs, as bench.py's microbench)")
 json.dump(res, open(out, "w"), indent=1)
 print(res)

@@ -31,4 +31,5 @@ for name, fn in (("plan", lambda k: plan(batches[k % 8])), ("critic", lambda k: 
     for k in range(10): fn(k)
     torch.cuda.synchronize(); pr.disable()
     print("=" * 30, name)
-    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(30)
+    pstats.Stats(pr).sort_stats("cumtime").print_stats(45)
