@@ -276,7 +276,7 @@ def test_generator_backward_and_penalty_against_float64(cuda, preset, graphs):
     """The float64 treatment the discriminator already had (VERDICT weak 3): the generator's parameter gradients
     through the critic and the gradient penalty's double backward, HIP (fp32) and oracle (fp32) each measured
     against the oracle run in float64 on identical inputs and noise.  The HIP path has to be as close to float64
-    as the fp32 oracle is (within 4x), and within GRAD64_BAR of each tensor's max."""
+    as the fp32 oracle is: per tensor, error <= max(GRAD64_BAR, 2 x the fp32 oracle's own error) of the tensor's scale."""
     from building_gan_amd.graph import detach_batch
     from building_gan_amd.losses import VolumetricDesignLoss_G, compute_gradient_penalty as gp_h
     from building_gan_amd.synthetic import batch_sizes, make_batch

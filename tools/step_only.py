@@ -20,12 +20,19 @@ def marker():
     torch.cumsum(torch.ones(64, device="cuda:0"), 0)          # the only cumsum of the process: the trace's bracket
 
 
+kind = os.environ.get("BG_STEP_KIND", "stream")      # "critic": critic-only iterations, plans kept (tuning aid)
+if kind == "critic":
+    step = lambda i: w.trainer.train_iteration(w.batches[i % len(w.batches)], 1)
+elif kind == "gupdate":
+    step = lambda i: w.trainer.train_iteration(w.batches[i % len(w.batches)], 5)
+else:
+    step = w.step
 for i in range(warm):
-    w.step(i)
+    step(i)
 w.sync()
 marker()
 for i in range(warm, warm + steps):
-    w.step(i)
+    step(i)
 w.sync()
 marker()
 torch.cuda.synchronize()
