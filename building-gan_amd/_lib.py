@@ -71,6 +71,10 @@ SIGNATURES = {
     "bg_d_coef_forward_f32": [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _p],
     "bg_d_coef_backward_f32": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "bg_adam_f32": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i32, _p, _p],
+    "bg_regroup_f32": [_p, _p, _i64, _i64, _i64, _i64, _int, _p],
+    "bg_add_f32": [_p, _p, _p, _i64, _p],
+    "bg_critic_head_forward_f32": [_p, _f, _p, _i64, _p, _p],
+    "bg_critic_head_backward_f32": [_p, _f, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "bg_plan_layout": [_p, _p, _p, _p],
     "bg_plan_build": [_p, _p, _p, _p],
 }
@@ -100,6 +104,15 @@ class PlanIn(C.Structure):
     _fields_ = [(n, _i64) for n in ("Np", "Nv", "Ep", "Ev", "Ec", "B", "S", "n_slot")] + \
                [(n, _fp) for n in ("pe_src", "pe_dst", "ve_src", "ve_dst", "cep", "cev", "vfc", "vbi", "pcc", "slot_graph",
                                    "target_ratio")] + [("chunk_rows", _i32 * 4)]
+
+
+class CriticHead(C.Structure):
+    """include/bgan.h: bgCriticHead."""
+    _fields_ = [(n, _i64) for n in ("N", "S", "B", "L", "ds", "dl", "H2", "Hd", "blk_n", "blk_max_rows", "blk_max_nnz",
+                                    "blk_max_deg")] + \
+               [(n, _fp) for n in ("Zs", "Zk", "W", "b_w1", "b_b1", "b_w2", "b_b2", "s_w1", "s_b1", "s_w2", "s_b2", "wb", "ws",
+                                   "st_rowptr", "st_col", "story_of_voxel", "sg_rowptr", "sg_col", "graph_of_story",
+                                   "graph_of_voxel", "a_rowptr", "a_col", "a_count", "at_rowptr", "at_col", "blk_ptr")]
 
 
 # include/bgan.h: the BGP_* / BGS_* enums (order is the ABI; tests/test_cabi.py checks them against the header)
@@ -138,9 +151,11 @@ def load() -> C.CDLL:
     lib.bg_generator_forward_workspace.argtypes = [_i64] * 5
     lib.bg_d_coef_backward_workspace.restype = C.c_int64
     lib.bg_d_coef_backward_workspace.argtypes = [_i64] * 4
+    lib.bg_critic_head_workspace.restype = C.c_int64
+    lib.bg_critic_head_workspace.argtypes = [_p]
     lib.bg_abi_sizeof.restype = C.c_int64
     lib.bg_abi_sizeof.argtypes = [C.c_int]
-    for which, st in enumerate((GeneratorWeights, GeneratorPlan, PlanIn)):
+    for which, st in enumerate((GeneratorWeights, GeneratorPlan, PlanIn, CriticHead)):
         if lib.bg_abi_sizeof(which) != C.sizeof(st):
             raise BganError(f"{LIB_PATH} was built from another revision of include/bgan.h ({st.__name__}: "
                             f"{lib.bg_abi_sizeof(which)} bytes there, {C.sizeof(st)} here): rebuild it "

@@ -244,9 +244,57 @@ __global__ void k_d_coef_init_bwd(const float* __restrict__ G, int64_t slab, int
     }
 }
 
+// [n, K, P, W] <-> [P, n, K, W], one float4 per thread (see bg_regroup_f32)
+__global__ void k_regroup(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n, int K, int P, int W4,
+                          int to_outer) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = n * K * P * W4;
+    if (t >= total) return;
+    // t enumerates the INNER layout [n, K, P, W4]
+    const int j = (int)(t % W4);
+    const int p = (int)((t / W4) % P);
+    const int k = (int)((t / ((int64_t)W4 * P)) % K);
+    const int64_t v = t / ((int64_t)W4 * P * K);
+    const int64_t outer = (((int64_t)p * n + v) * K + k) * W4 + j;
+    if (to_outer) dst[outer] = src[t]; else dst[t] = src[outer];
+}
+
+__global__ void k_add(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out, int64_t n4) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    const float4 x = a[t], y = b[t];
+    out[t] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+
 }  // namespace
 
 extern "C" {
+
+int bg_regroup_f32(const float* src, float* dst, int64_t n, int64_t K, int64_t P, int64_t W, int to_outer, bgStream stream) {
+    if (n < 0 || K <= 0 || P <= 0 || W <= 0) return BG_ERR_ARG;
+    if (n == 0) return BG_OK;
+    if (!src || !dst) return BG_ERR_ARG;
+    if (W % 4 != 0 || K > (1 << 20) || P > (1 << 20)) return BG_ERR_SHAPE;
+    if (!bg_aligned16(src) || !bg_aligned16(dst)) return BG_ERR_ALIGN;
+    const int64_t total = n * K * P * (W / 4);
+    k_regroup<<<bg_grid_for(total, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n, (int)K, (int)P, (int)(W / 4), to_outer);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_add_f32(const float* a, const float* b, float* out, int64_t n, bgStream stream) {
+    if (n < 0) return BG_ERR_ARG;
+    if (n == 0) return BG_OK;
+    if (!a || !b || !out) return BG_ERR_ARG;
+    if (n % 4 != 0) return BG_ERR_SHAPE;
+    if (!bg_aligned16(a) || !bg_aligned16(b) || !bg_aligned16(out)) return BG_ERR_ALIGN;
+    k_add<<<bg_grid_for(n / 4, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out), n / 4);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
 
 int bg_gp_sample_f32(const float* label, int64_t ldl, const float* out, int64_t ldo, const float* u,
                      float* sample, int64_t lds, int64_t n, int64_t C, bgStream stream) {

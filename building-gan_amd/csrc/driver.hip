@@ -73,6 +73,7 @@ extern "C" int64_t bg_abi_sizeof(int which) {
         case 0: return (int64_t)sizeof(bgGeneratorWeights);
         case 1: return (int64_t)sizeof(bgGeneratorPlan);
         case 2: return (int64_t)sizeof(bgPlanIn);
+        case 3: return (int64_t)sizeof(bgCriticHead);
         default: return -1;
     }
 }
@@ -231,4 +232,225 @@ extern "C" int bg_d_coef_backward_f32(const float* g, const float* xall, const f
                                  (int32_t)coef_splits(H2, L * S), 0, s));
     return bg_d_coef_init_bwd_f32(gall, S * H2, L, H, nf, nl, ML, ds, dl, g_fe_w, g_fe_b, g_le_w, g_le_b, gW + 2 * H2,
                                   2 * H2 + 4, g_bc, s);
+}
+
+// ---------------------------------------------------------------- the critic update below the coefficient table
+namespace {
+
+struct CriticBuffers {
+    // forward (kept for the backward)
+    float *Zp[3], *Sb, *v[3], *Xs, *Xb, *hs, *hb, *vals, *valb, *hat_s, *hat_b, *gp_b, *gp_s, *G2, *X, *Ys, *acc, *part;
+    int32_t *as, *ab, *arg_s, *arg_sb, *arg_b;
+    // backward
+    float *dvb, *dvs, *dacc, *dYs, *dX, *dG2, *dgp_b, *dgp_s, *c_b, *c_s, *dhs, *dhb, *dXs, *dXb, *T, *splitk, *colsum;
+};
+
+int32_t tn_splits(int64_t M, int64_t N, int64_t R) {           // ops.gemm_tn_raw's rule (one B segment)
+    const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    const int64_t steps = (R + 31) / 32;
+    int64_t s = (512 + tiles - 1) / tiles;
+    if (s > steps) s = steps;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    return (int32_t)s;
+}
+int32_t colsum_blocks(int64_t M) {                              // ops.colsum_raw's rule
+    int64_t nb = (M + 127) / 128;
+    if (nb > 256) nb = 256;
+    if (nb < 1) nb = 1;
+    return (int32_t)nb;
+}
+
+CriticBuffers carve_critic(Arena& ar, const bgCriticHead& h) {
+    const int64_t N = h.N, S = h.S, B = h.B, K1 = h.L + 1, ds = h.ds, dl = h.dl, H2 = h.H2, Hd = h.Hd;
+    CriticBuffers b;
+    b.Zp[0] = ar.take(3 * N * K1 * dl);            // [3, N, K1 dl]: one piece, bg_regroup_f32 writes all three
+    b.Zp[1] = b.Zp[0] ? b.Zp[0] + N * K1 * dl : nullptr; b.Zp[2] = b.Zp[0] ? b.Zp[0] + 2 * N * K1 * dl : nullptr;
+    b.Sb = ar.take(N * H2);
+    for (int p = 0; p < 3; ++p) b.v[p] = ar.take(N * H2);
+    b.Xs = ar.take(2 * S * H2); b.Xb = ar.take(2 * B * H2);
+    b.as = reinterpret_cast<int32_t*>(ar.take(2 * S * H2)); b.ab = reinterpret_cast<int32_t*>(ar.take(2 * B * H2));
+    b.hs = ar.take(2 * S * Hd); b.hb = ar.take(2 * B * Hd); b.vals = ar.take(2 * S); b.valb = ar.take(2 * B);
+    b.hat_s = ar.take(S * H2); b.hat_b = ar.take(B * H2);
+    b.arg_s = reinterpret_cast<int32_t*>(ar.take(S * H2)); b.arg_sb = reinterpret_cast<int32_t*>(ar.take(B * H2));
+    b.arg_b = reinterpret_cast<int32_t*>(ar.take(B * H2));
+    b.gp_b = ar.take(H2); b.gp_s = ar.take(H2);
+    b.G2 = ar.take(2 * N * H2); b.X = ar.take(2 * N * K1 * dl); b.Ys = ar.take(N * K1 * 2 * dl); b.acc = ar.take(N * 2 * dl);
+    b.part = ar.take(128);
+    b.dvb = ar.take(2 * B); b.dvs = ar.take(2 * S); b.dacc = ar.take(N * 2 * dl);
+    b.dYs = ar.take(N * K1 * 2 * dl); b.dX = ar.take(2 * N * K1 * dl); b.dG2 = ar.take(2 * N * H2);
+    b.dgp_b = ar.take(B * H2); b.dgp_s = ar.take(S * H2); b.c_b = ar.take(H2); b.c_s = ar.take(H2);
+    b.dhs = ar.take(2 * S * Hd); b.dhb = ar.take(2 * B * Hd); b.dXs = ar.take(2 * S * H2); b.dXb = ar.take(2 * B * H2);
+    b.T = ar.take(2 * S * H2);
+    // largest split-K partial of the backward's weight-gradient products
+    int64_t sk = 0;
+    auto need = [&](int64_t M, int64_t Nn, int64_t R) { const int64_t x = (int64_t)tn_splits(M, Nn, R) * M * Nn; if (x > sk) sk = x; };
+    need(K1 * dl, H2, 2 * N); need(K1 * dl, H2, N); need(K1 * ds, H2, N);
+    need(1, Hd, 2 * S); need(Hd, H2, 2 * S); need(1, Hd, 2 * B); need(Hd, H2, 2 * B);
+    b.splitk = ar.take(sk);
+    b.colsum = ar.take(256 * (H2 > Hd ? H2 : Hd));
+    return b;
+}
+
+int critic_shape_ok(const bgCriticHead& h) {
+    if (h.N <= 0 || h.S <= 0 || h.B <= 0 || h.L < 1 || h.ds <= 0 || h.dl <= 0 || h.H2 <= 0 || h.Hd <= 0) return BG_ERR_ARG;
+    if (h.ds % 4 || h.dl % 4 || h.H2 % 4 || h.Hd % 4 || h.H2 > 1024 || h.L > 64) return BG_ERR_SHAPE;
+    if (h.blk_n <= 0 || h.blk_max_deg > 8 || h.blk_max_rows <= 0) return BG_ERR_SHAPE;
+    return BG_OK;
+}
+
+// y = x W^T + b for a decoder layer (nn.Linear layout)
+int dec_linear(int64_t M, int64_t Nout, int64_t K, const float* x, const float* W, const float* bias, float* y, bgStream s) {
+    const float* A[4] = {x, nullptr, nullptr, nullptr};
+    int64_t ld[4] = {K, 0, 0, 0}, Ks[4] = {K, 0, 0, 0};
+    return bg_gemm_f32(0, 1, M, Nout, 1, A, ld, Ks, W, K, y, Nout, bias, nullptr, BG_ACT_NONE, 0.f, nullptr, 0, nullptr, 0,
+                       nullptr, nullptr, 0, nullptr, 0, s);
+}
+// C [M, N] = A [M, K] (pitch lda) * B, B given as [K, N] (tb = 0) or [N, K] (tb = 1), pitch ldb; optional start matrix
+int mm(int64_t M, int64_t Nn, int64_t K, const float* A_, int64_t lda, const float* B_, int64_t ldb, int tb, float* C_,
+       const float* pre_add, const float* acc_init, bgStream s) {
+    const float* A[4] = {A_, nullptr, nullptr, nullptr};
+    int64_t ld[4] = {lda, 0, 0, 0}, Ks[4] = {K, 0, 0, 0};
+    return bg_gemm_f32(0, tb, M, Nn, 1, A, ld, Ks, B_, ldb, C_, Nn, nullptr, nullptr, BG_ACT_NONE, 0.f, nullptr, 0,
+                       pre_add, pre_add ? Nn : 0, nullptr, acc_init, acc_init ? Nn : 0, nullptr, 0, s);
+}
+// C [M, N] (+)= A^T B for A [R, M], B [R, N], both contiguous
+int tn(int64_t M, int64_t Nn, int64_t R, const float* A_, const float* B_, float* C_, float* partial, int accumulate, bgStream s) {
+    const float* Bs[4] = {B_, nullptr, nullptr, nullptr};
+    int64_t ldb[4] = {Nn, 0, 0, 0}, Ns[4] = {Nn, 0, 0, 0};
+    return bg_gemm_tn_splitk_f32(M, R, A_, M, 1, Bs, ldb, Ns, C_, Nn, partial, tn_splits(M, Nn, R), accumulate, s);
+}
+
+}  // namespace
+
+extern "C" int64_t bg_critic_head_workspace(const bgCriticHead* h) {
+    if (!h || critic_shape_ok(*h) != BG_OK) return -1;
+    Arena ar{nullptr, 0, 0};
+    carve_critic(ar, *h);
+    return ar.used + 64;
+}
+
+extern "C" int bg_critic_head_forward_f32(const bgCriticHead* hp, float coef, float* workspace, int64_t workspace_floats,
+                                          float* loss, bgStream s) {
+    if (!hp || !workspace || !loss) return BG_ERR_ARG;
+    const bgCriticHead& h = *hp;
+    int rc = critic_shape_ok(h);
+    if (rc != BG_OK) return rc;
+    if (!h.Zs || !h.Zk || !h.W || !h.b_w1 || !h.b_b1 || !h.b_w2 || !h.b_b2 || !h.s_w1 || !h.s_b1 || !h.s_w2 || !h.s_b2 ||
+        !h.wb || !h.ws || !h.st_rowptr || !h.st_col || !h.story_of_voxel || !h.sg_rowptr || !h.sg_col || !h.graph_of_story ||
+        !h.graph_of_voxel || !h.a_rowptr || !h.a_col || !h.a_count || !h.at_rowptr || !h.at_col || !h.blk_ptr) return BG_ERR_ARG;
+    if (!bg_aligned16(workspace)) return BG_ERR_ALIGN;
+    Arena ar{workspace, 0, workspace_floats};
+    CriticBuffers b = carve_critic(ar, h);
+    if (ar.used > workspace_floats) return BG_ERR_ARG;
+    const int64_t N = h.N, S = h.S, B = h.B, K1 = h.L + 1, ds = h.ds, dl = h.dl, H2 = h.H2, Hd = h.Hd;
+    const float* Ws = h.W;
+    const float* Wl = h.W + K1 * ds * H2;
+
+    // label powers [N, K1, 3, dl] -> one contiguous [N, K1 dl] matrix per label set
+    BG_TRY(bg_regroup_f32(h.Zk, b.Zp[0], N, K1, 3, dl, 1, s));
+    // label-free part once, then one thin product per label set on top of it (models.py collapsed_multi)
+    BG_TRY(mm(N, H2, K1 * ds, h.Zs, K1 * ds, Ws, H2, 0, b.Sb, nullptr, nullptr, s));
+    for (int p = 0; p < 3; ++p)
+        BG_TRY(mm(N, H2, K1 * dl, b.Zp[p], K1 * dl, Wl, H2, 0, b.v[p], b.Sb, nullptr, s));
+    // D(real), D(fake): max over each story, then over the stories of each graph; both sets share one run of a decoder
+    for (int p = 0; p < 2; ++p) {
+        BG_TRY(bg_segmax_f32(b.v[p], H2, h.st_rowptr, h.st_col, nullptr, 0, 0, nullptr, nullptr, b.Xs + p * S * H2, H2,
+                             b.as + p * S * H2, S, H2, s));
+        BG_TRY(bg_segmax_f32(b.Xs + p * S * H2, H2, h.sg_rowptr, h.sg_col, nullptr, 0, 0, nullptr, nullptr,
+                             b.Xb + p * B * H2, H2, b.ab + p * B * H2, B, H2, s));
+    }
+    BG_TRY(dec_linear(2 * S, Hd, H2, b.Xs, h.s_w1, h.s_b1, b.hs, s));
+    BG_TRY(dec_linear(2 * S, 1, Hd, b.hs, h.s_w2, h.s_b2, b.vals, s));
+    BG_TRY(dec_linear(2 * B, Hd, H2, b.Xb, h.b_w1, h.b_b1, b.hb, s));
+    BG_TRY(dec_linear(2 * B, 1, Hd, b.hb, h.b_w2, h.b_b2, b.valb, s));
+    // the sample point: which voxel carries each pooled column (losses.py:83-84 in closed form)
+    BG_TRY(bg_segmax_f32(b.v[2], H2, h.st_rowptr, h.st_col, nullptr, 0, 0, nullptr, nullptr, b.hat_s, H2, b.arg_s, S, H2, s));
+    BG_TRY(bg_segmax_f32(b.hat_s, H2, h.sg_rowptr, h.sg_col, nullptr, 0, 0, nullptr, nullptr, b.hat_b, H2, b.arg_sb, B, H2, s));
+    BG_TRY(bg_gather_arg_f32(reinterpret_cast<const float*>(b.arg_s), H2, b.arg_sb, reinterpret_cast<float*>(b.arg_b), H2, B, H2, s));
+    // d D / d pooled of a decoder without activation is the constant row W2 W1
+    BG_TRY(mm(1, H2, Hd, h.b_w2, Hd, h.b_w1, H2, 0, b.gp_b, nullptr, nullptr, s));
+    BG_TRY(mm(1, H2, Hd, h.s_w2, Hd, h.s_w1, H2, 0, b.gp_s, nullptr, nullptr, s));
+    // scattered to the arg-max voxels (row pitch 0: every segment reads the same row): building rows, then story rows
+    BG_TRY(bg_scatter_arg_f32(b.gp_b, 0, b.arg_b, h.graph_of_voxel, b.G2, H2, B, N, H2, s));
+    BG_TRY(bg_scatter_arg_f32(b.gp_s, 0, b.arg_s, h.story_of_voxel, b.G2 + N * H2, H2, S, N, H2, s));
+    // sum_k (A^T)^k G Wl_k^T: all powers' columns by one product, both outputs side by side through one chain
+    BG_TRY(mm(2 * N, K1 * dl, H2, b.G2, H2, Wl, H2, 1, b.X, nullptr, nullptr, s));
+    BG_TRY(bg_regroup_f32(b.X, b.Ys, N, K1, 2, dl, 0, s));
+    const int64_t W2c = 2 * dl, ldy = K1 * W2c;
+    BG_TRY(bg_spmm_chain_f32(b.Ys + h.L * W2c, ldy, h.at_rowptr, h.at_col, nullptr, BG_SCALE_NONE, h.a_count, BG_SCALE_DIV,
+                             h.blk_ptr, h.blk_n, h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg,
+                             b.Ys + (h.L - 1) * W2c, ldy, -W2c, b.acc, W2c, 0, h.L, W2c, s));
+    BG_TRY(bg_critic_loss_f32(b.valb, h.wb, 2 * B, b.vals, h.ws, 2 * S, b.acc, dl, 2 * N, dl, coef, b.part, loss, s));
+    return BG_OK;
+}
+
+extern "C" int bg_critic_head_backward_f32(const bgCriticHead* hp, float coef, const float* go, float* workspace,
+                                           int64_t workspace_floats, float* gW, float* g_b_w1, float* g_b_b1,
+                                           float* g_b_w2, float* g_b_b2, float* g_s_w1, float* g_s_b1, float* g_s_w2,
+                                           float* g_s_b2, bgStream s) {
+    if (!hp || !workspace || !go || !gW || !g_b_w1 || !g_b_b1 || !g_b_w2 || !g_b_b2 || !g_s_w1 || !g_s_b1 || !g_s_w2 ||
+        !g_s_b2) return BG_ERR_ARG;
+    const bgCriticHead& h = *hp;
+    int rc = critic_shape_ok(h);
+    if (rc != BG_OK) return rc;
+    if (!bg_aligned16(workspace)) return BG_ERR_ALIGN;
+    Arena ar{workspace, 0, workspace_floats};
+    CriticBuffers b = carve_critic(ar, h);
+    if (ar.used > workspace_floats) return BG_ERR_ARG;
+    const int64_t N = h.N, S = h.S, B = h.B, K1 = h.L + 1, ds = h.ds, dl = h.dl, H2 = h.H2, Hd = h.Hd;
+    const float* Wl = h.W + K1 * ds * H2;
+    float* gWs = gW;
+    float* gWl = gW + K1 * ds * H2;
+    const int64_t W2c = 2 * dl, ldy = K1 * W2c;
+
+    BG_TRY(bg_critic_loss_bwd_f32(go, h.wb, 2 * B, h.ws, 2 * S, b.acc, dl, 2 * N, dl, coef, b.dvb, b.dvs, b.dacc, s));
+    // ---- penalty: transpose of the Horner chain = the powers of A applied to d acc
+    BG_HIP(hipMemcpy2DAsync(b.dYs, sizeof(float) * ldy, b.dacc, sizeof(float) * W2c, sizeof(float) * W2c, N,
+                            hipMemcpyDeviceToDevice, (hipStream_t)s));
+    BG_TRY(bg_spmm_chain_f32(b.dYs, ldy, h.a_rowptr, h.a_col, h.a_count, BG_SCALE_DIV, nullptr, BG_SCALE_NONE,
+                             h.blk_ptr, h.blk_n, h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg,
+                             nullptr, 0, 0, b.dYs + W2c, ldy, W2c, h.L, W2c, s));
+    BG_TRY(bg_regroup_f32(b.dYs, b.dX, N, K1, 2, dl, 1, s));
+    BG_TRY(mm(2 * N, H2, K1 * dl, b.dX, K1 * dl, Wl, H2, 0, b.dG2, nullptr, nullptr, s));                   // d G2 = dX Wl
+    BG_TRY(tn(K1 * dl, H2, 2 * N, b.dX, b.G2, gWl, b.splitk, 0, s));                                        // gWl  = dX^T G2
+    BG_TRY(bg_gather_arg_f32(b.dG2, H2, b.arg_b, b.dgp_b, H2, B, H2, s));
+    BG_TRY(bg_gather_arg_f32(b.dG2 + N * H2, H2, b.arg_s, b.dgp_s, H2, S, H2, s));
+    // every row of d D / d pooled is the same W2 W1: its gradient is the column sum c; g W1 = W2^T c, g W2 = c W1^T
+    BG_TRY(bg_colsum_f32(b.dgp_b, H2, B, H2, b.colsum, colsum_blocks(B), b.c_b, 0, s));
+    BG_TRY(bg_colsum_f32(b.dgp_s, H2, S, H2, b.colsum, colsum_blocks(S), b.c_s, 0, s));
+    {
+        const float* A[4] = {h.b_w2, nullptr, nullptr, nullptr};
+        int64_t ld[4] = {Hd, 0, 0, 0}, Ks[4] = {1, 0, 0, 0};
+        BG_TRY(bg_gemm_f32(1, 0, Hd, H2, 1, A, ld, Ks, b.c_b, H2, g_b_w1, H2, nullptr, nullptr, BG_ACT_NONE, 0.f, nullptr, 0,
+                           nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
+        A[0] = h.s_w2;
+        BG_TRY(bg_gemm_f32(1, 0, Hd, H2, 1, A, ld, Ks, b.c_s, H2, g_s_w1, H2, nullptr, nullptr, BG_ACT_NONE, 0.f, nullptr, 0,
+                           nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
+    }
+    BG_TRY(mm(1, Hd, H2, b.c_b, H2, h.b_w1, H2, 1, g_b_w2, nullptr, nullptr, s));
+    BG_TRY(mm(1, Hd, H2, b.c_s, H2, h.s_w1, H2, 1, g_s_w2, nullptr, nullptr, s));
+    // ---- D(real), D(fake): building decoder, back through the story level, story decoder
+    BG_TRY(tn(1, Hd, 2 * B, b.dvb, b.hb, g_b_w2, b.splitk, 1, s));
+    BG_TRY(bg_colsum_f32(b.dvb, 1, 2 * B, 1, b.colsum, colsum_blocks(2 * B), g_b_b2, 0, s));
+    BG_TRY(mm(2 * B, Hd, 1, b.dvb, 1, h.b_w2, Hd, 0, b.dhb, nullptr, nullptr, s));
+    BG_TRY(tn(Hd, H2, 2 * B, b.dhb, b.Xb, g_b_w1, b.splitk, 1, s));
+    BG_TRY(bg_colsum_f32(b.dhb, Hd, 2 * B, Hd, b.colsum, colsum_blocks(2 * B), g_b_b1, 0, s));
+    BG_TRY(mm(2 * B, H2, Hd, b.dhb, Hd, h.b_w1, H2, 0, b.dXb, nullptr, nullptr, s));
+    for (int p = 0; p < 2; ++p)
+        BG_TRY(bg_scatter_arg_f32(b.dXb + p * B * H2, H2, b.ab + p * B * H2, h.graph_of_story, b.T + p * S * H2, H2, B, S, H2, s));
+    BG_TRY(tn(1, Hd, 2 * S, b.dvs, b.hs, g_s_w2, b.splitk, 1, s));
+    BG_TRY(bg_colsum_f32(b.dvs, 1, 2 * S, 1, b.colsum, colsum_blocks(2 * S), g_s_b2, 0, s));
+    BG_TRY(mm(2 * S, Hd, 1, b.dvs, 1, h.s_w2, Hd, 0, b.dhs, nullptr, nullptr, s));
+    BG_TRY(tn(Hd, H2, 2 * S, b.dhs, b.Xs, g_s_w1, b.splitk, 1, s));
+    BG_TRY(bg_colsum_f32(b.dhs, Hd, 2 * S, Hd, b.colsum, colsum_blocks(2 * S), g_s_b1, 0, s));
+    BG_TRY(mm(2 * S, H2, Hd, b.dhs, Hd, h.s_w1, H2, 0, b.dXs, nullptr, b.T, s));          // + what arrived through the buildings
+    // to the arg-max voxels (v[0], v[1] are free after the forward's pooling: they take d v), then the coefficient table
+    for (int p = 0; p < 2; ++p) {
+        BG_TRY(bg_scatter_arg_f32(b.dXs + p * S * H2, H2, b.as + p * S * H2, h.story_of_voxel, b.v[p], H2, S, N, H2, s));
+        BG_TRY(tn(K1 * dl, H2, N, b.Zp[p], b.v[p], gWl, b.splitk, 1, s));
+    }
+    BG_TRY(bg_add_f32(b.v[0], b.v[1], b.v[2], N * H2, s));
+    BG_TRY(tn(K1 * ds, H2, N, h.Zs, b.v[2], gWs, b.splitk, 0, s));
+    return BG_OK;
 }

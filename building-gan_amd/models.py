@@ -39,6 +39,7 @@ FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is
 FUSE_POS_TERM = True      # generator: position columns x weight + bias once per forward, the 12 products start from it
 FUSE_COEF_INPUTS = True   # collapsed discriminator: the recurrence's parameter rows by one launch (ops.PolyCoefD)
 FUSE_GENERATOR_FORWARD = True   # graph-free Generator.forward as ONE host call (bg_generator_forward_f32)
+FUSE_CRITIC_HEAD = True   # WGAN-GP critic update below the coefficient table as ONE host call each way (ops.CriticHead)
 COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
 
 
@@ -544,11 +545,9 @@ class VoxelGNN_D(nn.Module):
         zl = ops.PowerChain.apply(F.pad(l, (0, dl - l.shape[1])), plan.vox_mean, L, plan.vox_blocks)
         return linear([Zs, zl.view(zl.shape[0], -1)], W, w_t=True)
 
-    def collapsed_multi(self, feat, labels, plan, pdm4):
-        """v_L of several label sets that share the graph (the passes of one critic update), labels
-        taken as data (no gradient reaches them through this call).  The label-free part S = Zs Ws is
-        evaluated once; each pass adds its own thin product.  Returns ([v_L per pass], Wl, dl) where
-        Wl [(L+1)*dl, 2H] maps label powers to the output (rows ordered (k, label column))."""
+    def _label_powers(self, feat, labels, plan, pdm4):
+        """(Zs [N, (L+1) ds], Zk [N, L+1, P dl], W, ds, dl): operator powers of the label-free columns and of the P
+        label sets (data), and the coefficient table."""
         L, P, N = self.layer_num, len(labels), feat.shape[0]
         n_lab = labels[0].shape[1]
         dl = (n_lab + 3) // 4 * 4
@@ -558,9 +557,18 @@ class VoxelGNN_D(nn.Module):
         Zs = self._static_powers(plan, feat, pdm4, rider)
         ds = Zs.shape[1] // (L + 1)
         W = self.coefficients(feat.shape[1], ds, dl)
-        Ws, Wl = W.split([(L + 1) * ds, (L + 1) * dl], dim=0)
         if not rider[2]:
             ops.power_chain_raw(plan.vox_mean, Zk, L, P * dl, plan.vox_blocks)
+        return Zs, Zk, W, ds, dl
+
+    def collapsed_multi(self, feat, labels, plan, pdm4):
+        """v_L of several label sets that share the graph (the passes of one critic update), labels
+        taken as data (no gradient reaches them through this call).  The label-free part S = Zs Ws is
+        evaluated once; each pass adds its own thin product.  Returns ([v_L per pass], Wl, dl) where
+        Wl [(L+1)*dl, 2H] maps label powers to the output (rows ordered (k, label column))."""
+        L, P, N = self.layer_num, len(labels), feat.shape[0]
+        Zs, Zk, W, ds, dl = self._label_powers(feat, labels, plan, pdm4)
+        Ws, Wl = W.split([(L + 1) * ds, (L + 1) * dl], dim=0)
         Zp = Zk.view(N, L + 1, P, dl).permute(0, 2, 1, 3).contiguous().view(N, P, (L + 1) * dl)
         S = linear([Zs], Ws, w_t=True)
         return [linear([Zp[:, p]], Wl, pre_add=S, w_t=True) for p in range(P)], Wl, dl
@@ -794,6 +802,31 @@ class DiscriminatorVoxel(nn.Module):
             return val_b_all, val_s_all, acc.view(N, 2, dl)      # the pad columns are exactly zero
         grad_b, _, grad_s, _ = acc.split([n_lab, dl - n_lab, n_lab, dl - n_lab], dim=1)
         return (*out, grad_b, grad_s)
+
+    def critic_objective(self, graph, label_real, label_fake, label_hat, wb, ws, coef: float):
+        """(objective, bare penalty sum) of one WGAN-GP critic update -- <D(real), D(fake), wb / ws> + coef * sum over
+        voxels and both outputs of (||d D(hat) / d label|| - 1)^2 -- with everything below the coefficient table issued
+        by ONE host call each way (ops.CriticHead) instead of critic_terms' ~90 launches from the interpreter.  Same
+        kernels, same formulas (tested against critic_terms + CriticLoss).  Returns None where it does not apply
+        (activation in a decoder, empty stories, blocks too large for the chain kernel, ...): the caller then takes
+        critic_terms."""
+        plan = build_plan(graph)
+        gnn = self.voxelGNN_D
+        if not (FUSE_CRITIC_HEAD and COLLAPSE_D and gnn.collapse_ok and COMPOSE_BLOCKS and plan.vox_all_has
+                and gnn.layer_num > 0 and self.piecewise_linear and label_hat is not None):
+            return None
+        blocks, st, sg = plan.vox_blocks, plan.story_seg, plan.story_graph_seg
+        if (blocks is None or not plan.stories_all_nonempty or not st.row_per_workgroup or not sg.row_per_workgroup
+                or len(self.building_dec) != 2 or len(self.story_dec) != 2 or blocks.max_deg > 8):
+            return None
+        pos, feat = extract_pos(graph.voxel_feature)
+        pdm4 = _pos_terms(plan, pos)
+        Zs, Zk, W, ds, dl = gnn._label_powers(feat, [label_real, label_fake, label_hat], plan, pdm4)
+        if not ops._chain_fits(plan.vox_mean.T, blocks, 2 * dl) or W.shape[1] % 4 != 0:
+            return None
+        bd, sd = self.building_dec, self.story_dec
+        return ops.CriticHead.apply(W.contiguous(), bd[0].weight, bd[0].bias, bd[1].weight, bd[1].bias, sd[0].weight,
+                                    sd[0].bias, sd[1].weight, sd[1].bias, Zs, Zk, plan, wb, ws, coef, gnn.layer_num, ds, dl)
 
     # fp32 error of the collapsed form relative to a column's largest activation ~ 2^-24 * amplification (measured:
     # tests/test_gpu_models.py::test_collapsed_discriminator_guard); beyond this bound the polynomial form would lose

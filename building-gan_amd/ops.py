@@ -1309,6 +1309,63 @@ class CriticLoss(torch.autograd.Function):
         return db, ds, dg, None, None, None
 
 
+class CriticHead(torch.autograd.Function):
+    """One WGAN-GP critic update below the collapsed GNN's coefficient table as ONE host call each way
+    (bg_critic_head_forward_f32 / _backward_f32: what DiscriminatorVoxel.critic_terms + CriticLoss launch op by op --
+    thin products, pooling, decoders, closed-form penalty gradients, objective -- and their hand-derived backward).
+    Inputs that get gradients: the coefficient table W and the two decoders' parameters; labels and operator powers
+    are data.  Returns (loss, bare penalty sum) like CriticLoss; first-order autograd."""
+
+    @staticmethod
+    def forward(ctx, W, bw1, bb1, bw2, bb2, sw1, sb1, sw2, sb2, Zs, Zk, plan, wb, ws, coef: float, L: int, ds: int, dl: int):
+        lib = _lib.load()
+        _lib.require_device(W, "critic_head")
+        ts = (W, bw1, bb1, bw2, bb2, sw1, sb1, sw2, sb2, Zs, Zk, wb, ws)
+        if any(t.dtype != torch.float32 or not t.is_contiguous() for t in ts):
+            raise _lib.BganError("critic_head: contiguous fp32 operands")
+        N, H2, Hd = Zs.shape[0], W.shape[1], bw1.shape[0]
+        K1 = L + 1
+        if (tuple(W.shape) != (K1 * (ds + dl), H2) or tuple(Zs.shape) != (N, K1 * ds) or Zk.numel() != N * K1 * 3 * dl
+                or tuple(bw1.shape) != (Hd, H2) or tuple(sw1.shape) != (Hd, H2) or bw2.numel() != Hd or sw2.numel() != Hd
+                or bb1.numel() != Hd or sb1.numel() != Hd or bb2.numel() != 1 or sb2.numel() != 1
+                or wb.numel() != 2 * plan.B or ws.numel() != 2 * plan.S or N != plan.Nv):
+            raise _lib.BganError("critic_head: operand shapes do not fit the plan / the coefficient table")
+        blocks, st, sg = plan.vox_blocks, plan.story_seg, plan.story_graph_seg
+        A, AT = plan.vox_mean, plan.vox_mean.T
+        if blocks is None or st.seg_of is None or sg.seg_of is None or plan.graph_seg.seg_of is None:
+            raise _lib.BganError("critic_head: the plan lacks diagonal blocks / segment tables")
+        h = _lib.CriticHead(N, plan.S, plan.B, L, ds, dl, H2, Hd, blocks.n, blocks.max_rows, blocks.max_nnz, blocks.max_deg,
+                            ptr(Zs), ptr(Zk), ptr(W), ptr(bw1), ptr(bb1), ptr(bw2), ptr(bb2), ptr(sw1), ptr(sb1), ptr(sw2),
+                            ptr(sb2), ptr(wb), ptr(ws), ptr(st.rowptr), ptr(st.col), ptr(st.seg_of), ptr(sg.rowptr),
+                            ptr(sg.col), ptr(sg.seg_of), ptr(plan.graph_seg.seg_of), ptr(A.csr.rowptr), ptr(A.csr.col),
+                            ptr(A.row_scale), ptr(AT.csr.rowptr), ptr(AT.csr.col), ptr(blocks.ptr))
+        n_ws = lib.bg_critic_head_workspace(C.byref(h))
+        if n_ws < 0:
+            raise _lib.BganError("critic_head: sizes not supported")
+        work = torch.empty(n_ws, dtype=torch.float32, device=W.device)
+        loss = torch.empty(2, dtype=torch.float32, device=W.device)
+        check(lib.bg_critic_head_forward_f32(C.byref(h), float(coef), ptr(work), n_ws, ptr(loss), stream()),
+              "bg_critic_head_forward_f32")
+        ctx.h, ctx.work, ctx.n_ws, ctx.coef = h, work, n_ws, float(coef)
+        ctx.keep = (Zs, Zk, wb, ws, plan)                       # the struct holds raw addresses
+        ctx.save_for_backward(W, bw1, bb1, bw2, bb2, sw1, sb1, sw2, sb2)
+        total, pen = loss[0], loss[1]
+        ctx.mark_non_differentiable(pen)
+        return total, pen
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go, _gpen):
+        lib = _lib.load()
+        W, bw1, bb1, bw2, bb2, sw1, sb1, sw2, sb2 = ctx.saved_tensors
+        go = _f32c(go.reshape(1))
+        outs = [torch.empty_like(t) for t in (W, bw1, bb1, bw2, bb2, sw1, sb1, sw2, sb2)]
+        check(lib.bg_critic_head_backward_f32(C.byref(ctx.h), ctx.coef, ptr(go), ptr(ctx.work), ctx.n_ws,
+                                              *[ptr(t) for t in outs], stream()), "bg_critic_head_backward_f32")
+        ctx.work = None
+        return (*outs, None, None, None, None, None, None, None, None, None)
+
+
 def adam_step(param, grad, m, v, lr, beta1, beta2, eps, step, step_dev=None):
     """``step`` (host int) or ``step_dev`` (int32 device tensor holding the step count)."""
     lib = _lib.load()

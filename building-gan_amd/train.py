@@ -296,13 +296,22 @@ class Trainer:
             if do_d:
                 gp = None
                 fused = None
+                head = None
                 if fused_ok:
                     sample = None
                     if self.gp_lambda != 0:      # labels are data in the fused pass: the sample point in one launch
                         sample = ops.gp_sample_raw(batch.voxel_label, soft_out.detach(),
                                                    u if u is not None else torch.rand(out.shape[0], device=dev))
-                    fused = D.critic_terms(batch, batch.voxel_label, out.detach(), sample, stacked=True)
-                if fused is not None:
+                    plan_now = batch.__dict__.get("_bg_plan") if hasattr(batch, "__dict__") else None      # built by G's forward
+                    if sample is not None and self.gan_loss == "WGANGP" and hasattr(D, "critic_objective") and plan_now is not None:
+                        # the whole update below the coefficient table as one host call each way
+                        wb, ws = self._critic_weights(plan_now.B, plan_now.S, Bg, Sg, dev)
+                        head = D.critic_objective(batch, batch.voxel_label, out.detach(), sample, wb, ws, self.gp_lambda / Nvg)
+                    if head is None:
+                        fused = D.critic_terms(batch, batch.voxel_label, out.detach(), sample, stacked=True)
+                if head is not None:
+                    pass
+                elif fused is not None:
                     val_b_all, val_s_all, grads = fused
                     if grads is not None and self.gan_loss != "WGANGP":   # both penalties at once: grads[:, 0] and grads[:, 1]
                         gp = ((grads.norm(2, 2) - 1) ** 2).sum() / Nvg
@@ -313,7 +322,10 @@ class Trainer:
                                                     soft_out.detach(), u, Nvg)
                     real_b, real_s = D(batch, batch.voxel_label)
         if do_d:
-            if fused is not None and self.gan_loss == "WGANGP":
+            if head is not None:
+                d_loss, pen = head
+                stats["gp"] = pen / Nvg
+            elif fused is not None and self.gan_loss == "WGANGP":
                 # -E[real] + E[fake] over graphs and over stories as two dot products with +-1/count weights
                 # and the penalty lambda/Nv * sum (||grad|| - 1)^2 over both outputs' gradients: ONE node
                 wb, ws = self._critic_weights(val_b_all.shape[0] // 2, val_s_all.shape[0] // 2, Bg, Sg, dev)

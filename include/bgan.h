@@ -531,6 +531,58 @@ int bg_d_coef_backward_f32(const float* g, const float* xall, const float* Wc, i
                            float* partial, float* gW, float* g_bc, float* g_fe_w, float* g_fe_b, float* g_le_w,
                            float* g_le_b, bgStream stream);
 
+/* src [n, K, P, W] -> dst [P, n, K, W] (to_outer != 0) or src [P, n, K, W] -> dst [n, K, P, W] (to_outer == 0):
+ * column groups that several label sets / both critic outputs share in one operator chain, regrouped into one
+ * contiguous matrix per set for the products on either side.  W % 4 == 0, 16-byte aligned, contiguous.
+ * replaces: view + permute + contiguous around the collapsed discriminator's chains (no reference counterpart: the
+ * reference runs one pass per label set, train.py:88-96).                                                  */
+int bg_regroup_f32(const float* src, float* dst, int64_t n, int64_t K, int64_t P, int64_t W, int to_outer, bgStream stream);
+
+/* out = a + b over n floats (n % 4 == 0, 16-byte aligned): the one elementwise sum the critic's backward needs
+ * (the gradients of D(real) and D(fake) with respect to the shared label-free part).
+ * replaces: autograd's gradient accumulation for a tensor used twice.                                      */
+int bg_add_f32(const float* a, const float* b, float* out, int64_t n, bgStream stream);
+
+/* Everything one WGAN-GP critic update evaluates AFTER the collapsed GNN's coefficient table W and the operator powers
+ * exist -- D(real), D(fake), the closed-form penalty gradients at the sample point, the objective -- and its
+ * backward, as ONE host call each (models.DiscriminatorVoxel.critic_terms + ops.CriticLoss issued from C++).
+ * Sizes: N voxels, S stories, B graphs, L layers, ds / dl static / label columns per power (multiples of 4),
+ * H2 = 2 H the GNN width, Hd the decoders' hidden width.  Decoders are two Linears without activation.          */
+typedef struct {
+    int64_t N, S, B, L, ds, dl, H2, Hd;
+    int64_t blk_n, blk_max_rows, blk_max_nnz, blk_max_deg;      /* diagonal blocks of the voxel operator (bg_spmm_chain_f32) */
+    const float *Zs;                                            /* [N, (L+1) ds] label-free operator powers                  */
+    const float *Zk;                                            /* [N, L+1, 3, dl] label powers of (real, fake, sample)      */
+    const float *W;                                             /* [(L+1) ds + (L+1) dl, H2] coefficient table (rows: static | label) */
+    const float *b_w1, *b_b1, *b_w2, *b_b2;                     /* building_dec: [Hd, H2], [Hd], [1, Hd], [1]                */
+    const float *s_w1, *s_b1, *s_w2, *s_b2;                     /* story_dec                                                 */
+    const float *wb, *ws;                                       /* [2 B], [2 S]: -+1/count weights, real rows first          */
+    const int32_t *st_rowptr, *st_col, *story_of_voxel;         /* voxels by story (every story non-empty, <= 4096 voxels)   */
+    const int32_t *sg_rowptr, *sg_col, *graph_of_story;         /* stories by graph (<= 256 stories per graph)               */
+    const int32_t *graph_of_voxel;                              /* [N]                                                       */
+    const int32_t *a_rowptr, *a_col; const float *a_count;      /* voxel edges by target + max(in-degree, 1): the operator A */
+    const int32_t *at_rowptr, *at_col;                          /* voxel edges by source: A^T = P^T diag(1 / count)          */
+    const int32_t *blk_ptr;                                     /* [blk_n + 1]                                               */
+} bgCriticHead;
+
+/* Floats of workspace (shared by the forward and the backward call of one update; the forward leaves what the
+ * backward reads in it) for these sizes; -1 for sizes the calls do not take.                                   */
+int64_t bg_critic_head_workspace(const bgCriticHead* h);
+
+/* loss[0] = <D(real), D(fake) values, wb / ws> + coef * sum over voxels and both outputs of (||grad|| - 1)^2,
+ * loss[1] = the bare penalty sum.  ~35 launches; BG_ERR_SHAPE for plans outside the limits above (the caller
+ * then runs the op-by-op path).
+ * replaces: Model/losses.py:14-19,73-89 with train.py:88-98 (three discriminator passes + two autograd.grad calls). */
+int bg_critic_head_forward_f32(const bgCriticHead* h, float coef, float* workspace, int64_t workspace_floats,
+                               float* loss, bgStream stream);
+
+/* Gradients of go[0] * loss[0] with respect to W and the decoders' parameters (each written, not accumulated):
+ * gW [(L+1)(ds + dl), H2], g_b_w1 [Hd, H2], g_b_b1 [Hd], g_b_w2 [Hd], g_b_b2 [1], the same for story_dec.  ~50 launches.
+ * replaces: d_loss.backward() of train.py:98 below the coefficient table.                                       */
+int bg_critic_head_backward_f32(const bgCriticHead* h, float coef, const float* go, float* workspace,
+                                int64_t workspace_floats, float* gW, float* g_b_w1, float* g_b_b1, float* g_b_w2,
+                                float* g_b_b2, float* g_s_w1, float* g_s_b1, float* g_s_w2, float* g_s_b2, bgStream stream);
+
 /* ------------------------------------------------------------------ optimiser ----------- */
 
 /* One Adam step on a flat fp32 buffer (torch.optim.Adam semantics, no weight decay/amsgrad):

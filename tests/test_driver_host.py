@@ -304,3 +304,193 @@ def test_generator_python_binding_hands_the_right_buffers_to_the_driver(drv, mon
     inside(co[9], 4 * Nv * 6, soft_out, "soft_out")
     inside(co[10], 8 * Nv, idx, "idx")
     assert co[3] == cv.rowptr.data_ptr() and co[4] == cv.col.data_ptr() and co[11] == Nv
+
+
+# ------------------------------------------------------------------------------------ critic head (bg_critic_head_*)
+def _critic_run(lib, N, S, B, L=12, ds=32, dl=8, H2=256, Hd=128, max_rows=None):
+    import sys
+    sys.path.insert(0, ROOT)
+    from building_gan_amd._lib import CriticHead
+    R = Ranges()
+    f, K1, Ev = 4, L + 1, 6 * N
+    max_rows = max_rows or (N + B - 1) // B
+    h = CriticHead(N, S, B, L, ds, dl, H2, Hd, B, max_rows, 6 * max_rows, 6,
+                   R.new("Zs", N * K1 * ds * f), R.new("Zk", N * K1 * 3 * dl * f), R.new("W", K1 * (ds + dl) * H2 * f),
+                   R.new("b_w1", Hd * H2 * f), R.new("b_b1", Hd * f), R.new("b_w2", Hd * f), R.new("b_b2", f),
+                   R.new("s_w1", Hd * H2 * f), R.new("s_b1", Hd * f), R.new("s_w2", Hd * f), R.new("s_b2", f),
+                   R.new("wb", 2 * B * f), R.new("ws", 2 * S * f),
+                   R.new("st_rowptr", (S + 1) * 4), R.new("st_col", N * 4), R.new("story_of_voxel", N * 4),
+                   R.new("sg_rowptr", (B + 1) * 4), R.new("sg_col", S * 4), R.new("graph_of_story", S * 4),
+                   R.new("graph_of_voxel", N * 4), R.new("a_rowptr", (N + 1) * 4), R.new("a_col", Ev * 4),
+                   R.new("a_count", N * f), R.new("at_rowptr", (N + 1) * 4), R.new("at_col", Ev * 4),
+                   R.new("blk_ptr", (B + 1) * 4))
+    lib.bg_critic_head_workspace.restype = C.c_int64
+    lib.bg_critic_head_workspace.argtypes = [C.c_void_p]
+    nws = lib.bg_critic_head_workspace(C.byref(h))
+    if nws < 0:
+        return nws, None, None, R, h
+    work = R.new("workspace", nws * f)
+    lib.bg_critic_head_forward_f32.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.bg_critic_head_backward_f32.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 10
+
+    def calls_of(fn, *args):
+        lib.stub_reset()
+        rc = fn(*args)
+        out = []
+        for i in range(lib.stub_count()):
+            c = lib.stub_call(i)
+            out.append((c[0], [c[2 + k] for k in range(c[1])]))
+        return rc, out
+    rc_f, fwd = calls_of(lib.bg_critic_head_forward_f32, C.byref(h), 0.1, work, nws, R.new("loss", 2 * f), None)
+    grads = [R.new("gW", K1 * (ds + dl) * H2 * f), R.new("g_b_w1", Hd * H2 * f), R.new("g_b_b1", Hd * f),
+             R.new("g_b_w2", Hd * f), R.new("g_b_b2", f), R.new("g_s_w1", Hd * H2 * f), R.new("g_s_b1", Hd * f),
+             R.new("g_s_w2", Hd * f), R.new("g_s_b2", f)]
+    rc_b, bwd = calls_of(lib.bg_critic_head_backward_f32, C.byref(h), 0.1, R.new("go", f), work, nws, *grads, None)
+    return (rc_f, rc_b), fwd, bwd, R, h
+
+
+def _check_critic_calls(calls, R, h):
+    """Every pointer + extent of every launcher call lies inside one buffer; outputs never alias their inputs."""
+    f = 4
+    N, S, B = h.N, h.S, h.B
+    rows_of = {"st_rowptr": (S, N), "sg_rowptr": (B, S)}           # pooling plan -> (segments, rows of the operand)
+    for ci, (kind, a) in enumerate(calls):
+        tag = "call %d kind %d" % (ci, kind)
+        if kind == 1:
+            (tA, tB, M, Nn, n_seg), A, lda, Ks = a[0:5], a[5:9], a[9:13], a[13:17]
+            Bp, ldb, Cp, ldc, bias, rs, act, res, ldr, pre, ldp, rows, acc, ldacc, pro, ldpro = a[17:33]
+            assert n_seg == 1 and not rs and not res and not rows and not pro
+            K = Ks[0]
+            if tA:
+                assert lda[0] >= M
+                R.check(A[0], ((K - 1) * lda[0] + M) * f, tag + " A^T")
+            else:
+                assert lda[0] >= K
+                R.check(A[0], ((M - 1) * lda[0] + K) * f, tag + " A")
+            if tB:
+                assert ldb >= K
+                R.check(Bp, ((Nn - 1) * ldb + K) * f, tag + " B [N,K]")
+            else:
+                assert ldb >= Nn
+                R.check(Bp, ((K - 1) * ldb + Nn) * f, tag + " B [K,N]")
+            assert ldc >= Nn
+            R.check(Cp, ((M - 1) * ldc + Nn) * f, tag + " C")
+            assert Cp != A[0] and Cp != Bp
+            if bias:
+                R.check(bias, Nn * f, tag + " bias")
+            if pre:
+                assert ldp >= Nn
+                R.check(pre, ((M - 1) * ldp + Nn) * f, tag + " pre_add")
+                assert pre != Cp
+            if acc:
+                assert ldacc >= Nn
+                R.check(acc, ((M - 1) * ldacc + Nn) * f, tag + " acc_init")
+                assert acc != Cp
+        elif kind == 10:
+            src, dst, n, K, Pn, W, to_outer = a
+            R.check(src, n * K * Pn * W * f, tag + " src")
+            R.check(dst, n * K * Pn * W * f, tag + " dst")
+            assert src != dst
+        elif kind == 11:
+            x, ldx, rp, col, chunk, out, ldo, arg, n_rows, H = a
+            nseg, xr = rows_of[R.check(rp, 4, tag + " rowptr")]
+            assert n_rows == nseg and chunk == 0
+            R.check(rp, (nseg + 1) * 4, tag + " rowptr")
+            R.check(col, xr * 4, tag + " col")
+            R.check(x, ((xr - 1) * ldx + H) * f, tag + " x")
+            R.check(out, ((nseg - 1) * ldo + H) * f, tag + " out")
+            R.check(arg, nseg * H * 4, tag + " arg")
+            assert out != x
+        elif kind == 12:
+            x, ldx, arg, out, ldo, n_seg, H = a
+            R.check(arg, n_seg * H * 4, tag + " arg")
+            R.check(out, ((n_seg - 1) * ldo + H) * f, tag + " out")
+            R.check(x, H * f, tag + " x")
+        elif kind == 13:
+            g, ldg, arg, seg_of, out, ldo, n_seg, n_rows, H = a
+            R.check(g, ((n_seg - 1) * ldg + H) * f, tag + " g")
+            R.check(arg, n_seg * H * 4, tag + " arg")
+            R.check(seg_of, n_rows * 4, tag + " seg_of")
+            R.check(out, ((n_rows - 1) * ldo + H) * f, tag + " out")
+        elif kind == 14:
+            (x0, ldx, rp, col, rsc, rm, csc, cm, blk, n_blk, mr, mn, md, add, ld_add, add_step, out, ldo, out_step,
+             n_steps, W) = a
+            R.check(x0, ((N - 1) * ldx + W) * f, tag + " x0")
+            R.check(rp, (N + 1) * 4, tag + " rowptr")
+            R.check(blk, (n_blk + 1) * 4, tag + " blk_ptr")
+            assert (rm != 0) != (cm != 0)
+            R.check(rsc if rm else csc, N * f, tag + " scale")
+            for k in range(1, n_steps + 1):
+                if add:
+                    R.check(add + (k - 1) * add_step * f, ((N - 1) * ld_add + W) * f, tag + " add_%d" % k)
+                if out_step or k == n_steps:
+                    R.check(out + (k - 1) * out_step * f, ((N - 1) * ldo + W) * f, tag + " out_%d" % k)
+        elif kind == 15:
+            vb, wb, nb, vs, ws, ns, g, ldg, n_rows, W, part, loss = a
+            R.check(vb, nb * f, tag); R.check(wb, nb * f, tag); R.check(vs, ns * f, tag); R.check(ws, ns * f, tag)
+            R.check(g, ((n_rows - 1) * ldg + W) * f, tag + " grads")
+            R.check(part, 128 * f, tag + " partial")
+            assert R.check(loss, 2 * f, tag + " loss") == "loss"
+        elif kind == 16:
+            go, wb, nb, ws, ns, g, ldg, n_rows, W, dvb, dvs, dg = a
+            assert R.check(go, f, tag) == "go"
+            R.check(g, ((n_rows - 1) * ldg + W) * f, tag + " grads")
+            R.check(dvb, nb * f, tag); R.check(dvs, ns * f, tag); R.check(dg, n_rows * W * f, tag + " d_grads")
+            assert dg != g
+        elif kind == 17:
+            x, ldx, M, Nn, part, nb, out, accum = a
+            R.check(x, ((M - 1) * ldx + Nn) * f, tag + " x")
+            R.check(part, nb * Nn * f, tag + " partial")
+            R.check(out, Nn * f, tag + " out")
+        elif kind == 18:
+            x, y, out, n = a
+            for q in (x, y, out):
+                R.check(q, n * f, tag)
+        elif kind == 19:
+            M, Rr, A, lda, n_seg, B0, ldb0, N0, Cp, ldc, part, splits, accum = a
+            assert n_seg == 1 and lda >= M and ldb0 >= N0 and ldc >= N0 and splits >= 1
+            R.check(A, ((Rr - 1) * lda + M) * f, tag + " A")
+            R.check(B0, ((Rr - 1) * ldb0 + N0) * f, tag + " B")
+            R.check(Cp, ((M - 1) * ldc + N0) * f, tag + " C")
+            R.check(part, splits * M * N0 * f, tag + " partial")
+        elif kind == 20:
+            dst, dp, src, sp, width, height = a
+            R.check(dst, (height - 1) * dp + width, tag + " dst")
+            R.check(src, (height - 1) * sp + width, tag + " src")
+        else:
+            raise AssertionError("unexpected launcher %d" % kind)
+
+
+@pytest.mark.parametrize("N,S,B", [(11520, 80, 8), (10130, 75, 8), (7, 3, 2), (1001, 17, 3)])
+def test_critic_head_host_sequence_and_extents(drv, N, S, B):
+    (rc_f, rc_b), fwd, bwd, R, h = _critic_run(drv, N, S, B)
+    assert rc_f == 0 and rc_b == 0
+    assert [k for k, _ in fwd] == [10, 1, 1, 1, 1, 11, 11, 11, 11, 1, 1, 1, 1, 11, 11, 12, 1, 1, 13, 13, 1, 10, 14, 15]
+    assert [k for k, _ in bwd] == ([16, 20, 14, 10, 1, 19, 12, 12, 17, 17, 1, 1, 1, 1] + [19, 17, 1, 19, 17, 1, 13, 13]
+                                   + [19, 17, 1, 19, 17, 1] + [13, 19, 13, 19, 18, 19])
+    _check_critic_calls(fwd, R, h)
+    _check_critic_calls(bwd, R, h)
+    # where the gradients land: every one of the nine outputs is written (assigned first, then accumulated into)
+    written = {}
+    for k, a in bwd:
+        if k == 19:
+            written.setdefault(R.check(a[8], 4, "C"), []).append(a[12])
+        elif k == 17 and R.check(a[6], 4, "out") != "workspace":
+            written.setdefault(R.check(a[6], 4, "out"), []).append(a[7])
+        elif k == 1:
+            nm = R.check(a[19], 4, "C")
+            if nm.startswith("g"):
+                written.setdefault(nm, []).append(0)
+    assert set(written) == {"gW", "g_b_w1", "g_b_b1", "g_b_w2", "g_b_b2", "g_s_w1", "g_s_b1", "g_s_w2", "g_s_b2"}
+    for nm, acc in written.items():
+        assert acc[0] == 0 and all(x == 1 for x in acc[1:] if nm != "gW"), (nm, acc)
+    # gW: static rows assigned once, label rows assigned then accumulated twice
+    gw = [(a[8], a[12]) for k, a in bwd if k == 19 and R.check(a[8], 4, "C") == "gW"]
+    base = R.r["gW"][0]
+    assert [(p - base, acc) for p, acc in gw] == [(13 * 32 * 256 * 4, 0), (13 * 32 * 256 * 4, 1), (13 * 32 * 256 * 4, 1), (0, 0)]
+
+
+def test_critic_head_rejects_unsupported_sizes(drv):
+    assert _critic_run(drv, 100, 10, 2, ds=30)[0] == -1          # workspace query: widths must be multiples of 4
+    rc, *_ = _critic_run(drv, 100, 10, 2, L=0)
+    assert rc == -1

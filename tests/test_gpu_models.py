@@ -478,6 +478,82 @@ def test_trainer_other_objectives_match_oracle(cuda, gan_loss):
     _assert_adam_steps_agree(Go.named_parameters(), tr.generator.named_parameters(), before)
 
 
+@pytest.mark.parametrize("preset,ragged,seed", [("small", True, 31), ("small", "jitter", 32), ("dataset", "jitter", 33)])
+def test_critic_head_in_one_host_call_equals_op_by_op_path(cuda, preset, ragged, seed):
+    """ops.CriticHead (bg_critic_head_forward_f32 / _backward_f32: everything of a WGAN-GP critic update below the
+    coefficient table, forward and hand-derived backward, as one host call each) against critic_terms + CriticLoss
+    (the same kernels launched op by op under autograd) on identical parameters, labels and sample point: objective
+    and penalty to 1e-6 relative, every discriminator gradient to 2e-5 of its scale."""
+    from building_gan_amd import models as hm, ops
+    from building_gan_amd.plan import build_plan
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup(preset, seed, ragged, cuda)
+    torch.manual_seed(seed)
+    Nv = sz["Nv"]
+    fake = (torch.zeros(Nv, 6).scatter_(1, torch.randint(0, 6, (Nv, 1)), 1.0) * (torch.rand(Nv, 1) > 0.3)).to(cuda)
+    sample = ops.gp_sample_raw(gpu.voxel_label, fake, torch.rand(Nv, device=cuda))
+    plan = build_plan(gpu)
+    B, S = plan.B, plan.S
+    wb = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B)]).to(cuda)
+    ws = torch.cat([torch.full((S,), -1.0 / S), torch.full((S,), 1.0 / S)]).to(cuda)
+    coef = 10.0 / Nv
+
+    def grads_of(fn):
+        for p in Dh.parameters():
+            p.grad = None
+        plan.begin_iteration()
+        with Dh.shared_coefficients():
+            loss, pen = fn()
+        loss.backward()
+        return loss.detach().cpu(), pen.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in Dh.named_parameters()}
+
+    def op_by_op():
+        vb, vs, g = Dh.critic_terms(gpu, gpu.voxel_label, fake, sample, stacked=True)
+        return ops.CriticLoss.apply(vb, vs, g, wb, ws, coef)
+
+    def one_call():
+        res = Dh.critic_objective(gpu, gpu.voxel_label, fake, sample, wb, ws, coef)
+        assert res is not None, "the one-call path declined this batch"
+        return res
+
+    l0, p0, g0 = grads_of(op_by_op)
+    l1, p1, g1 = grads_of(one_call)
+    torch.testing.assert_close(l1, l0, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(p1, p0, rtol=1e-6, atol=1e-7)
+    top = max(float(g.abs().max()) for g in g0.values())
+    worst = 0.0
+    for n in g0:
+        e = float((g1[n] - g0[n]).abs().max()) / max(float(g0[n].abs().max()), 1e-3 * top)
+        assert e <= 2e-5, (n, e)
+        worst = max(worst, e)
+    print("critic head vs op-by-op: worst gradient error %.2e" % worst)
+    # switched off, the trainer's iteration takes the op-by-op path and arrives at the same update
+    assert hm.FUSE_CRITIC_HEAD
+
+
+def test_trainer_iteration_with_and_without_the_one_call_critic_head(cuda, monkeypatch):
+    """One critic-only Trainer iteration from identical state with models.FUSE_CRITIC_HEAD on / off: same d_loss, same
+    flat gradient buffer (to 2e-5 of its max), same penalty statistic."""
+    from building_gan_amd import models as hm
+    from building_gan_amd.train import Trainer
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 35, "jitter", cuda)
+    u = torch.rand(sz["Nv"], device=cuda)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(hm, "FUSE_CRITIC_HEAD", on)
+        torch.manual_seed(35)
+        tr = Trainer(cuda)
+        tr.generator.load_state_dict(Go.state_dict())
+        tr.discriminator.load_state_dict(Do.state_dict())
+        tr.refresh_derived()
+        gpu.__dict__.pop("_bg_plan", None)
+        st = tr.train_iteration(gpu, 1, pz.to(cuda), vz.to(cuda), _to(noise, cuda), u)
+        res.append((st["d_loss"].cpu(), st["gp"].cpu(), tr.opt_d.grad.detach().cpu().clone()))
+    (l1, gp1, g1), (l0, gp0, g0) = res
+    torch.testing.assert_close(l1, l0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gp1, gp0, rtol=1e-5, atol=1e-7)
+    assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
+
+
 def test_fused_attention_forward_equals_unfused(cuda):
     """The one-launch Attention call of graph-free passes (bg_attention_fwd_f32) against the five-kernel
     autograd path on identical weights, inputs and noise: same pointers, activations to rounding."""
