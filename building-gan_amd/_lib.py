@@ -75,6 +75,8 @@ SIGNATURES = {
     "bg_add_f32": [_p, _p, _p, _i64, _p],
     "bg_critic_head_forward_f32": [_p, _f, _p, _i64, _p, _p],
     "bg_critic_head_backward_f32": [_p, _f, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "bg_gstack_forward_f32": [_p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p],
+    "bg_gstack_backward_f32": [_p, _p, _p, _p, _p, _p, _i64, _p, _i64] + [_p] * 6 + [_p] * 10 + [_p],
     "bg_plan_layout": [_p, _p, _p, _p],
     "bg_plan_build": [_p, _p, _p, _p],
 }
@@ -104,6 +106,11 @@ class PlanIn(C.Structure):
     _fields_ = [(n, _i64) for n in ("Np", "Nv", "Ep", "Ev", "Ec", "B", "S", "n_slot")] + \
                [(n, _fp) for n in ("pe_src", "pe_dst", "ve_src", "ve_dst", "cep", "cev", "vfc", "vbi", "pcc", "slot_graph",
                                    "target_ratio")] + [("chunk_rows", _i32 * 4)]
+
+
+class GeneratorBackPlan(C.Structure):
+    """include/bgan.h: bgGeneratorBackPlan."""
+    _fields_ = [(n, _fp) for n in ("vt_rowptr", "vt_col", "cp_rowptr", "cp_col", "cp_perm")] + [("cp_one_launch", _i64)]
 
 
 class CriticHead(C.Structure):
@@ -151,11 +158,13 @@ def load() -> C.CDLL:
     lib.bg_generator_forward_workspace.argtypes = [_i64] * 5
     lib.bg_d_coef_backward_workspace.restype = C.c_int64
     lib.bg_d_coef_backward_workspace.argtypes = [_i64] * 4
+    lib.bg_gstack_workspace.restype = C.c_int64
+    lib.bg_gstack_workspace.argtypes = [_i64] * 6
     lib.bg_critic_head_workspace.restype = C.c_int64
     lib.bg_critic_head_workspace.argtypes = [_p]
     lib.bg_abi_sizeof.restype = C.c_int64
     lib.bg_abi_sizeof.argtypes = [C.c_int]
-    for which, st in enumerate((GeneratorWeights, GeneratorPlan, PlanIn, CriticHead)):
+    for which, st in enumerate((GeneratorWeights, GeneratorPlan, PlanIn, CriticHead, GeneratorBackPlan)):
         if lib.bg_abi_sizeof(which) != C.sizeof(st):
             raise BganError(f"{LIB_PATH} was built from another revision of include/bgan.h ({st.__name__}: "
                             f"{lib.bg_abi_sizeof(which)} bytes there, {C.sizeof(st)} here): rebuild it "

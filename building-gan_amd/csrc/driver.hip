@@ -5,6 +5,7 @@
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <initializer_list>
 
 namespace {
 
@@ -74,6 +75,7 @@ extern "C" int64_t bg_abi_sizeof(int which) {
         case 1: return (int64_t)sizeof(bgGeneratorPlan);
         case 2: return (int64_t)sizeof(bgPlanIn);
         case 3: return (int64_t)sizeof(bgCriticHead);
+        case 4: return (int64_t)sizeof(bgGeneratorBackPlan);
         default: return -1;
     }
 }
@@ -452,5 +454,278 @@ extern "C" int bg_critic_head_backward_f32(const bgCriticHead* hp, float coef, c
     }
     BG_TRY(bg_add_f32(b.v[0], b.v[1], b.v[2], N * H2, s));
     BG_TRY(tn(K1 * ds, H2, N, h.Zs, b.v[2], gWs, b.splitk, 0, s));
+    return BG_OK;
+}
+
+// ---------------------------------------------------------------- generator voxel GNN: forward that saves, backward
+namespace {
+
+struct GStack {
+    int64_t n_ops;                   // attention / block calls in forward order
+    int kind[64];                    // 0 = attention, 1 = block
+    int idx[64];                     // call number among its kind
+    int64_t n_att, n_blk;
+    float *nnp, *posb, *v[65], *gm[32], *y[32], *a[32], *soft0[32], *soft[32];
+    float *pq, *term, *h0, *ha;                                                   // forward scratch
+    // backward scratch
+    float *g0, *g1, *gz, *gterm, *story, *sb, *gx, *gsb, *g_story, *G_al, *gg, *d_att, *dpre, *dth_p, *gb_acc, *gx_acc,
+          *tmpNp, *zero, *splitk, *colsum;
+};
+
+int32_t tn_splits_multi(int64_t M, const int64_t* Ns, int n_seg, int64_t R) {     // ops.gemm_tn_raw's rule
+    int64_t ct = 0;
+    for (int i = 0; i < n_seg; ++i) ct += (Ns[i] + 63) / 64;
+    const int64_t tiles = ((M + 63) / 64) * ct, steps = (R + 31) / 32;
+    int64_t s = (512 + tiles - 1) / tiles;
+    if (s > steps) s = steps;
+    if (s > 256) s = 256;
+    return (int32_t)(s < 1 ? 1 : s);
+}
+
+int gstack_ops(int64_t L, GStack& g) {
+    int64_t last_att = -1;
+    for (int64_t i = 0; i < L; ++i) if (i % 2 == 0 && i != 0) last_att = i;
+    g.n_ops = 0; g.n_att = 0; g.n_blk = 0;
+    g.kind[g.n_ops] = 0; g.idx[g.n_ops++] = (int)g.n_att++;
+    for (int64_t i = 0; i <= last_att; ++i) {
+        if (g.n_ops + 2 >= 64 || g.n_blk >= 32 || g.n_att >= 32) return BG_ERR_SHAPE;
+        g.kind[g.n_ops] = 1; g.idx[g.n_ops++] = (int)g.n_blk++;
+        if (i % 2 == 0 && i != 0) { g.kind[g.n_ops] = 0; g.idx[g.n_ops++] = (int)g.n_att++; }
+    }
+    return BG_OK;
+}
+
+int cross_logit_blocks(int64_t Nv) {                       // ops.AttentionNode._backward_tail
+    int64_t nb = (Nv + 3) / 4;
+    if (nb > 1024) nb = 1024;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+int carve_gstack(Arena& ar, int64_t Np, int64_t Nv, int64_t S, int64_t Ec, int64_t H, int64_t L, GStack& g) {
+    int rc = gstack_ops(L, g);
+    if (rc != BG_OK) return rc;
+    g.nnp = ar.take(Np * H); g.posb = ar.take(Nv * H);
+    for (int64_t k = 0; k <= g.n_ops; ++k) g.v[k] = ar.take(Nv * H);
+    for (int64_t i = 0; i < g.n_blk; ++i) { g.gm[i] = ar.take(Nv * H); g.y[i] = ar.take(Nv * H); }
+    for (int64_t c = 0; c < g.n_att; ++c) { g.a[c] = ar.take(Nv * H); g.soft0[c] = ar.take(Nv); g.soft[c] = ar.take(Ec); }
+    g.pq = ar.take(S * 2 * H); g.term = ar.take(S * H); g.h0 = ar.take(Nv); g.ha = ar.take(Ec);
+    g.g0 = ar.take(Nv * H); g.g1 = ar.take(Nv * H); g.gz = ar.take(Nv * H); g.gterm = ar.take(S * H); g.story = ar.take(S * H);
+    g.sb = ar.take(S * H); g.gx = ar.take(Nv * 2 * H); g.gsb = ar.take(S * 2 * H); g.g_story = ar.take(S * H);
+    g.G_al = ar.take(Nv * (H + 4)); g.gg = ar.take(Nv * H); g.d_att = ar.take(Ec); g.dpre = ar.take(Ec * H);
+    g.dth_p = ar.take((int64_t)cross_logit_blocks(Nv) * H);
+    g.gb_acc = ar.take(Np * H); g.gx_acc = ar.take(Np * H); g.tmpNp = ar.take(Np * H); g.zero = ar.take(Nv * H);
+    int64_t sk = 0;
+    auto need = [&](int64_t M, std::initializer_list<int64_t> ns, int64_t R) {
+        int64_t Ns[4] = {0, 0, 0, 0}, N = 0; int n = 0;
+        for (int64_t v : ns) { Ns[n++] = v; N += v; }
+        const int64_t x = (int64_t)tn_splits_multi(M, Ns, n, R) * M * N;
+        if (x > sk) sk = x;
+    };
+    need(H, {H, H, 4}, Nv); need(H, {H, H}, S); need(H + 4, {H}, Nv); need(H, {4}, Nv); need(H, {H}, Np);
+    g.splitk = ar.take(sk);
+    g.colsum = ar.take(256 * (H + 4));
+    return BG_OK;
+}
+
+int gstack_shape_ok(const bgGeneratorWeights* w, const bgGeneratorPlan* p) {
+    const int64_t H = w->H, L = w->voxel_layer;
+    if (H <= 0 || p->Np <= 0 || p->Nv <= 0 || p->S <= 0 || p->Ec <= 0 || L < 1) return BG_ERR_ARG;
+    if (H % 64 != 0 || H > 256 || p->Nv > 65536) return BG_ERR_SHAPE;
+    if (!p->vox_all_has || p->cx_max_len < 1 || p->cx_max_len > 64) return BG_ERR_SHAPE;
+    return BG_OK;
+}
+
+// C [M, sum Ns] (+)= A^T [B_0 | B_1 | ..] for A [R, M] (contiguous), B_s [R, Ns[s]] with pitch ldb[s]
+int tn_multi(int64_t M, int64_t R, const float* A_, int n_seg, const float* const* Bs, const int64_t* ldb, const int64_t* Ns,
+             float* C_, float* partial, int accumulate, bgStream s) {
+    int64_t N = 0;
+    for (int i = 0; i < n_seg; ++i) N += Ns[i];
+    return bg_gemm_tn_splitk_f32(M, R, A_, M, n_seg, Bs, ldb, Ns, C_, N, partial, tn_splits_multi(M, Ns, n_seg, R), accumulate, s);
+}
+
+}  // namespace
+
+extern "C" int64_t bg_gstack_workspace(int64_t Np, int64_t Nv, int64_t S, int64_t Ec, int64_t H, int64_t L) {
+    if (Np <= 0 || Nv <= 0 || S <= 0 || Ec <= 0 || H <= 0 || L < 1) return -1;
+    Arena ar{nullptr, 0, 0};
+    GStack g;
+    if (carve_gstack(ar, Np, Nv, S, Ec, H, L, g) != BG_OK) return -1;
+    return ar.used + 64;
+}
+
+extern "C" int bg_gstack_forward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan* p, const float* x,
+                                     const float* voxel_in, const float* pdm4, const float* const* exp_mask,
+                                     const float* const* exp_att, int64_t n_calls, float* workspace,
+                                     int64_t workspace_floats, float* mask_hard, float* mask_soft, float* att_hard,
+                                     float* att_soft, bgStream s) {
+    if (!w || !p || !x || !voxel_in || !pdm4 || !exp_mask || !exp_att || !workspace || !mask_hard || !mask_soft || !att_hard ||
+        !att_soft) return BG_ERR_ARG;
+    int rc = gstack_shape_ok(w, p);
+    if (rc != BG_OK) return rc;
+    if (!bg_aligned16(workspace)) return BG_ERR_ALIGN;
+    const int64_t H = w->H, Np = p->Np, Nv = p->Nv, S = p->S, Ec = p->Ec, L = w->voxel_layer;
+    Arena ar{workspace, 0, workspace_floats};
+    GStack g;
+    rc = carve_gstack(ar, Np, Nv, S, Ec, H, L, g);
+    if (rc != BG_OK) return rc;
+    if (ar.used > workspace_floats || n_calls != g.n_att) return BG_ERR_ARG;
+
+    BG_TRY(linear(Nv, H, 1, voxel_in, 4, nullptr, 0, nullptr, 0, 4, w->v_enc_w, 4, g.v[0], w->v_enc_b, nullptr, BG_ACT_NONE,
+                  nullptr, w->pe, H, p->level, nullptr, s));
+    BG_TRY(linear(Np, H, 1, x, H, nullptr, 0, nullptr, 0, H, w->nnp_w, H, g.nnp, w->nnp_b, nullptr, BG_ACT_NONE, nullptr,
+                  nullptr, 0, nullptr, nullptr, s));
+    BG_TRY(linear(Nv, H, 1, pdm4, 4, nullptr, 0, nullptr, 0, 4, w->Wc + 2 * H, w->ldwc, g.posb, w->bc, nullptr, BG_ACT_NONE,
+                  nullptr, nullptr, 0, nullptr, nullptr, s));
+    for (int64_t k = 0; k < g.n_ops; ++k) {
+        const float* v = g.v[k];
+        float* vn = g.v[k + 1];
+        if (g.kind[k] == 0) {
+            const int c = g.idx[k];
+            const bool last = c == g.n_att - 1;
+            BG_TRY(linear(Nv, H, 1, v, H, nullptr, 0, nullptr, 0, H, w->Wcat, H, g.a[c], w->bcat, nullptr, BG_ACT_NONE, nullptr,
+                          nullptr, 0, nullptr, nullptr, s));
+            BG_TRY(bg_attention_fwd_f32(g.a[c], H, nullptr, 0, g.nnp, H, x, H, v, H, w->theta, p->cx_rowptr, p->cx_col,
+                                        exp_mask[c], exp_att[c], -1.0f, last ? mask_soft : g.soft0[c], last ? mask_hard : g.h0,
+                                        last ? att_soft : g.soft[c], last ? att_hard : g.ha, vn, H, Nv, H,
+                                        w->Wcat + H * H, H, w->bcat + H, s));
+        } else {
+            const int i = g.idx[k];
+            BG_TRY(bg_gather_story_f32(v, H, p->vx_rowptr, p->vx_col, p->vx_count, BG_SCALE_DIV, g.gm[i], H, Nv,
+                                       p->st_rowptr, p->st_col, p->st_count, w->Wsb, 2 * H, H, g.pq, 2 * H, S, H, s));
+            BG_TRY(bg_spmm_add_f32(g.pq + H, 2 * H, p->sb_rowptr, p->sb_col, p->sb_count, BG_SCALE_DIV, nullptr, BG_SCALE_NONE,
+                                   g.pq, 2 * H, nullptr, 0, nullptr, 0, nullptr, nullptr, BG_SCALE_NONE, g.term, H, S, H, s));
+            const float* A[4] = {v, g.gm[i], nullptr, nullptr};
+            const int64_t ld[4] = {H, H, 0, 0}, Ks[4] = {H, H, 0, 0};
+            BG_TRY(bg_gemm_f32(0, 1, Nv, H, 2, A, ld, Ks, w->Wc, w->ldwc, vn, H, nullptr, nullptr, BG_ACT_LEAKY, 0.01f, v, H,
+                               g.term, H, p->story_of_voxel, g.posb, H, g.y[i], H, s));
+        }
+    }
+    return BG_OK;
+}
+
+extern "C" int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan* p, const bgGeneratorBackPlan* bp,
+                                      const float* x, const float* voxel_in, const float* pdm4, int64_t n_calls,
+                                      float* workspace, int64_t workspace_floats, const float* mask_soft,
+                                      const float* att_soft, const float* g_mask_hard, const float* g_mask_soft,
+                                      const float* g_att_hard, const float* g_att_soft, float* g_x, float* g_enc_w,
+                                      float* g_enc_b, float* g_nnp_w, float* g_nnp_b, float* g_Wcat, float* g_bcat,
+                                      float* g_theta, float* g_Wc, float* g_Wsb, bgStream s) {
+    if (!w || !p || !bp || !x || !voxel_in || !pdm4 || !workspace || !mask_soft || !att_soft || !g_x || !g_enc_w || !g_enc_b ||
+        !g_nnp_w || !g_nnp_b || !g_Wcat || !g_bcat || !g_theta || !g_Wc || !g_Wsb) return BG_ERR_ARG;
+    if (!bp->vt_rowptr || !bp->vt_col || !bp->cp_rowptr || !bp->cp_col || !bp->cp_perm) return BG_ERR_ARG;
+    int rc = gstack_shape_ok(w, p);
+    if (rc != BG_OK) return rc;
+    if (!bg_aligned16(workspace)) return BG_ERR_ALIGN;
+    const int64_t H = w->H, Np = p->Np, Nv = p->Nv, S = p->S, Ec = p->Ec, L = w->voxel_layer;
+    Arena ar{workspace, 0, workspace_floats};
+    GStack g;
+    rc = carve_gstack(ar, Np, Nv, S, Ec, H, L, g);
+    if (rc != BG_OK) return rc;
+    if (ar.used > workspace_floats || n_calls != g.n_att) return BG_ERR_ARG;
+    hipStream_t st = (hipStream_t)s;
+    const int nb = cross_logit_blocks(Nv);
+    bool have_att = false, have_blk = false, have_np = false;
+    BG_HIP(hipMemsetAsync(g.zero, 0, sizeof(float) * (size_t)(Nv * H), st));
+    const float* gin = g.zero;                 // gradient at the current call's output (the last call's features are unused)
+    float* bufs[2] = {g.g0, g.g1};
+    int flip = 0;
+    for (int64_t k = g.n_ops - 1; k >= 0; --k) {
+        const float* v = g.v[k];
+        float* gout = bufs[flip];
+        flip ^= 1;
+        if (g.kind[k] == 0) {
+            const int c = g.idx[k];
+            const bool last = c == g.n_att - 1;
+            const float* soft0 = last ? mask_soft : g.soft0[c];
+            const float* soft = last ? att_soft : g.soft[c];
+            BG_TRY(bg_attention_bwd_head_f32(gin, H, x, H, soft0, soft, p->cx_rowptr, p->cx_col, last ? g_att_soft : nullptr,
+                                             last ? g_att_hard : nullptr, last ? g_mask_soft : nullptr,
+                                             last ? g_mask_hard : nullptr, -1.0f, g.gg, H, g.d_att, g.G_al + H, H + 4, Nv, H, s));
+            if (!last) {                       // (the last call's gg is zero: nothing reaches x through its gather)
+                float* dst = have_np ? g.tmpNp : g.gx_acc;
+                if (bp->cp_one_launch)
+                    BG_TRY(bg_segreduce_sum_f32(g.gg, H, bp->cp_rowptr, bp->cp_col, soft, bp->cp_perm, nullptr, BG_SCALE_NONE,
+                                                nullptr, 0, 0, nullptr, dst, H, Np, H, s));
+                else
+                    BG_TRY(bg_spmm_f32(g.gg, H, bp->cp_rowptr, bp->cp_col, soft, bp->cp_perm, nullptr, BG_SCALE_NONE, nullptr,
+                                       BG_SCALE_NONE, dst, H, Np, H, s));
+                if (have_np) BG_TRY(bg_add_f32(g.gx_acc, g.tmpNp, g.gx_acc, Np * H, s));
+            }
+            BG_TRY(bg_cross_logits_bwd_f32(g.a[c], H, g.nnp, H, w->theta, p->cx_rowptr, p->cx_col, g.d_att, g.dpre, g.G_al,
+                                           H + 4, g.dth_p, nb, Nv, H, s));
+            {
+                float* dst = have_att ? g.tmpNp : g.gb_acc;
+                if (bp->cp_one_launch)
+                    BG_TRY(bg_segreduce_sum_f32(g.dpre, H, bp->cp_rowptr, bp->cp_perm, nullptr, nullptr, nullptr, BG_SCALE_NONE,
+                                                nullptr, 0, 0, nullptr, dst, H, Np, H, s));
+                else
+                    BG_TRY(bg_spmm_f32(g.dpre, H, bp->cp_rowptr, bp->cp_perm, nullptr, nullptr, nullptr, BG_SCALE_NONE, nullptr,
+                                       BG_SCALE_NONE, dst, H, Np, H, s));
+                if (have_att) BG_TRY(bg_add_f32(g.gb_acc, g.tmpNp, g.gb_acc, Np * H, s));
+            }
+            if (!last && !have_np) have_np = true;
+            BG_TRY(bg_colsum_f32(g.dth_p, H, nb, H, g.colsum, colsum_blocks(nb), g_theta, have_att ? 1 : 0, s));
+            {
+                const float* Bs[4] = {v, nullptr, nullptr, nullptr};
+                const int64_t ldb[4] = {H, 0, 0, 0}, Ns[4] = {H, 0, 0, 0};
+                BG_TRY(tn_multi(H + 4, Nv, g.G_al, 1, Bs, ldb, Ns, g_Wcat, g.splitk, have_att ? 1 : 0, s));
+            }
+            BG_TRY(bg_colsum_f32(g.G_al, H + 4, Nv, H + 4, g.colsum, colsum_blocks(Nv), g_bcat, have_att ? 1 : 0, s));
+            {
+                const float* A[4] = {g.G_al, nullptr, nullptr, nullptr};
+                const int64_t ld[4] = {H + 4, 0, 0, 0}, Ks[4] = {H + 4, 0, 0, 0};
+                BG_TRY(bg_gemm_f32(0, 0, Nv, H, 1, A, ld, Ks, w->Wcat, H, gout, H, nullptr, nullptr, BG_ACT_NONE, 0.f, gin, H,
+                                   nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
+            }
+            have_att = true;
+        } else {
+            const int i = g.idx[k];
+            BG_TRY(bg_story_bwd_f32(gin, H, g.y[i], H, v, H, p->st_rowptr, p->st_col, p->st_count, 0.01f, g.gz, H, g.gterm, H,
+                                    g.story, H, S, H, s));
+            {
+                const float* Bs[4] = {v, g.gm[i], pdm4, nullptr};
+                const int64_t ldb[4] = {H, H, 4, 0}, Ns[4] = {H, H, 4, 0};
+                BG_TRY(tn_multi(H, Nv, g.gz, 3, Bs, ldb, Ns, g_Wc, g.splitk, have_blk ? 1 : 0, s));
+            }
+            BG_TRY(bg_spmm_f32(g.story, H, p->sb_rowptr, p->sb_col, nullptr, nullptr, p->sb_count, BG_SCALE_DIV, nullptr,
+                               BG_SCALE_NONE, g.sb, H, S, H, s));
+            {
+                const float* Bs[4] = {g.story, g.sb, nullptr, nullptr};
+                const int64_t ldb[4] = {H, H, 0, 0}, Ns[4] = {H, H, 0, 0};
+                BG_TRY(tn_multi(H, S, g.gterm, 2, Bs, ldb, Ns, g_Wsb, g.splitk, have_blk ? 1 : 0, s));
+            }
+            {
+                const float* A[4] = {g.gz, nullptr, nullptr, nullptr};
+                const int64_t ld[4] = {H, 0, 0, 0}, Ks[4] = {H, 0, 0, 0};
+                BG_TRY(bg_gemm_f32(0, 0, Nv, 2 * H, 1, A, ld, Ks, w->Wc, w->ldwc, g.gx, 2 * H, nullptr, nullptr, BG_ACT_NONE, 0.f,
+                                   nullptr, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
+                A[0] = g.gterm;
+                BG_TRY(bg_gemm_f32(0, 0, S, 2 * H, 1, A, ld, Ks, w->Wsb, 2 * H, g.gsb, 2 * H, nullptr, nullptr, BG_ACT_NONE, 0.f,
+                                   nullptr, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
+            }
+            BG_TRY(bg_spmm_add_f32(g.gsb + H, 2 * H, p->sb_rowptr, p->sb_col, p->sb_count, BG_SCALE_DIV, nullptr, BG_SCALE_NONE,
+                                   g.gsb, 2 * H, nullptr, 0, nullptr, 0, nullptr, nullptr, BG_SCALE_NONE, g.g_story, H, S, H, s));
+            BG_TRY(bg_spmm_add_f32(g.gx + H, 2 * H, bp->vt_rowptr, bp->vt_col, nullptr, BG_SCALE_NONE, p->vx_count, BG_SCALE_DIV,
+                                   gin, H, g.gx, 2 * H, g.g_story, H, p->story_of_voxel, p->st_count, BG_SCALE_DIV, gout, H, Nv,
+                                   H, s));
+            have_blk = true;
+        }
+        gin = gout;
+    }
+    // encoder and NN_p
+    {
+        const float* Bs[4] = {voxel_in, nullptr, nullptr, nullptr};
+        const int64_t ldb[4] = {4, 0, 0, 0}, Ns[4] = {4, 0, 0, 0};
+        BG_TRY(tn_multi(H, Nv, gin, 1, Bs, ldb, Ns, g_enc_w, g.splitk, 0, s));
+        BG_TRY(bg_colsum_f32(gin, H, Nv, H, g.colsum, colsum_blocks(Nv), g_enc_b, 0, s));
+        Bs[0] = x;
+        const int64_t ldx[4] = {H, 0, 0, 0}, Nx[4] = {H, 0, 0, 0};
+        BG_TRY(tn_multi(H, Np, g.gb_acc, 1, Bs, ldx, Nx, g_nnp_w, g.splitk, 0, s));
+        BG_TRY(bg_colsum_f32(g.gb_acc, H, Np, H, g.colsum, colsum_blocks(Np), g_nnp_b, 0, s));
+        const float* A[4] = {g.gb_acc, nullptr, nullptr, nullptr};
+        const int64_t ld[4] = {H, 0, 0, 0}, Ks[4] = {H, 0, 0, 0};
+        BG_TRY(bg_gemm_f32(0, 0, Np, H, 1, A, ld, Ks, w->nnp_w, H, g_x, H, nullptr, nullptr, BG_ACT_NONE, 0.f, nullptr, 0,
+                           nullptr, 0, nullptr, have_np ? g.gx_acc : nullptr, have_np ? H : 0, nullptr, 0, s));
+    }
     return BG_OK;
 }

@@ -167,21 +167,28 @@ __global__ __launch_bounds__(256) void k_rowsort_long(const int32_t* __restrict_
     d_rowsort_long(rowptr, perm, flags, worklist);
 }
 
-__device__ __forceinline__ void d_fill_col(const int64_t* __restrict__ other, const int32_t* __restrict__ perm, int64_t E,
-                                           int32_t* __restrict__ col, int32_t* __restrict__ flags) {
+// Slots [0, rowptr[N]) hold the edges whose key is in range; with out-of-range keys (reported in flags[0]; the caller
+// rejects the plan) the slots behind them were never placed: they get defined values instead of being read as indices.
+__device__ __forceinline__ void d_fill_col(const int64_t* __restrict__ other, int32_t* __restrict__ perm, int64_t E,
+                                           int32_t* __restrict__ col, int32_t* __restrict__ flags,
+                                           const int32_t* __restrict__ rowptr, int64_t N) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t valid = rowptr[N];
     int moved = 0;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < E; k += stride) {
+        if (k >= valid) { perm[k] = 0; col[k] = 0; continue; }
         int32_t p = perm[k];
+        if ((uint32_t)p >= (uint64_t)E) { col[k] = 0; continue; }          // (cannot happen for placed slots)
         col[k] = other ? (int32_t)other[p] : p;
         moved += (p != (int32_t)k);
     }
     if (moved) atomicAdd(&flags[1], moved);
 }
 
-__global__ void k_fill_col(const int64_t* __restrict__ other, const int32_t* __restrict__ perm, int64_t E,
-                           int32_t* __restrict__ col, int32_t* __restrict__ flags) {
-    d_fill_col(other, perm, E, col, flags);
+__global__ void k_fill_col(const int64_t* __restrict__ other, int32_t* __restrict__ perm, int64_t E,
+                           int32_t* __restrict__ col, int32_t* __restrict__ flags, const int32_t* __restrict__ rowptr,
+                           int64_t N) {
+    d_fill_col(other, perm, E, col, flags, rowptr, N);
 }
 
 // ---- the same six steps for up to kMaxBuilds CSR builds at once: blockIdx.y = the build
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256) void k_rowsort_long_b(CsrJobs J) {
 }
 __global__ void k_fill_col_b(CsrJobs J) {
     const CsrJob& j = J.j[blockIdx.y];
-    d_fill_col(j.other, j.perm, j.E, j.col, j.flags);
+    d_fill_col(j.other, j.perm, j.E, j.col, j.flags, j.rowptr, j.N);
 }
 
 __global__ void k_segptr(const int64_t* __restrict__ seg, int64_t n, int64_t nseg,
@@ -475,7 +482,7 @@ int bg_plan_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N,
         BG_LAUNCH_CHECK();
         k_rowsort_long<<<512, 256, 0, s>>>(rowptr, perm, flags, cursor);
         BG_LAUNCH_CHECK();
-        k_fill_col<<<bg_grid_for(E, 256, 2048), 256, 0, s>>>(other, perm, E, col, flags);
+        k_fill_col<<<bg_grid_for(E, 256, 2048), 256, 0, s>>>(other, perm, E, col, flags, rowptr, N);
         BG_LAUNCH_CHECK();
     }
     return BG_OK;

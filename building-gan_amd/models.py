@@ -39,6 +39,7 @@ FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is
 FUSE_POS_TERM = True      # generator: position columns x weight + bias once per forward, the 12 products start from it
 FUSE_COEF_INPUTS = True   # collapsed discriminator: the recurrence's parameter rows by one launch (ops.PolyCoefD)
 FUSE_GENERATOR_FORWARD = True   # graph-free Generator.forward as ONE host call (bg_generator_forward_f32)
+FUSE_GSTACK = True        # generator update: VoxelGNN_G below the program GNN as ONE autograd node, one host call each way (ops.VoxelStackG)
 FUSE_CRITIC_HEAD = True   # WGAN-GP critic update below the coefficient table as ONE host call each way (ops.CriticHead)
 COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
 
@@ -375,6 +376,23 @@ class VoxelGNN_G(nn.Module):
         Wcat, bcat = self.attention.stacked_weights()
         return [Wc, bc, Wsb, Wcat, bcat]
 
+    def _one_node_ok(self, x, v, plan) -> bool:
+        """ops.VoxelStackG applies: the conditions of ops.GBlock / ops.AttentionNode with the position term taken once,
+        and plan pieces the one-call backward can run (bg_gstack_backward_f32)."""
+        H = x.shape[1]
+        o = plan.ops
+        if not (FUSE_GSTACK and torch.is_grad_enabled() and x.is_cuda and COMPOSE_BLOCKS and FUSE_GBLOCK and FUSE_ATTENTION_NODE
+                and FUSE_POS_TERM and SHARE_WEIGHT_GRADS and PDM4_PAD == 1.0 and self.noise_dim == 0 and len(self.enc) == 1
+                and self.block.if_agg_story_in_update and plan.vox_all_has and self.layer_num >= 1
+                and H % 64 == 0 and H <= 256 and 0 < plan.Nv <= FUSE_GATHER_STORY_MAX_ROWS and plan.Np > 0
+                and 0 < plan.cross_v.max_len <= 64 and "story_building_mean" in o and "prog_pair" in o
+                and o["max_level"] < self.pe.shape[0] and v.shape[1] == 4 and v.dtype == torch.float32):
+            return False
+        st, cp = plan.story_seg, plan.cross_p
+        if st.nnz != plan.Nv or st.count is None or plan.cross_v.col is None:
+            return False
+        return cp.row_per_workgroup or not cp.long_rows          # (two-phase reductions stay on the op-by-op path)
+
     def forward(self, x, v, z, plan, noise: Optional[Sequence] = None, derived=None):
         n_calls = 1 + sum(1 for i in range(self.layer_num) if i % 2 == 0 and i != 0)
         if noise is None:
@@ -383,9 +401,21 @@ class VoxelGNN_G(nn.Module):
             flat = torch.empty(n_calls * per, dtype=torch.float32, device=v.device).exponential_()
             noise = [(flat[c * per:c * per + 2 * plan.Nv].view(plan.Nv, 2),
                       flat[c * per + 2 * plan.Nv:c * per + 2 * plan.Nv + plan.Ec]) for c in range(n_calls)]
-        draws = iter(noise)
         pos, v = extract_pos(v)
         pdm4 = _pos_terms(plan, pos)
+        if self._one_node_ok(x, v, plan):
+            # a graph is being built (generator update): everything below the program GNN is ONE autograd node whose
+            # forward and backward are one host call each
+            att = self.attention
+            Wc, bc, Wsb = tuple(derived[:3]) if derived is not None else self.block.compose()
+            Wcat, bcat = (derived[3], derived[4]) if (derived is not None and derived[3] is not None) else att.stacked_weights()
+            if Wcat is not None:
+                _generator_plan_struct(plan)
+                ms, mh, as_, ah = ops.VoxelStackG.apply(x, self.enc[0].weight, self.enc[0].bias, att.NN_p.weight, att.NN_p.bias,
+                                                        Wcat, bcat, att.theta, Wc, bc, Wsb, self.pe, v, pdm4, noise, plan,
+                                                        self.layer_num)
+                return {"hard": mh, "soft": ms}, {"hard": ah.view(-1, 1), "soft": as_.view(-1, 1)}, None
+        draws = iter(noise)
         enc = self.enc[0]                       # pe[level] rides in the encoder product's epilogue (gathered addend)
         v = linear(torch.cat((v, z), dim=-1) if self.noise_dim != 0 else v, enc.weight, enc.bias,
                    pre_add=self.pe, pre_gather=_level_op(plan, self.pe.shape[0]))
@@ -592,6 +622,24 @@ class VoxelGNN_D(nn.Module):
         return v
 
 
+def _generator_plan_struct(plan):
+    """include/bgan.h bgGeneratorPlan of a plan (kept on the plan: it only holds addresses of the plan's own tensors)."""
+    from . import _lib
+    ops_ = plan.ops
+    ps = ops_.get("_generator_plan_struct")
+    if ps is None:
+        pp, vx, st, sb, cx = (ops_["prog_pair"], plan.vox_mean, plan.story_seg, ops_["story_building_mean"], plan.cross_v)
+        P = _lib.ptr
+        ps = _lib.GeneratorPlan(plan.Np, plan.Nv, plan.S, plan.Ec, cx.max_len, 1,
+                                P(pp.csr.rowptr), P(pp.csr.col), P(pp.row_scale), P(plan.prog_has),
+                                P(vx.csr.rowptr), P(vx.csr.col), P(vx.row_scale),
+                                P(st.rowptr), P(st.col), P(st.count), P(plan.story_gather.csr.col),
+                                P(sb.csr.rowptr), P(sb.csr.col), P(sb.row_scale), P(plan.level),
+                                P(cx.rowptr), P(cx.col))
+        ops_["_generator_plan_struct"] = ps
+    return ps
+
+
 class Generator(nn.Module):
     def __init__(self, program_input_dim, voxel_input_dim, hidden_dim, noise_dim, program_layer, voxel_layer,
                  device=None, max_len: int = 20):
@@ -649,17 +697,7 @@ class Generator(nn.Module):
                 raise _lib.BganError("generator: noise must hold one ([Nv, 2], [Ec]) pair per Attention call")
             em_ptrs, ea_ptrs = [a.data_ptr() for a, _ in keep], [b.data_ptr() for _, b in keep]
         lib = _lib.load()
-        ps = ops_.get("_generator_plan_struct")
-        if ps is None:
-            pp, vx, st, sb, cx = (ops_["prog_pair"], plan.vox_mean, plan.story_seg, ops_["story_building_mean"], plan.cross_v)
-            P = _lib.ptr
-            ps = _lib.GeneratorPlan(plan.Np, Nv, plan.S, Ec, cx.max_len, 1,
-                                    P(pp.csr.rowptr), P(pp.csr.col), P(pp.row_scale), P(plan.prog_has),
-                                    P(vx.csr.rowptr), P(vx.csr.col), P(vx.row_scale),
-                                    P(st.rowptr), P(st.col), P(st.count), P(plan.story_gather.csr.col),
-                                    P(sb.csr.rowptr), P(sb.csr.col), P(sb.row_scale), P(plan.level),
-                                    P(cx.rowptr), P(cx.col))
-            ops_["_generator_plan_struct"] = ps
+        ps = _generator_plan_struct(plan)
         penc, venc, blk = pg.enc[0], gnn.enc[0], pg.block
         tensors = [penc.weight, penc.bias, blk.messageMLP[0].weight, blk.messageMLP[0].bias, blk.updateMLP[0].weight,
                    blk.updateMLP[0].bias, venc.weight, venc.bias, gnn.pe, Wc, bc, Wsb, Wcat, bcat, att.NN_p.weight,

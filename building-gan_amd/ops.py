@@ -1309,6 +1309,83 @@ class CriticLoss(torch.autograd.Function):
         return db, ds, dg, None, None, None
 
 
+class VoxelStackG(torch.autograd.Function):
+    """VoxelGNN_G.forward below the program GNN -- encoder, NN_p(x), every Attention and VoxelBlock call -- as ONE
+    autograd node whose forward and backward are one host call each (bg_gstack_forward_f32 / _backward_f32: the
+    launches of ops.AttentionNode / ops.GBlock and their hand-written backward, issued from C++; every call's input,
+    neighbour mean and activation stay in one workspace).  First-order autograd.
+
+    Differentiable inputs: x [Np, H], enc_w [H, 4], enc_b, nnp_w, nnp_b, Wcat [H+4, H], bcat, theta, Wc [H, 2H+4],
+    bc, Wsb.  Returns the last Attention call's (mask soft [Nv,1], mask hard, pointer soft [Ec], pointer hard)."""
+
+    @staticmethod
+    def forward(ctx, x, enc_w, enc_b, nnp_w, nnp_b, Wcat, bcat, theta, Wc, bc, Wsb, pe, v4, pdm4, noise, plan, L: int):
+        lib = _lib.load()
+        _lib.require_device(x, "voxel_stack")
+        H = x.shape[1]
+        Np, Nv, S, Ec = plan.Np, plan.Nv, plan.S, plan.Ec
+        dev = x.device
+        x, v4, pdm4 = _f32c(x).contiguous(), _f32c(v4).contiguous(), _f32c(pdm4).contiguous()
+        ts = [enc_w, enc_b, nnp_w, nnp_b, Wcat, bcat, theta, bc, Wsb, pe]
+        ts = [t.contiguous() for t in ts]
+        enc_w, enc_b, nnp_w, nnp_b, Wcat, bcat, theta, bc, Wsb, pe = ts
+        if Wc.stride(1) != 1:
+            Wc = Wc.contiguous()
+        n_calls = 1 + sum(1 for i in range(L) if i % 2 == 0 and i != 0)
+        keep = [(_f32c(a).contiguous(), _f32c(b.reshape(-1)).contiguous()) for a, b in list(noise)[:n_calls]]
+        if len(keep) != n_calls or any(tuple(a.shape) != (Nv, 2) or b.numel() != Ec for a, b in keep):
+            raise _lib.BganError("voxel_stack: noise must hold one ([Nv, 2], [Ec]) pair per Attention call")
+        PA = C.c_void_p * n_calls
+        em, ea = PA(*[a.data_ptr() for a, _ in keep]), PA(*[b.data_ptr() for _, b in keep])
+        ws = _lib.GeneratorWeights(H, 0, 0, L, 1, pe.shape[0], None, None, None, None, None, None, ptr(enc_w), ptr(enc_b),
+                                   ptr(pe), ptr(Wc), Wc.stride(0), ptr(bc), ptr(Wsb), ptr(Wcat), ptr(bcat), ptr(nnp_w),
+                                   ptr(nnp_b), ptr(theta))
+        ps = plan.ops.get("_generator_plan_struct")
+        if ps is None:
+            raise _lib.BganError("voxel_stack: the plan carries no bgGeneratorPlan (models._generator_plan_struct)")
+        n_ws = int(lib.bg_gstack_workspace(Np, Nv, S, Ec, H, L))
+        if n_ws < 0:
+            raise _lib.BganError("voxel_stack: sizes not supported")
+        work = torch.empty(n_ws, dtype=torch.float32, device=dev)
+        mask_hard = torch.empty(Nv, 1, dtype=torch.float32, device=dev)
+        mask_soft = torch.empty(Nv, 1, dtype=torch.float32, device=dev)
+        att_hard = torch.empty(Ec, dtype=torch.float32, device=dev)
+        att_soft = torch.empty(Ec, dtype=torch.float32, device=dev)
+        check(lib.bg_gstack_forward_f32(C.byref(ws), C.byref(ps), ptr(x), ptr(v4), ptr(pdm4), em, ea, n_calls, ptr(work), n_ws,
+                                        ptr(mask_hard), ptr(mask_soft), ptr(att_hard), ptr(att_soft), stream()),
+              "bg_gstack_forward_f32")
+        ctx.ws, ctx.ps, ctx.work, ctx.n_ws, ctx.n_calls, ctx.plan = ws, ps, work, n_ws, n_calls, plan
+        ctx.keep = (x, v4, pdm4, ts, Wc, mask_soft, att_soft)
+        ctx.set_materialize_grads(False)
+        return mask_soft, mask_hard, att_soft, att_hard
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_ms, g_mh, g_as, g_ah):
+        lib = _lib.load()
+        x, v4, pdm4, ts, Wc, mask_soft, att_soft = ctx.keep
+        enc_w, enc_b, nnp_w, nnp_b, Wcat, bcat, theta, bc, Wsb, pe = ts
+        plan = ctx.plan
+        H = x.shape[1]
+        dev = x.device
+        cp, vt = plan.cross_p, plan.vox_mean.T.csr
+        bp = _lib.GeneratorBackPlan(ptr(vt.rowptr), ptr(vt.col), ptr(cp.rowptr), ptr(cp.col), ptr(cp.perm),
+                                    1 if cp.row_per_workgroup else 0)
+        cont = lambda t: _f32c(t).reshape(-1).contiguous() if t is not None else None
+        g_ms, g_mh, g_as, g_ah = cont(g_ms), cont(g_mh), cont(g_as), cont(g_ah)
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        g_x, g_enc_w, g_enc_b, g_nnp_w, g_nnp_b = new(x.shape), new(enc_w.shape), new(enc_b.shape), new(nnp_w.shape), new(nnp_b.shape)
+        g_Wcat, g_bcat, g_theta, g_Wc, g_Wsb = new(Wcat.shape), new(bcat.shape), new(theta.shape), new(H, 2 * H + 4), new(Wsb.shape)
+        check(lib.bg_gstack_backward_f32(C.byref(ctx.ws), C.byref(ctx.ps), C.byref(bp), ptr(x), ptr(v4), ptr(pdm4), ctx.n_calls,
+                                         ptr(ctx.work), ctx.n_ws, ptr(mask_soft), ptr(att_soft), ptr(g_mh), ptr(g_ms),
+                                         ptr(g_ah), ptr(g_as), ptr(g_x), ptr(g_enc_w), ptr(g_enc_b), ptr(g_nnp_w),
+                                         ptr(g_nnp_b), ptr(g_Wcat), ptr(g_bcat), ptr(g_theta), ptr(g_Wc), ptr(g_Wsb),
+                                         stream()), "bg_gstack_backward_f32")
+        ctx.work = None
+        return (g_x, g_enc_w, g_enc_b, g_nnp_w, g_nnp_b, g_Wcat, g_bcat, g_theta, g_Wc, g_Wc[:, -1], g_Wsb,
+                None, None, None, None, None, None)
+
+
 class CriticHead(torch.autograd.Function):
     """One WGAN-GP critic update below the collapsed GNN's coefficient table as ONE host call each way
     (bg_critic_head_forward_f32 / _backward_f32: what DiscriminatorVoxel.critic_terms + CriticLoss launch op by op --

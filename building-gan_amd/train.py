@@ -213,12 +213,21 @@ class Trainer:
                 + F.relu(fake_b + 1.0).sum() / Bg + F.relu(fake_s + 1.0).sum() / Sg)          # hinge
 
     def _critic_weights(self, B, S, Bg, Sg, dev):
+        # a stream of batches brings a handful of (B, S) pairs over and over: kept per pair, and made on the device
+        # (two fills each: a host-made vector would cost a blocking copy in the middle of the iteration)
         key = (B, S, Bg, Sg)
-        if self._cw_cache is None or self._cw_cache[0] != key:
-            wb = torch.cat([torch.full((B,), -1.0 / Bg), torch.full((B,), 1.0 / Bg)]).to(dev)
-            ws = torch.cat([torch.full((S,), -1.0 / Sg), torch.full((S,), 1.0 / Sg)]).to(dev)
-            self._cw_cache = (key, wb, ws)
-        return self._cw_cache[1], self._cw_cache[2]
+        if self._cw_cache is None:
+            self._cw_cache = {}
+        hit = self._cw_cache.get(key)
+        if hit is None:
+            if len(self._cw_cache) >= 256:
+                self._cw_cache.clear()
+            wb = torch.full((2 * B,), 1.0 / Bg, dtype=torch.float32, device=dev)
+            wb[:B] = -1.0 / Bg
+            ws = torch.full((2 * S,), 1.0 / Sg, dtype=torch.float32, device=dev)
+            ws[:S] = -1.0 / Sg
+            hit = self._cw_cache[key] = (wb, ws)
+        return hit
 
     def _g_adversarial(self, val_b, val_s, Bg, Sg):
         gl = self.gan_loss

@@ -531,6 +531,43 @@ int bg_d_coef_backward_f32(const float* g, const float* xall, const float* Wc, i
                            float* partial, float* gW, float* g_bc, float* g_fe_w, float* g_fe_b, float* g_le_w,
                            float* g_le_b, bgStream stream);
 
+/* ---- the generator's voxel GNN with a backward: forward that keeps what the backward reads, and the backward ----
+ * Plan pieces only the backward reads (besides bgGeneratorPlan).                                                  */
+typedef struct {
+    const int32_t *vt_rowptr, *vt_col;               /* voxel edges by source: A^T = P^T diag(1 / vx_count)          */
+    const int32_t *cp_rowptr, *cp_col, *cp_perm;     /* cross edges by program node (slots -> voxel, slot -> edge id) */
+    int64_t cp_one_launch;                           /* != 0: those rows are long: one workgroup per row
+                                                        (bg_segreduce_sum_f32 without a chunk table), else bg_spmm_f32 */
+} bgGeneratorBackPlan;
+
+/* Floats of workspace shared by bg_gstack_forward_f32 and bg_gstack_backward_f32 of one pass (the forward leaves
+ * every call's input, aggregate and activation in it).                                                          */
+int64_t bg_gstack_workspace(int64_t Np, int64_t Nv, int64_t S, int64_t Ec, int64_t H, int64_t L);
+
+/* VoxelGNN_G.forward (Model/models.py:185-203) from the program features x [Np, H] on -- encoder + pe[level],
+ * NN_p(x), then Attention / VoxelBlock calls in the reference's order -- as ONE host call that keeps every call's
+ * input, neighbour mean, activation, NN_v product, soft mask and soft pointer in the workspace.  The same launches
+ * as ops.GBlock / ops.AttentionNode issue one by one (bit-identical).  Outputs: the last Attention call's mask and
+ * pointer.  Uses w's v_enc_*, pe, Wc / bc / Wsb, Wcat / bcat, nnp_*, theta (the program GNN's fields are not read).
+ * Limits as bg_generator_forward_f32.                                                                            */
+int bg_gstack_forward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan* p, const float* x, const float* voxel_in,
+                          const float* pdm4, const float* const* exp_mask, const float* const* exp_att, int64_t n_calls,
+                          float* workspace, int64_t workspace_floats,
+                          float* mask_hard, float* mask_soft, float* att_hard, float* att_soft, bgStream stream);
+
+/* Its backward for the gradients arriving at the four outputs (any may be NULL): every weight gradient summed over
+ * the calls inside the weight-gradient launches (accumulate), in backward order.  Writes g_x [Np, H], g_enc_w [H, 4],
+ * g_enc_b [H], g_nnp_w [H, H], g_nnp_b [H], g_Wcat [H + 4, H], g_bcat [H + 4], g_theta [H], g_Wc [H, 2H + 4]
+ * (contiguous; its last column is the gradient of bc: pdm4's pad column is 1), g_Wsb [H, 2H].
+ * replaces: g_loss.backward() below the program GNN, train.py:112 (autograd over Model/models.py:185-203).        */
+int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan* p, const bgGeneratorBackPlan* bp,
+                           const float* x, const float* voxel_in, const float* pdm4, int64_t n_calls,
+                           float* workspace, int64_t workspace_floats,
+                           const float* mask_soft, const float* att_soft,
+                           const float* g_mask_hard, const float* g_mask_soft, const float* g_att_hard, const float* g_att_soft,
+                           float* g_x, float* g_enc_w, float* g_enc_b, float* g_nnp_w, float* g_nnp_b, float* g_Wcat,
+                           float* g_bcat, float* g_theta, float* g_Wc, float* g_Wsb, bgStream stream);
+
 /* src [n, K, P, W] -> dst [P, n, K, W] (to_outer != 0) or src [P, n, K, W] -> dst [n, K, P, W] (to_outer == 0):
  * column groups that several label sets / both critic outputs share in one operator chain, regrouped into one
  * contiguous matrix per set for the products on either side.  W % 4 == 0, 16-byte aligned, contiguous.

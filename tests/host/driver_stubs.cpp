@@ -140,6 +140,44 @@ int bg_add_f32(const float* x, const float* y, float* out, int64_t n, bgStream) 
     rec(18, a, sizeof(a) / 8);
     return 0;
 }
+int bg_story_bwd_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, const float* v, int64_t ldv,
+                     const int32_t* rowptr, const int32_t* col, const float* count, float, float* gz, int64_t ldz,
+                     float* gterm, int64_t ldt, float* story, int64_t lds, int64_t n_story, int64_t H, bgStream) {
+    int64_t a[] = {P(g), ldg, P(y), ldy, P(v), ldv, P(rowptr), P(col), P(count), P(gz), ldz, P(gterm), ldt, P(story), lds,
+                   n_story, H};
+    rec(21, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_attention_bwd_head_f32(const float* g_out, int64_t ldg, const float* x, int64_t ldx, const float* soft0,
+                              const float* soft, const int32_t* rowptr, const int32_t* col, const float* g_soft,
+                              const float* g_hard, const float* g_soft0, const float* g_hard0, float, float* gg, int64_t ldgg,
+                              float* d_att, float* d_mask, int64_t ldd, int64_t n_vox, int64_t H, bgStream) {
+    int64_t a[] = {P(g_out), ldg, P(x), ldx, P(soft0), P(soft), P(rowptr), P(col), P(g_soft), P(g_hard), P(g_soft0),
+                   P(g_hard0), P(gg), ldgg, P(d_att), P(d_mask), ldd, n_vox, H};
+    rec(22, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_cross_logits_bwd_f32(const float* a_, int64_t lda, const float* b, int64_t ldb, const float* theta,
+                            const int32_t* rowptr, const int32_t* col, const float* g, float* dpre, float* da, int64_t ldda,
+                            float* dtheta_partial, int32_t n_blocks, int64_t n_vox, int64_t H, bgStream) {
+    int64_t a[] = {P(a_), lda, P(b), ldb, P(theta), P(rowptr), P(col), P(g), P(dpre), P(da), ldda, P(dtheta_partial),
+                   n_blocks, n_vox, H};
+    rec(23, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_segreduce_sum_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* edge_w,
+                         const int32_t* eperm, const float* row_scale, int row_mode, const int32_t* chunk_ptr, int32_t,
+                         int64_t, float* partial, float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream) {
+    int64_t a[] = {P(x), ldx, P(rowptr), P(col), P(edge_w), P(eperm), P(row_scale), row_mode, P(chunk_ptr), P(partial), P(out),
+                   ldo, n_rows, H};
+    rec(24, a, sizeof(a) / 8);
+    return 0;
+}
+int hipMemsetAsync(void* dst, int value, size_t bytes, void*) {
+    int64_t a[] = {P(dst), value, (int64_t)bytes};
+    rec(25, a, sizeof(a) / 8);
+    return 0;
+}
 // the one HIP runtime call the critic composites make themselves (a strided device-to-device copy)
 int hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int, void*) {
     int64_t a[] = {P(dst), (int64_t)dpitch, P(src), (int64_t)spitch, (int64_t)width, (int64_t)height};

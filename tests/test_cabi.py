@@ -26,7 +26,7 @@ def test_python_binding_covers_the_header():
     from building_gan_amd import _lib
     # (functions that do not return an int status are bound by hand in _lib.load())
     declared = set(_declared()) - {"bg_version", "bg_error_string", "bg_abi_sizeof", "bg_generator_forward_workspace",
-                                    "bg_d_coef_backward_workspace", "bg_critic_head_workspace"}
+                                    "bg_d_coef_backward_workspace", "bg_critic_head_workspace", "bg_gstack_workspace"}
     assert declared == set(_lib.SIGNATURES.keys())
     lib = _lib.load()
     assert lib.bg_version() >= 1
@@ -36,6 +36,7 @@ def test_python_binding_covers_the_header():
     assert lib.bg_abi_sizeof(1) == ctypes.sizeof(_lib.GeneratorPlan) and lib.bg_abi_sizeof(7) == -1
     assert lib.bg_abi_sizeof(2) == ctypes.sizeof(_lib.PlanIn)
     assert lib.bg_abi_sizeof(3) == ctypes.sizeof(_lib.CriticHead)
+    assert lib.bg_abi_sizeof(4) == ctypes.sizeof(_lib.GeneratorBackPlan)
 
 
 def test_plan_piece_enums_match_the_header():

@@ -494,3 +494,241 @@ def test_critic_head_rejects_unsupported_sizes(drv):
     assert _critic_run(drv, 100, 10, 2, ds=30)[0] == -1          # workspace query: widths must be multiples of 4
     rc, *_ = _critic_run(drv, 100, 10, 2, L=0)
     assert rc == -1
+
+
+# ------------------------------------------------------------------------------------ generator stack (bg_gstack_*)
+def _gstack_run(lib, Np, Nv, S, Ec, H=128, L=12, one_launch=1):
+    import sys
+    sys.path.insert(0, ROOT)
+    from building_gan_amd._lib import GeneratorBackPlan, GeneratorPlan, GeneratorWeights
+    R = Ranges()
+    f = 4
+    ldwc = 2 * H + 4
+    w = GeneratorWeights(H, 0, 0, L, 1, 20, None, None, None, None, None, None,
+                         R.new("v_enc_w", H * 4 * f), R.new("v_enc_b", H * f), R.new("pe", 20 * H * f),
+                         R.new("Wc", H * ldwc * f), ldwc, R.new("bc", H * f), R.new("Wsb", H * 2 * H * f),
+                         R.new("Wcat", (H + 4) * H * f), R.new("bcat", (H + 4) * f), R.new("nnp_w", H * H * f),
+                         R.new("nnp_b", H * f), R.new("theta", H * f))
+    Ev, nnz_sb = 6 * Nv, 3 * S
+    p = GeneratorPlan(Np, Nv, S, Ec, 4, 1, None, None, None, None,
+                      R.new("vx_rowptr", (Nv + 1) * 4), R.new("vx_col", Ev * 4), R.new("vx_count", Nv * f),
+                      R.new("st_rowptr", (S + 1) * 4), R.new("st_col", Nv * 4), R.new("st_count", S * f),
+                      R.new("story_of_voxel", Nv * 4), R.new("sb_rowptr", (S + 1) * 4), R.new("sb_col", nnz_sb * 4),
+                      R.new("sb_count", S * f), R.new("level", Nv * 4), R.new("cx_rowptr", (Nv + 1) * 4), R.new("cx_col", Ec * 4))
+    bp = GeneratorBackPlan(R.new("vt_rowptr", (Nv + 1) * 4), R.new("vt_col", Ev * 4), R.new("cp_rowptr", (Np + 1) * 4),
+                           R.new("cp_col", Ec * 4), R.new("cp_perm", Ec * 4), one_launch)
+    n_calls = 1 + (L - 1) // 2
+    PA = C.c_void_p * n_calls
+    em = PA(*[R.new("exp_mask%d" % c, Nv * 2 * f) for c in range(n_calls)])
+    ea = PA(*[R.new("exp_att%d" % c, Ec * f) for c in range(n_calls)])
+    lib.bg_gstack_workspace.restype = C.c_int64
+    lib.bg_gstack_workspace.argtypes = [C.c_int64] * 6
+    nws = lib.bg_gstack_workspace(Np, Nv, S, Ec, H, L)
+    assert nws > 0
+    work = R.new("workspace", nws * f)
+    x, v4, pdm4 = R.new("x", Np * H * f), R.new("voxel_in", Nv * 4 * f), R.new("pdm4", Nv * 4 * f)
+    outs = [R.new("mask_hard", Nv * f), R.new("mask_soft", Nv * f), R.new("att_hard", Ec * f), R.new("att_soft", Ec * f)]
+    lib.bg_gstack_forward_f32.argtypes = [C.c_void_p] * 7 + [C.c_int64, C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+    lib.bg_gstack_backward_f32.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_void_p, C.c_int64] + [C.c_void_p] * 17
+
+    def calls_of(fn, *args):
+        lib.stub_reset()
+        rc = fn(*args)
+        return rc, [(lib.stub_call(i)[0], [lib.stub_call(i)[2 + k] for k in range(lib.stub_call(i)[1])])
+                    for i in range(lib.stub_count())]
+    rc_f, fwd = calls_of(lib.bg_gstack_forward_f32, C.byref(w), C.byref(p), x, v4, pdm4, em, ea, n_calls, work, nws, *outs, None)
+    gin = [R.new("g_mask_hard", Nv * f), R.new("g_mask_soft", Nv * f), R.new("g_att_hard", Ec * f), R.new("g_att_soft", Ec * f)]
+    gout = [R.new("g_x", Np * H * f), R.new("g_enc_w", H * 4 * f), R.new("g_enc_b", H * f), R.new("g_nnp_w", H * H * f),
+            R.new("g_nnp_b", H * f), R.new("g_Wcat", (H + 4) * H * f), R.new("g_bcat", (H + 4) * f), R.new("g_theta", H * f),
+            R.new("g_Wc", H * ldwc * f), R.new("g_Wsb", H * 2 * H * f)]
+    rc_b, bwd = calls_of(lib.bg_gstack_backward_f32, C.byref(w), C.byref(p), C.byref(bp), x, v4, pdm4, n_calls, work, nws,
+                         outs[1], outs[3], *gin, *gout, None)
+    return (rc_f, rc_b), fwd, bwd, R, dict(Np=Np, Nv=Nv, S=S, Ec=Ec, H=H, L=L)
+
+
+def _check_generic(calls, R, z):
+    """Pointer + extent of every operand of every launcher call lies inside one buffer."""
+    f = 4
+    Np, Nv, S, Ec, H = z["Np"], z["Nv"], z["S"], z["Ec"], z["H"]
+    rows_under = {"vx_rowptr": Nv, "vt_rowptr": Nv, "st_rowptr": S, "sb_rowptr": S, "cx_rowptr": Nv, "cp_rowptr": Np}
+    cols_of = {"vx_rowptr": Nv, "vt_rowptr": Nv, "sb_rowptr": S, "cp_rowptr": None}
+    for ci, (kind, a) in enumerate(calls):
+        tag = "call %d kind %d" % (ci, kind)
+        if kind == 1:
+            (tA, tB, M, Nn, n_seg), A, lda, Ks = a[0:5], a[5:9], a[9:13], a[13:17]
+            Bp, ldb, Cp, ldc, bias, rs, act, res, ldr, pre, ldp, rows, acc, ldacc, pro, ldpro = a[17:33]
+            assert tA == 0
+            K = sum(Ks[:n_seg])
+            for sgm in range(n_seg):
+                assert lda[sgm] >= Ks[sgm]
+                R.check(A[sgm], ((M - 1) * lda[sgm] + Ks[sgm]) * f, tag + " A%d" % sgm)
+                assert A[sgm] != Cp
+            if tB:
+                assert ldb >= K
+                R.check(Bp, ((Nn - 1) * ldb + K) * f, tag + " B [N,K]")
+            else:
+                assert ldb >= Nn
+                R.check(Bp, ((K - 1) * ldb + Nn) * f, tag + " B [K,N]")
+            R.check(Cp, ((M - 1) * ldc + Nn) * f, tag + " C")
+            if bias:
+                R.check(bias, Nn * f, tag + " bias")
+            if res:
+                R.check(res, ((M - 1) * ldr + Nn) * f, tag + " residual")
+                assert res != Cp
+            if pre:
+                nrow = M if not rows else (S if R.check(rows, 4, "rows") == "story_of_voxel" else 20)
+                R.check(pre, ((nrow - 1) * ldp + Nn) * f, tag + " pre_add")
+            if rows:
+                R.check(rows, M * 4, tag + " pre_rows")
+            if acc:
+                R.check(acc, ((M - 1) * ldacc + Nn) * f, tag + " acc_init")
+                assert acc != Cp
+            if pro:
+                R.check(pro, ((M - 1) * ldpro + Nn) * f, tag + " pre_residual_out")
+                assert pro != Cp
+        elif kind in (2, 24):                               # spmm / segreduce: x [n_cols, H] gathered by col
+            if kind == 2:
+                x, ldx, rp, col, ew, ep, rsc, rm, csc, cm, out, ldo, n_rows, Hh = a
+            else:
+                x, ldx, rp, col, ew, ep, rsc, rm, chunk, part, out, ldo, n_rows, Hh = a
+                assert chunk == 0
+            name = R.check(rp, (n_rows + 1) * 4, tag + " rowptr")
+            assert rows_under[name] == n_rows
+            xr = Ec if name == "cp_rowptr" else cols_of[name]
+            R.check(x, ((xr - 1) * ldx + Hh) * f, tag + " x")
+            R.check(out, ((n_rows - 1) * ldo + Hh) * f, tag + " out")
+            if ew:
+                R.check(ew, Ec * f, tag + " edge_w")
+                R.check(ep, Ec * 4, tag + " eperm")
+            if rm:
+                R.check(rsc, n_rows * f, tag + " row_scale")
+            assert x != out
+        elif kind == 3:
+            x, ldx, rp, col, rsc, rm, csc, cm, a1, ld1, a2, ld2, ga, ldg, grow, gs, gm_, out, ldo, n_rows, Hh = a
+            name = R.check(rp, (n_rows + 1) * 4, tag + " rowptr")
+            assert rows_under[name] == n_rows
+            R.check(x, ((cols_of[name] - 1) * ldx + Hh) * f, tag + " x")
+            R.check(out, ((n_rows - 1) * ldo + Hh) * f, tag + " out")
+            for q, ldq in ((a1, ld1), (a2, ld2)):
+                if q:
+                    R.check(q, ((n_rows - 1) * ldq + Hh) * f, tag + " addend")
+                    assert q != out
+            if ga:
+                R.check(ga, ((S - 1) * ldg + Hh) * f, tag + " gathered addend")
+                R.check(grow, n_rows * 4, tag + " grow")
+                R.check(gs, S * f, tag + " gscale")
+            if rm:
+                R.check(rsc, n_rows * f, tag + " row_scale")
+            if cm:
+                R.check(csc, cols_of[name] * f, tag + " col_scale")
+        elif kind == 4:
+            x, ldx, rp, col, rsc, rm, gm, ldg, n_rows, srp, scol, scount, W, ldw, Hout, pq, ldq, n_story, Hh = a
+            R.check(x, ((n_rows - 1) * ldx + Hh) * f, tag + " x")
+            R.check(gm, ((n_rows - 1) * ldg + Hh) * f, tag + " gm")
+            R.check(pq, ((n_story - 1) * ldq + 2 * Hout) * f, tag + " pq")
+            assert x != gm and n_rows == Nv and n_story == S
+        elif kind == 5:
+            (a_, lda, lg, ldl, b, ldb, x, ldx, v, ldv, th, rp, col, em, ea, tau, s0, h0, so, ha, out, ldo, n, Hh, wd, ldwd, bd) = a
+            R.check(a_, ((n - 1) * lda + Hh) * f, tag + " a")
+            R.check(b, ((Np - 1) * ldb + Hh) * f, tag + " b")
+            R.check(x, ((Np - 1) * ldx + Hh) * f, tag + " x")
+            R.check(v, ((n - 1) * ldv + Hh) * f, tag + " v")
+            R.check(em, n * 2 * f, tag + " exp_mask")
+            R.check(ea, Ec * f, tag + " exp_att")
+            for q in (s0, h0):
+                R.check(q, n * f, tag + " mask out")
+            for q in (so, ha):
+                R.check(q, Ec * f, tag + " att out")
+            R.check(out, ((n - 1) * ldo + Hh) * f, tag + " out")
+            R.check(wd, (ldwd + Hh) * f, tag + " wd")
+            R.check(bd, 2 * f, tag + " bd")
+            assert out != v and out != a_ and n == Nv
+        elif kind == 17:
+            x, ldx, M, Nn, part, nb, out, accum = a
+            R.check(x, ((M - 1) * ldx + Nn) * f, tag + " x")
+            R.check(part, nb * Nn * f, tag + " partial")
+            R.check(out, Nn * f, tag + " out")
+        elif kind == 18:
+            x, y, out, n = a
+            for q in (x, y, out):
+                R.check(q, n * f, tag)
+        elif kind == 19:
+            M, Rr, A, lda, n_seg, B0, ldb0, N0, Cp, ldc, part, splits, accum = a
+            assert lda >= M and ldb0 >= N0 and ldc >= N0 and splits >= 1
+            R.check(A, ((Rr - 1) * lda + M) * f, tag + " A")
+            R.check(B0, ((Rr - 1) * ldb0 + N0) * f, tag + " B0")
+            R.check(Cp, ((M - 1) * ldc + ldc) * f, tag + " C")
+            R.check(part, splits * M * ldc * f, tag + " partial")
+        elif kind == 21:
+            g, ldg, y, ldy, v, ldv, rp, col, cnt, gz, ldz, gterm, ldt, story, lds, n_story, Hh = a
+            for q, ldq in ((g, ldg), (y, ldy), (v, ldv), (gz, ldz)):
+                R.check(q, ((Nv - 1) * ldq + Hh) * f, tag + " voxel operand")
+            for q, ldq in ((gterm, ldt), (story, lds)):
+                R.check(q, ((n_story - 1) * ldq + Hh) * f, tag + " story operand")
+            assert n_story == S and gz != g and gz != y and gz != v
+        elif kind == 22:
+            go, ldg, x, ldx, s0, so, rp, col, gs, gh, gs0, gh0, gg, ldgg, d_att, d_mask, ldd, n, Hh = a
+            R.check(go, ((n - 1) * ldg + Hh) * f, tag + " g_out")
+            R.check(x, ((Np - 1) * ldx + Hh) * f, tag + " x")
+            R.check(s0, n * f, tag + " soft0"); R.check(so, Ec * f, tag + " soft")
+            for q, m in ((gs, Ec), (gh, Ec), (gs0, n), (gh0, n)):
+                if q:
+                    R.check(q, m * f, tag + " incoming")
+            R.check(gg, ((n - 1) * ldgg + Hh) * f, tag + " gg")
+            R.check(d_att, Ec * f, tag + " d_att")
+            R.check(d_mask, ((n - 1) * ldd + 4) * f, tag + " d_mask")
+            assert n == Nv and gg != go
+        elif kind == 23:
+            a_, lda, b, ldb, th, rp, col, g, dpre, da, ldda, dthp, nb, n, Hh = a
+            R.check(a_, ((n - 1) * lda + Hh) * f, tag + " a")
+            R.check(b, ((Np - 1) * ldb + Hh) * f, tag + " b")
+            R.check(g, Ec * f, tag + " g")
+            R.check(dpre, Ec * Hh * f, tag + " dpre")
+            R.check(da, ((n - 1) * ldda + Hh) * f, tag + " da")
+            R.check(dthp, nb * Hh * f, tag + " dtheta partial")
+        elif kind == 25:
+            dst, val, nbytes = a
+            R.check(dst, nbytes, tag + " memset")
+        else:
+            raise AssertionError("unexpected launcher %d" % kind)
+
+
+@pytest.mark.parametrize("Np,Nv,S,Ec,one", [(320, 11520, 80, 46080, 1), (33, 1001, 9, 3999, 0), (7, 7, 5, 11, 0)])
+def test_gstack_host_sequence_and_extents(drv, Np, Nv, S, Ec, one):
+    (rc_f, rc_b), fwd, bwd, R, z = _gstack_run(drv, Np, Nv, S, Ec, one_launch=one)
+    assert rc_f == 0 and rc_b == 0
+    expect = [1, 1, 1] + [1, 5]
+    for i in range(11):
+        expect += [4, 3, 1] + ([1, 5] if (i % 2 == 0 and i != 0) else [])
+    assert [k for k, _ in fwd] == expect
+    _check_generic(fwd, R, z)
+    _check_generic(bwd, R, z)
+    red = 24 if one else 2
+    att_last = [22, 23, red, 17, 19, 17, 1]
+    att_first_np = [22, red, 23, red, 18, 17, 19, 17, 1]                  # first call that reaches x: assigns g_x's sum
+    att = [22, red, 18, 23, red, 18, 17, 19, 17, 1]
+    blk = [21, 19, 2, 19, 1, 1, 3, 3]
+    seq = [25] + att_last
+    n_att_seen = 1
+    for i in range(10, -1, -1):                                           # ops in reverse: ..., block i, (attention before it)
+        seq += blk
+        if i % 2 == 1 and i != 1 or i == 0:
+            pass
+        if (i - 1) % 2 == 0 and (i - 1) != 0 and i - 1 >= 0:             # an attention call follows block i-1
+            seq += att_first_np if n_att_seen == 1 else att
+            n_att_seen += 1
+    seq += (att_first_np if n_att_seen == 1 else att) + [19, 17, 19, 17, 1]
+    assert [k for k, _ in bwd] == seq
+    # the forward's saved pieces live in the workspace; the last call writes the caller's outputs
+    att_calls = [a for k, a in fwd if k == 5]
+    assert [R.check(a[16], 4, "s0") for a in att_calls] == ["workspace"] * 5 + ["mask_soft"]
+    # accumulate flags: each shared weight gradient is assigned once, then accumulated
+    flags = {}
+    for k, a in bwd:
+        if k == 19:
+            flags.setdefault(R.check(a[8], 4, "C"), []).append(a[12])
+        elif k == 17 and R.check(a[6], 4, "out") != "workspace":
+            flags.setdefault(R.check(a[6], 4, "out"), []).append(a[7])
+    assert flags["g_Wc"] == [0] + [1] * 10 and flags["g_Wsb"] == [0] + [1] * 10
+    assert flags["g_Wcat"] == [0] + [1] * 5 and flags["g_bcat"] == [0] + [1] * 5 and flags["g_theta"] == [0] + [1] * 5
+    assert flags["g_enc_w"] == [0] and flags["g_enc_b"] == [0] and flags["g_nnp_w"] == [0] and flags["g_nnp_b"] == [0]

@@ -117,6 +117,10 @@ def test_plan_in_one_host_call_reports_bad_indices(cuda, monkeypatch):
                          ("cross_edge_program_index_select", 10 ** 8), ("program_target_ratio_batch", 99)):
         g = _batch("small", 4, True).to(cuda)
         S = int(g.voxel_floor_cluster.max()) + 1
+        # the plan's arenas are torch.empty: make what the allocator hands back hold wild values, so that a slot the
+        # build leaves unwritten (edges with a bad key are never placed) would show if anything read it as an index
+        junk = torch.full((1 << 22,), 0x7f7f7f7f, dtype=torch.int32, device=cuda)
+        del junk
         t = getattr(g, field).clone()
         t[t.numel() // 2] = value
         setattr(g, field, t)

@@ -554,6 +554,43 @@ def test_trainer_iteration_with_and_without_the_one_call_critic_head(cuda, monke
     assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
 
 
+@pytest.mark.parametrize("preset,ragged,seed", [("small", True, 51), ("small", "jitter", 53), ("dataset", "jitter", 52)])
+def test_generator_stack_in_one_host_call_equals_node_by_node_path(cuda, preset, ragged, seed, monkeypatch):
+    """ops.VoxelStackG (bg_gstack_forward_f32 / _backward_f32: the generator's voxel GNN as one autograd node, one host
+    call each way) against the node-per-call path (ops.GBlock / ops.AttentionNode) on identical parameters, inputs and
+    noise: the four outputs bit-identical (same launches), every generator gradient to 2e-5 of its scale (weight
+    gradients are summed over the calls in the same launches; the program features' gradient in another order)."""
+    from building_gan_amd import models as hm
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup(preset, seed, ragged, cuda)
+    torch.manual_seed(seed)
+    Nv, Ec = sz["Nv"], sz["Ec"]
+    w_out, w_soft = torch.rand(Nv, 6, device=cuda) - 0.5, torch.rand(Nv, 6, device=cuda) - 0.5
+    w_ms, w_mh = torch.rand(Nv, 1, device=cuda) - 0.5, torch.rand(Nv, 1, device=cuda) - 0.5
+    w_as, w_ah = torch.rand(Ec, 1, device=cuda) - 0.5, torch.rand(Ec, 1, device=cuda) - 0.5
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(hm, "FUSE_GSTACK", on)
+        for p in Gh.parameters():
+            p.grad = None
+        out, soft_out, mask, att, idx = Gh(gpu, pz.to(cuda), vz.to(cuda), _to(noise, cuda))
+        loss = ((out * w_out).sum() + (soft_out * w_soft).sum() + (mask["soft"] * w_ms).sum() + (mask["hard"] * w_mh).sum()
+                + (att["soft"] * w_as).sum() + (att["hard"] * w_ah).sum())
+        loss.backward()
+        res.append(([t.detach().clone() for t in (out, soft_out, mask["soft"], mask["hard"], att["soft"], att["hard"], idx)],
+                    {n: p.grad.detach().clone() for n, p in Gh.named_parameters() if p.grad is not None}))
+    (o1, g1), (o0, g0) = res
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    assert set(g1) == set(g0)
+    top = max(float(g.abs().max()) for g in g0.values())
+    worst = 0.0
+    for n in g0:
+        e = float((g1[n] - g0[n]).abs().max()) / max(float(g0[n].abs().max()), 1e-3 * top)
+        assert e <= 2e-5, (n, e)
+        worst = max(worst, e)
+    print("generator stack vs node by node: worst gradient error %.2e" % worst)
+
+
 def test_fused_attention_forward_equals_unfused(cuda):
     """The one-launch Attention call of graph-free passes (bg_attention_fwd_f32) against the five-kernel
     autograd path on identical weights, inputs and noise: same pointers, activations to rounding."""
