@@ -259,6 +259,11 @@ __global__ void k_regroup(const float4* __restrict__ src, float4* __restrict__ d
     if (to_outer) dst[outer] = src[t]; else dst[t] = src[outer];
 }
 
+__global__ void k_fill4(float4* __restrict__ p, int64_t n4, float v) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n4) p[t] = make_float4(v, v, v, v);
+}
+
 __global__ void k_add(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out, int64_t n4) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n4) return;
@@ -279,6 +284,17 @@ int bg_regroup_f32(const float* src, float* dst, int64_t n, int64_t K, int64_t P
     const int64_t total = n * K * P * (W / 4);
     k_regroup<<<bg_grid_for(total, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
         reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n, (int)K, (int)P, (int)(W / 4), to_outer);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_fill_f32(float* p, int64_t n, float value, bgStream stream) {
+    if (n < 0) return BG_ERR_ARG;
+    if (n == 0) return BG_OK;
+    if (!p) return BG_ERR_ARG;
+    if (n % 4 != 0) return BG_ERR_SHAPE;
+    if (!bg_aligned16(p)) return BG_ERR_ALIGN;
+    k_fill4<<<bg_grid_for(n / 4, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(p), n / 4, value);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

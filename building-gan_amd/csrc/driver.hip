@@ -408,8 +408,11 @@ extern "C" int bg_critic_head_backward_f32(const bgCriticHead* hp, float coef, c
 
     BG_TRY(bg_critic_loss_bwd_f32(go, h.wb, 2 * B, h.ws, 2 * S, b.acc, dl, 2 * N, dl, coef, b.dvb, b.dvs, b.dacc, s));
     // ---- penalty: transpose of the Horner chain = the powers of A applied to d acc
-    BG_HIP(hipMemcpy2DAsync(b.dYs, sizeof(float) * ldy, b.dacc, sizeof(float) * W2c, sizeof(float) * W2c, N,
-                            hipMemcpyDeviceToDevice, (hipStream_t)s));
+    {   // d acc into column group 0 of the chain's matrix (a strided copy, as a kernel)
+        const float* src[4] = {b.dacc, nullptr, nullptr, nullptr};
+        const int64_t lds[4] = {W2c, 0, 0, 0};
+        BG_TRY(bg_pack_columns_f32(src, lds, 1, W2c, W2c, b.dYs, ldy, N, s));
+    }
     BG_TRY(bg_spmm_chain_f32(b.dYs, ldy, h.a_rowptr, h.a_col, h.a_count, BG_SCALE_DIV, nullptr, BG_SCALE_NONE,
                              h.blk_ptr, h.blk_n, h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg,
                              nullptr, 0, 0, b.dYs + W2c, ldy, W2c, h.L, W2c, s));
@@ -622,10 +625,9 @@ extern "C" int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGener
     rc = carve_gstack(ar, Np, Nv, S, Ec, H, L, g);
     if (rc != BG_OK) return rc;
     if (ar.used > workspace_floats || n_calls != g.n_att) return BG_ERR_ARG;
-    hipStream_t st = (hipStream_t)s;
     const int nb = cross_logit_blocks(Nv);
     bool have_att = false, have_blk = false, have_np = false;
-    BG_HIP(hipMemsetAsync(g.zero, 0, sizeof(float) * (size_t)(Nv * H), st));
+    BG_TRY(bg_fill_f32(g.zero, Nv * H, 0.f, s));
     const float* gin = g.zero;                 // gradient at the current call's output (the last call's features are unused)
     float* bufs[2] = {g.g0, g.g1};
     int flip = 0;

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 import threading
 from typing import List, Optional, Sequence
 
@@ -1355,7 +1356,10 @@ class VoxelStackG(torch.autograd.Function):
                                         ptr(mask_hard), ptr(mask_soft), ptr(att_hard), ptr(att_soft), stream()),
               "bg_gstack_forward_f32")
         ctx.ws, ctx.ps, ctx.work, ctx.n_ws, ctx.n_calls, ctx.plan = ws, ps, work, n_ws, n_calls, plan
-        ctx.keep = (x, v4, pdm4, ts, Wc, mask_soft, att_soft)
+        # (outputs go through save_for_backward: kept as plain attributes they would tie the node to its own outputs
+        # in a reference cycle, and the dead graph -- with the parameters' AccumulateGrad nodes -- would linger until
+        # the cycle collector runs, which breaks a later stream capture)
+        ctx.save_for_backward(x, v4, pdm4, *ts, Wc, mask_soft, att_soft)
         ctx.set_materialize_grads(False)
         return mask_soft, mask_hard, att_soft, att_hard
 
@@ -1363,8 +1367,7 @@ class VoxelStackG(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_ms, g_mh, g_as, g_ah):
         lib = _lib.load()
-        x, v4, pdm4, ts, Wc, mask_soft, att_soft = ctx.keep
-        enc_w, enc_b, nnp_w, nnp_b, Wcat, bcat, theta, bc, Wsb, pe = ts
+        x, v4, pdm4, enc_w, enc_b, nnp_w, nnp_b, Wcat, bcat, theta, bc, Wsb, pe, Wc, mask_soft, att_soft = ctx.saved_tensors
         plan = ctx.plan
         H = x.shape[1]
         dev = x.device

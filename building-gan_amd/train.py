@@ -442,6 +442,9 @@ class Trainer:
         if warmup < 1:
             raise ValueError("capture needs >= 1 eager warm-up iteration (host-side caches such as the critic's "
                              "+-1/count weights are uploaded there, not inside a stream capture)")
+        import gc
+        gc.collect()        # autograd graphs of earlier eager iterations that only a reference cycle keeps alive hold
+                            # AccumulateGrad nodes made on the default stream, which must not be pulled into the capture
         saved = (self.opt_g.state(), self.opt_d.state())
         counts = global_counts(batch, self.group)
         self._overlap_stream = torch.cuda.Stream() if overlap else None

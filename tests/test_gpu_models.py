@@ -591,6 +591,32 @@ def test_generator_stack_in_one_host_call_equals_node_by_node_path(cuda, preset,
     print("generator stack vs node by node: worst gradient error %.2e" % worst)
 
 
+def test_graph_capture_after_eager_iterations_on_other_batches(cuda):
+    """bench.py's order: eager iterations over a stream of differently shaped batches, then Trainer.capture on a fixed
+    one.  An autograd node that kept its own outputs alive in a reference cycle (and with them the parameters'
+    AccumulateGrad nodes of the eager iterations, made on the default stream) pulled the default stream into the
+    capture and crashed hipStreamEndCapture; nodes keep outputs through save_for_backward, and capture() collects
+    dead cycles first."""
+    from building_gan_amd.plan import build_plan
+    from building_gan_amd.synthetic import make_batch
+    from building_gan_amd.train import Trainer
+    torch.manual_seed(3)
+    tr = Trainer(cuda)
+    others = [make_batch("small", seed=60 + k, ragged="jitter").to(cuda) for k in range(3)]
+    for i in range(6):
+        b = others[i % 3]
+        b.__dict__.pop("_bg_plan", None)
+        build_plan(b)
+        tr.train_iteration(b, i)
+    fixed = make_batch("small", seed=7).to(cuda)
+    build_plan(fixed)
+    tr.capture(fixed)
+    for i in range(6):
+        st = tr.train_iteration_graphed(i)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.opt_d.grad).all() and torch.isfinite(tr.opt_g.grad).all()
+
+
 def test_fused_attention_forward_equals_unfused(cuda):
     """The one-launch Attention call of graph-free passes (bg_attention_fwd_f32) against the five-kernel
     autograd path on identical weights, inputs and noise: same pointers, activations to rounding."""
