@@ -575,8 +575,8 @@ int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan* p
  * reference runs one pass per label set, train.py:88-96).                                                  */
 int bg_regroup_f32(const float* src, float* dst, int64_t n, int64_t K, int64_t P, int64_t W, int to_outer, bgStream stream);
 
-/* p[0..n) = value (n % 4 == 0, 16-byte aligned): a fill as a kernel launch (the whole-pass entry points issue
- * kernels only, no runtime memset / memcpy nodes, so that they capture into a hipGraph like any other launch). */
+/* p[0..n) = value (n % 4 == 0, 16-byte aligned): a fill as a kernel launch (the critic head and the generator
+ * stack issue kernels only, no runtime memset / memcpy nodes). */
 int bg_fill_f32(float* p, int64_t n, float value, bgStream stream);
 
 /* out = a + b over n floats (n % 4 == 0, 16-byte aligned): the one elementwise sum the critic's backward needs
