@@ -331,10 +331,42 @@ def _build_plan_one_call(graph, S) -> Optional[GraphPlan]:
     return _check_and_publish(graph, p, flags, stat["MIN_CROSS"])
 
 
+_PREFETCH_STREAMS = {}
+
+
+def prefetch_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
+    """Build the plan of a batch that a LATER iteration will use, beside the work already queued on the current
+    stream: the launches go to a side stream and the one host read-back waits for that stream only, so an iteration
+    whose kernels are still running is not drained first (what a loader's prefetch does for the reference's collate).
+    The first build_plan() on the batch makes the then-current stream wait for the side stream's event.  A plan
+    depends on the batch's index vectors alone, never on parameters."""
+    cached = graph.__dict__.get("_bg_plan") if hasattr(graph, "__dict__") else None
+    if cached is not None:
+        return cached
+    dev = graph.voxel_feature.device
+    if dev.type != "cuda":
+        return build_plan(graph, num_stories)
+    side = _PREFETCH_STREAMS.get(dev)
+    if side is None:
+        side = _PREFETCH_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    with torch.cuda.stream(side):
+        p = build_plan(graph, num_stories)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    p.ops["_ready_event"] = ev
+    for t in p.ops.get("_arenas", ()):
+        t.record_stream(main)             # allocated under the side stream, read by kernels of the main stream
+    return p
+
+
 def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     """Build (or fetch the cached) plan for a batch that exposes the row-a0 attributes."""
     cached = graph.__dict__.get("_bg_plan") if hasattr(graph, "__dict__") else None
     if cached is not None:
+        ev = cached.ops.pop("_ready_event", None) if cached.ops else None
+        if ev is not None:                # prefetched on a side stream: order this stream behind its launches
+            torch.cuda.current_stream(cached.device).wait_event(ev)
         return cached
     if ONE_CALL_BUILD:
         _lib.require_device(graph.voxel_feature, "build_plan")

@@ -416,11 +416,22 @@ class Trainer:
         ``on_epoch(epoch, stats)`` (evaluation, logging) is called.  Returns the last iteration's losses."""
         import os
         stats = {}
+        from .plan import prefetch_plan
+        dev = torch.device(self.device)
+
+        def fetch(it):
+            b = next(it, None)
+            if b is not None and b.voxel_feature.device != dev:
+                b = b.to(dev)
+            return b
         for epoch in range(n_epochs):
-            for i, batch in enumerate(loader):
-                if batch.voxel_feature.device != torch.device(self.device):
-                    batch = batch.to(self.device)
+            it = iter(loader)
+            batch, i = fetch(it), 0
+            while batch is not None:
                 stats = self.train_iteration(batch, i)
+                batch, i = fetch(it), i + 1
+                if batch is not None and dev.type == "cuda":
+                    prefetch_plan(batch)          # the next batch's index plan beside this iteration's kernels
             if epoch % eval_period == 0:
                 if model_dir is not None:
                     os.makedirs(model_dir, exist_ok=True)

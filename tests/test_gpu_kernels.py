@@ -129,6 +129,29 @@ def test_plan_in_one_host_call_reports_bad_indices(cuda, monkeypatch):
     torch.cuda.synchronize()
 
 
+def test_prefetched_plan_equals_direct_build_and_orders_the_consumer(cuda):
+    """plan.prefetch_plan builds on a side stream; the plan must equal the directly built one bit for bit, and the
+    first build_plan() on the batch must order the current stream behind the side stream (the event is consumed)."""
+    from building_gan_amd import ops, plan as P
+    g = _batch("dataset", 9, "jitter").to(cuda)
+    direct = P.build_plan(g)
+    g.__dict__.pop("_bg_plan")
+    x = torch.rand(direct.Nv, 128, device=cuda)
+    want = ops.spmm_raw(direct.vox_mean, x)
+    # keep the main stream busy so that the side stream really runs beside it
+    for _ in range(20):
+        ops.spmm_raw(direct.vox_mean, x)
+    pre = P.prefetch_plan(g)
+    assert "_ready_event" in pre.ops
+    got_plan = P.build_plan(g)
+    assert got_plan is pre and "_ready_event" not in pre.ops
+    got = ops.spmm_raw(got_plan.vox_mean, x)
+    assert torch.equal(got, want)
+    a = {k: v for k, v in pre.ops.items() if k != "_arenas"}
+    b = {k: v for k, v in direct.ops.items() if k != "_arenas"}
+    _same(a, b, "plan", set())
+
+
 def test_plan_unsorted_random_keys(cuda):
     """Random (unsorted, skewed) keys incl. empty rows and one very long row (> LDS sort size)."""
     from building_gan_amd.plan import _Builder
