@@ -76,6 +76,10 @@ SIGNATURES = {
     "bg_fill_f32": [_p, _i64, _f, _p],
     "bg_critic_head_forward_f32": [_p, _f, _p, _i64, _p, _p],
     "bg_critic_head_backward_f32": [_p, _f, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "bg_leaky_bwd_f32": [_p, _p, _f, _p, _i64, _p],
+    "bg_rowscale_f32": [_p, _i64, _p, _p, _i64, _i64, _i64, _p],
+    "bg_pstack_forward_f32": [_p, _p, _p, _p, _i64, _p, _p],
+    "bg_pstack_backward_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p],
     "bg_gstack_forward_f32": [_p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p],
     "bg_gstack_backward_f32": [_p, _p, _p, _p, _p, _p, _i64, _p, _i64] + [_p] * 6 + [_p] * 10 + [_p],
     "bg_plan_layout": [_p, _p, _p, _p],
@@ -159,6 +163,8 @@ def load() -> C.CDLL:
     lib.bg_generator_forward_workspace.argtypes = [_i64] * 5
     lib.bg_d_coef_backward_workspace.restype = C.c_int64
     lib.bg_d_coef_backward_workspace.argtypes = [_i64] * 4
+    lib.bg_pstack_workspace.restype = C.c_int64
+    lib.bg_pstack_workspace.argtypes = [_i64] * 4
     lib.bg_gstack_workspace.restype = C.c_int64
     lib.bg_gstack_workspace.argtypes = [_i64] * 6
     lib.bg_critic_head_workspace.restype = C.c_int64

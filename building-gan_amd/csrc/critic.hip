@@ -264,6 +264,27 @@ __global__ void k_fill4(float4* __restrict__ p, int64_t n4, float v) {
     if (t < n4) p[t] = make_float4(v, v, v, v);
 }
 
+// out = g where y > 0, slope * g elsewhere (y = the leaky ReLU's RESULT, which has the sign of its input)
+__global__ void k_leaky_bwd(const float4* __restrict__ g, const float4* __restrict__ y, float slope, float4* __restrict__ out,
+                            int64_t n4) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    const float4 a = g[t], b = y[t];
+    out[t] = make_float4(b.x > 0.f ? a.x : a.x * slope, b.y > 0.f ? a.y : a.y * slope, b.z > 0.f ? a.z : a.z * slope,
+                         b.w > 0.f ? a.w : a.w * slope);
+}
+
+// out[r, :] = scale[r] * x[r, :]  (x with a row pitch)
+__global__ void k_rowscale(const float* __restrict__ x, int64_t ldx, const float* __restrict__ scale, float* __restrict__ out,
+                           int64_t ldo, int64_t n, int H4) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * H4) return;
+    const int64_t r = t / H4; const int c = (int)(t % H4);
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + 4 * c);
+    const float s = scale[r];
+    *reinterpret_cast<float4*>(out + r * ldo + 4 * c) = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+}
+
 __global__ void k_add(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out, int64_t n4) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n4) return;
@@ -295,6 +316,30 @@ int bg_fill_f32(float* p, int64_t n, float value, bgStream stream) {
     if (n % 4 != 0) return BG_ERR_SHAPE;
     if (!bg_aligned16(p)) return BG_ERR_ALIGN;
     k_fill4<<<bg_grid_for(n / 4, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(p), n / 4, value);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_leaky_bwd_f32(const float* g, const float* y, float slope, float* out, int64_t n, bgStream stream) {
+    if (n < 0) return BG_ERR_ARG;
+    if (n == 0) return BG_OK;
+    if (!g || !y || !out) return BG_ERR_ARG;
+    if (n % 4 != 0) return BG_ERR_SHAPE;
+    if (!bg_aligned16(g) || !bg_aligned16(y) || !bg_aligned16(out)) return BG_ERR_ALIGN;
+    k_leaky_bwd<<<bg_grid_for(n / 4, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(y), slope, reinterpret_cast<float4*>(out), n / 4);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_rowscale_f32(const float* x, int64_t ldx, const float* scale, float* out, int64_t ldo, int64_t n, int64_t H,
+                    bgStream stream) {
+    if (n < 0 || H < 0) return BG_ERR_ARG;
+    if (n == 0 || H == 0) return BG_OK;
+    if (!x || !scale || !out || ldx < H || ldo < H) return BG_ERR_ARG;
+    if (H % 4 != 0 || ldx % 4 != 0 || ldo % 4 != 0) return BG_ERR_SHAPE;
+    if (!bg_aligned16(x) || !bg_aligned16(out)) return BG_ERR_ALIGN;
+    k_rowscale<<<bg_grid_for(n * (H / 4), 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(x, ldx, scale, out, ldo, n, (int)(H / 4));
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

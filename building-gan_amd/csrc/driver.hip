@@ -731,3 +731,139 @@ extern "C" int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGener
     }
     return BG_OK;
 }
+
+// ---------------------------------------------------------------- program GNN: forward that saves, backward
+namespace {
+struct PStack {
+    float *x[33], *both[32], *aggr[32], *y[32];
+    float *g0, *g1, *gz, *gcat, *gpre, *gcat2, *t, *splitk, *colsum;
+};
+int carve_pstack(Arena& ar, int64_t Np, int64_t H, int64_t kin, int64_t L, PStack& b) {
+    if (L < 0 || L > 32) return BG_ERR_SHAPE;
+    for (int64_t l = 0; l <= L; ++l) b.x[l] = ar.take(Np * H);
+    for (int64_t l = 0; l < L; ++l) { b.both[l] = ar.take(2 * Np * H); b.aggr[l] = ar.take(Np * H); b.y[l] = ar.take(Np * H); }
+    b.g0 = ar.take(Np * H); b.g1 = ar.take(Np * H); b.gz = ar.take(Np * H); b.gcat = ar.take(Np * 3 * H);
+    b.gpre = ar.take(Np * H); b.gcat2 = ar.take(Np * 2 * H); b.t = ar.take(Np * H);
+    int64_t sk = 0;
+    auto need = [&](int64_t M, std::initializer_list<int64_t> ns, int64_t R) {
+        int64_t Ns[4] = {0, 0, 0, 0}, N = 0; int n = 0;
+        for (int64_t v : ns) { Ns[n++] = v; N += v; }
+        const int64_t x = (int64_t)tn_splits_multi(M, Ns, n, R) * M * N;
+        if (x > sk) sk = x;
+    };
+    need(H, {H, H, H}, Np); need(H, {H, H}, Np); need(H, {kin}, Np);
+    b.splitk = ar.take(sk);
+    b.colsum = ar.take(256 * H);
+    return BG_OK;
+}
+}  // namespace
+
+extern "C" int64_t bg_pstack_workspace(int64_t Np, int64_t H, int64_t kin, int64_t L) {
+    if (Np <= 0 || H <= 0 || kin <= 0 || L < 0) return -1;
+    Arena ar{nullptr, 0, 0};
+    PStack b;
+    if (carve_pstack(ar, Np, H, kin, L, b) != BG_OK) return -1;
+    return ar.used + 64;
+}
+
+extern "C" int bg_pstack_forward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan* p, const float* program_in,
+                                     float* workspace, int64_t workspace_floats, float* x_out, bgStream s) {
+    if (!w || !p || !program_in || !workspace || !x_out) return BG_ERR_ARG;
+    if (!w->p_enc_w || !w->p_enc_b || !w->p_msg_w || !w->p_msg_b || !w->p_upd_w || !w->p_upd_b || !p->pp_rowptr || !p->pp_col ||
+        !p->pp_scale || !p->prog_has) return BG_ERR_ARG;
+    const int64_t H = w->H, Np = p->Np, L = w->program_layer, kin = w->n_class + 1 + w->noise_dim;
+    if (H <= 0 || Np <= 0 || L < 0 || kin <= 0) return BG_ERR_ARG;
+    if (H % 4 != 0) return BG_ERR_SHAPE;
+    if (!bg_aligned16(workspace)) return BG_ERR_ALIGN;
+    Arena ar{workspace, 0, workspace_floats};
+    PStack b;
+    int rc = carve_pstack(ar, Np, H, kin, L, b);
+    if (rc != BG_OK) return rc;
+    if (ar.used > workspace_floats) return BG_ERR_ARG;
+    BG_TRY(linear(Np, H, 1, program_in, kin, nullptr, 0, nullptr, 0, kin, w->p_enc_w, kin, L == 0 ? x_out : b.x[0], w->p_enc_b,
+                  nullptr, BG_ACT_NONE, nullptr, nullptr, 0, nullptr, nullptr, s));
+    for (int64_t l = 0; l < L; ++l) {
+        const float* x = b.x[l];
+        float* xn = l == L - 1 ? x_out : b.x[l + 1];
+        BG_TRY(bg_spmm_f32(x, H, p->pp_rowptr, p->pp_col, nullptr, nullptr, p->pp_scale, BG_SCALE_MUL, nullptr, BG_SCALE_NONE,
+                           b.both[l], H, 2 * Np, H, s));
+        BG_TRY(linear(Np, H, 2, x, H, b.both[l], H, nullptr, 0, H, w->p_msg_w, 2 * H, b.aggr[l], w->p_msg_b, p->prog_has,
+                      BG_ACT_NONE, nullptr, nullptr, 0, nullptr, nullptr, s));
+        const float* A[4] = {x, b.aggr[l], b.both[l] + Np * H, nullptr};
+        const int64_t ld[4] = {H, H, H, 0}, Ks[4] = {H, H, H, 0};
+        BG_TRY(bg_gemm_f32(0, 1, Np, H, 3, A, ld, Ks, w->p_upd_w, 3 * H, xn, H, w->p_upd_b, nullptr, BG_ACT_LEAKY, 0.01f, x, H,
+                           nullptr, 0, nullptr, nullptr, 0, b.y[l], H, s));
+    }
+    return BG_OK;
+}
+
+extern "C" int bg_pstack_backward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan* p, const int32_t* pr_rowptr,
+                                      const int32_t* pr_col, const float* pf_count, const float* program_in, const float* g,
+                                      float* workspace, int64_t workspace_floats, float* g_enc_w, float* g_enc_b,
+                                      float* g_msg_w, float* g_msg_b, float* g_upd_w, float* g_upd_b, bgStream s) {
+    if (!w || !p || !pr_rowptr || !pr_col || !pf_count || !program_in || !g || !workspace || !g_enc_w || !g_enc_b || !g_msg_w ||
+        !g_msg_b || !g_upd_w || !g_upd_b) return BG_ERR_ARG;
+    const int64_t H = w->H, Np = p->Np, L = w->program_layer, kin = w->n_class + 1 + w->noise_dim;
+    if (H <= 0 || Np <= 0 || L < 0 || kin <= 0) return BG_ERR_ARG;
+    if (H % 4 != 0) return BG_ERR_SHAPE;
+    if (!bg_aligned16(workspace)) return BG_ERR_ALIGN;
+    Arena ar{workspace, 0, workspace_floats};
+    PStack b;
+    int rc = carve_pstack(ar, Np, H, kin, L, b);
+    if (rc != BG_OK) return rc;
+    if (ar.used > workspace_floats) return BG_ERR_ARG;
+    const float* gin = g;
+    float* bufs[2] = {b.g0, b.g1};
+    int flip = 0;
+    if (L == 0) {      // no block: nothing accumulates into these
+        BG_TRY(bg_fill_f32(g_msg_w, H * 2 * H, 0.f, s)); BG_TRY(bg_fill_f32(g_msg_b, H, 0.f, s));
+        BG_TRY(bg_fill_f32(g_upd_w, H * 3 * H, 0.f, s)); BG_TRY(bg_fill_f32(g_upd_b, H, 0.f, s));
+    }
+    for (int64_t l = L - 1; l >= 0; --l) {
+        const int acc = l == L - 1 ? 0 : 1;
+        const float* x = b.x[l];
+        float* gout = bufs[flip];
+        flip ^= 1;
+        BG_TRY(bg_leaky_bwd_f32(gin, b.y[l], 0.01f, b.gz, Np * H, s));
+        {
+            const float* Bs[4] = {x, b.aggr[l], b.both[l] + Np * H, nullptr};
+            const int64_t ldb[4] = {H, H, H, 0}, Ns[4] = {H, H, H, 0};
+            BG_TRY(tn_multi(H, Np, b.gz, 3, Bs, ldb, Ns, g_upd_w, b.splitk, acc, s));
+        }
+        BG_TRY(bg_colsum_f32(b.gz, H, Np, H, b.colsum, colsum_blocks(Np), g_upd_b, acc, s));
+        {
+            const float* A[4] = {b.gz, nullptr, nullptr, nullptr};
+            const int64_t ld[4] = {H, 0, 0, 0}, Ks[4] = {H, 0, 0, 0};
+            BG_TRY(bg_gemm_f32(0, 0, Np, 3 * H, 1, A, ld, Ks, w->p_upd_w, 3 * H, b.gcat, 3 * H, nullptr, nullptr, BG_ACT_NONE, 0.f,
+                               nullptr, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
+        }
+        BG_TRY(bg_rowscale_f32(b.gcat + H, 3 * H, p->prog_has, b.gpre, H, Np, H, s));
+        {
+            const float* Bs[4] = {x, b.both[l], nullptr, nullptr};
+            const int64_t ldb[4] = {H, H, 0, 0}, Ns[4] = {H, H, 0, 0};
+            BG_TRY(tn_multi(H, Np, b.gpre, 2, Bs, ldb, Ns, g_msg_w, b.splitk, acc, s));
+        }
+        BG_TRY(bg_colsum_f32(b.gpre, H, Np, H, b.colsum, colsum_blocks(Np), g_msg_b, acc, s));
+        {
+            const float* A[4] = {b.gpre, nullptr, nullptr, nullptr};
+            const int64_t ld[4] = {H, 0, 0, 0}, Ks[4] = {H, 0, 0, 0};
+            BG_TRY(bg_gemm_f32(0, 0, Np, 2 * H, 1, A, ld, Ks, w->p_msg_w, 2 * H, b.gcat2, 2 * H, nullptr, nullptr, BG_ACT_NONE, 0.f,
+                               nullptr, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
+        }
+        // g + gx(update) + transpose of the in-edge mean applied to g_gm ...
+        BG_TRY(bg_spmm_add_f32(b.gcat2 + H, 2 * H, pr_rowptr, pr_col, nullptr, BG_SCALE_NONE, pf_count, BG_SCALE_DIV, gin, H,
+                               b.gcat, 3 * H, nullptr, 0, nullptr, nullptr, BG_SCALE_NONE, b.t, H, Np, H, s));
+        // ... + gx(message) + the class-slot operator (symmetric: rows [Np, 2 Np) of the pair operator) applied to g_on
+        BG_TRY(bg_spmm_add_f32(b.gcat + 2 * H, 3 * H, p->pp_rowptr + Np, p->pp_col, p->pp_scale + Np, BG_SCALE_MUL, nullptr,
+                               BG_SCALE_NONE, b.t, H, b.gcat2, 2 * H, nullptr, 0, nullptr, nullptr, BG_SCALE_NONE, gout, H, Np,
+                               H, s));
+        gin = gout;
+    }
+    {
+        const float* Bs[4] = {program_in, nullptr, nullptr, nullptr};
+        const int64_t ldb[4] = {kin, 0, 0, 0}, Ns[4] = {kin, 0, 0, 0};
+        BG_TRY(tn_multi(H, Np, gin, 1, Bs, ldb, Ns, g_enc_w, b.splitk, 0, s));
+        BG_TRY(bg_colsum_f32(gin, H, Np, H, b.colsum, colsum_blocks(Np), g_enc_b, 0, s));
+    }
+    return BG_OK;
+}

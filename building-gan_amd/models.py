@@ -39,6 +39,7 @@ FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is
 FUSE_POS_TERM = True      # generator: position columns x weight + bias once per forward, the 12 products start from it
 FUSE_COEF_INPUTS = True   # collapsed discriminator: the recurrence's parameter rows by one launch (ops.PolyCoefD)
 FUSE_GENERATOR_FORWARD = True   # graph-free Generator.forward as ONE host call (bg_generator_forward_f32)
+FUSE_PSTACK = True        # generator update: ProgramGNN as ONE autograd node, one host call each way (ops.ProgramStack)
 FUSE_GSTACK = True        # generator update: VoxelGNN_G below the program GNN as ONE autograd node, one host call each way (ops.VoxelStackG)
 FUSE_CRITIC_HEAD = True   # WGAN-GP critic update below the coefficient table as ONE host call each way (ops.CriticHead)
 COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
@@ -164,7 +165,16 @@ class ProgramGNN(nn.Module):
         self.block = ProgramBlock(hidden_dim)
 
     def forward(self, cf, slf, tr, z, plan):
-        x = run_mlp(self.enc, torch.cat([cf, slf.view(-1, 1), z], dim=-1))
+        program_in = torch.cat([cf, slf.view(-1, 1), z], dim=-1)
+        if (FUSE_PSTACK and torch.is_grad_enabled() and program_in.is_cuda and FUSE_PROGRAM_BLOCK and "prog_pair" in plan.ops
+                and "story_building_mean" in plan.ops and len(self.enc) == 1 and program_in.dtype == torch.float32
+                and self.enc[0].weight.shape[0] % 4 == 0 and plan.Np > 0 and plan.Ep > 0):
+            # a graph is being built (generator update): the whole program GNN as one autograd node
+            _generator_plan_struct(plan)
+            blk = self.block
+            return ops.ProgramStack.apply(self.enc[0].weight, self.enc[0].bias, blk.messageMLP[0].weight, blk.messageMLP[0].bias,
+                                          blk.updateMLP[0].weight, blk.updateMLP[0].bias, program_in, plan, self.layer_num)
+        x = run_mlp(self.enc, program_in)
         fused = FUSE_PROGRAM_BLOCK and not torch.is_grad_enabled() and "prog_pair" in plan.ops
         for _ in range(self.layer_num):
             x = self.block.forward_residual(x, plan) if fused else x + self.block(x, plan, tr)

@@ -1310,6 +1310,53 @@ class CriticLoss(torch.autograd.Function):
         return db, ds, dg, None, None, None
 
 
+class ProgramStack(torch.autograd.Function):
+    """ProgramGNN.forward -- encoder and every ProgramBlock call with its residual -- as ONE autograd node whose
+    forward and backward are one host call each (bg_pstack_forward_f32 / _backward_f32).  First-order autograd.
+    Differentiable inputs: enc_w [H, kin], enc_b, Wm [H, 2H], bm, Wu [H, 3H], bu; program_in [Np, kin] is data."""
+
+    @staticmethod
+    def forward(ctx, enc_w, enc_b, Wm, bm, Wu, bu, program_in, plan, L: int):
+        lib = _lib.load()
+        _lib.require_device(program_in, "program_stack")
+        ts = [t.contiguous() for t in (enc_w, enc_b, Wm, bm, Wu, bu)]
+        program_in = _f32c(program_in).contiguous()
+        H, kin = ts[0].shape
+        Np = program_in.shape[0]
+        if program_in.shape[1] != kin or Np != plan.Np or tuple(ts[2].shape) != (H, 2 * H) or tuple(ts[4].shape) != (H, 3 * H):
+            raise _lib.BganError("program_stack: operand shapes do not fit")
+        ps = plan.ops.get("_generator_plan_struct")
+        if ps is None:
+            raise _lib.BganError("program_stack: the plan carries no bgGeneratorPlan (models._generator_plan_struct)")
+        ws = _lib.GeneratorWeights(H, 0, L, 0, kin - 1, 0, ptr(ts[0]), ptr(ts[1]), ptr(ts[2]), ptr(ts[3]), ptr(ts[4]), ptr(ts[5]),
+                                   None, None, None, None, 0, None, None, None, None, None, None, None)
+        n_ws = int(lib.bg_pstack_workspace(Np, H, kin, L))
+        if n_ws < 0:
+            raise _lib.BganError("program_stack: sizes not supported")
+        work = torch.empty(n_ws, dtype=torch.float32, device=program_in.device)
+        x = torch.empty(Np, H, dtype=torch.float32, device=program_in.device)
+        check(lib.bg_pstack_forward_f32(C.byref(ws), C.byref(ps), ptr(program_in), ptr(work), n_ws, ptr(x), stream()),
+              "bg_pstack_forward_f32")
+        ctx.ws, ctx.ps, ctx.work, ctx.n_ws, ctx.plan = ws, ps, work, n_ws, plan
+        ctx.save_for_backward(program_in, *ts)
+        return x
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        program_in, *ts = ctx.saved_tensors
+        plan = ctx.plan
+        pr, cnt = plan.prog_mean.T.csr, plan.prog_mean.row_scale
+        g = _f32c(g).contiguous()
+        outs = [torch.empty_like(t) for t in ts]
+        check(lib.bg_pstack_backward_f32(C.byref(ctx.ws), C.byref(ctx.ps), ptr(pr.rowptr), ptr(pr.col), ptr(cnt),
+                                         ptr(program_in), ptr(g), ptr(ctx.work), ctx.n_ws, *[ptr(t) for t in outs], stream()),
+              "bg_pstack_backward_f32")
+        ctx.work = None
+        return (*outs, None, None, None)
+
+
 class VoxelStackG(torch.autograd.Function):
     """VoxelGNN_G.forward below the program GNN -- encoder, NN_p(x), every Attention and VoxelBlock call -- as ONE
     autograd node whose forward and backward are one host call each (bg_gstack_forward_f32 / _backward_f32: the

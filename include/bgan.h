@@ -568,6 +568,28 @@ int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan* p
                            float* g_x, float* g_enc_w, float* g_enc_b, float* g_nnp_w, float* g_nnp_b, float* g_Wcat,
                            float* g_bcat, float* g_theta, float* g_Wc, float* g_Wsb, bgStream stream);
 
+/* out = g * (y > 0 ? 1 : slope) over n floats (y = the LeakyReLU's result; n % 4 == 0, 16-byte aligned), and
+ * out[r, :] = scale[r] * x[r, :] (H, pitches % 4 == 0): the two elementwise steps of a ProgramBlock's backward.
+ * replaces: aten leaky_relu_backward and the row mask's product in the backward of Model/models.py:68,73.       */
+int bg_leaky_bwd_f32(const float* g, const float* y, float slope, float* out, int64_t n, bgStream stream);
+int bg_rowscale_f32(const float* x, int64_t ldx, const float* scale, float* out, int64_t ldo, int64_t n, int64_t H,
+                    bgStream stream);
+
+/* ProgramGNN.forward (Model/models.py:83-92 with :52-76) keeping every layer's input, aggregates and activation,
+ * and its backward, as ONE host call each.  program_in = [class one-hot | story level | z] [Np, kin],
+ * kin = n_class + 1 + noise_dim; uses w's p_* fields and p's pp_* / prog_has; vt_* of the back plan are not read
+ * here: pr_rowptr / pr_col = program edges by source (the transpose of the in-edge mean, column scale pf_count).
+ * forward: x_out [Np, H].  backward: g [Np, H] = d / d x_out; writes g_enc_w [H, kin], g_enc_b, g_msg_w [H, 2H],
+ * g_msg_b, g_upd_w [H, 3H], g_upd_b (weight gradients summed over the layers inside the launches).
+ * replaces: the program GNN's part of Generator.forward and of g_loss.backward(), train.py:84,112.               */
+int64_t bg_pstack_workspace(int64_t Np, int64_t H, int64_t kin, int64_t L);
+int bg_pstack_forward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan* p, const float* program_in,
+                          float* workspace, int64_t workspace_floats, float* x_out, bgStream stream);
+int bg_pstack_backward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan* p, const int32_t* pr_rowptr,
+                           const int32_t* pr_col, const float* pf_count, const float* program_in, const float* g,
+                           float* workspace, int64_t workspace_floats, float* g_enc_w, float* g_enc_b, float* g_msg_w,
+                           float* g_msg_b, float* g_upd_w, float* g_upd_b, bgStream stream);
+
 /* src [n, K, P, W] -> dst [P, n, K, W] (to_outer != 0) or src [P, n, K, W] -> dst [n, K, P, W] (to_outer == 0):
  * column groups that several label sets / both critic outputs share in one operator chain, regrouped into one
  * contiguous matrix per set for the products on either side.  W % 4 == 0, 16-byte aligned, contiguous.

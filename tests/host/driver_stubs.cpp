@@ -173,6 +173,16 @@ int bg_segreduce_sum_f32(const float* x, int64_t ldx, const int32_t* rowptr, con
     rec(24, a, sizeof(a) / 8);
     return 0;
 }
+int bg_leaky_bwd_f32(const float* g, const float* y, float, float* out, int64_t n, bgStream) {
+    int64_t a[] = {P(g), P(y), P(out), n};
+    rec(26, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_rowscale_f32(const float* x, int64_t ldx, const float* scale, float* out, int64_t ldo, int64_t n, int64_t H, bgStream) {
+    int64_t a[] = {P(x), ldx, P(scale), P(out), ldo, n, H};
+    rec(27, a, sizeof(a) / 8);
+    return 0;
+}
 int bg_fill_f32(float* p, int64_t n, float, bgStream) {
     int64_t a[] = {P(p), 0, n * 4};
     rec(25, a, sizeof(a) / 8);

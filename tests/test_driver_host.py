@@ -732,3 +732,87 @@ def test_gstack_host_sequence_and_extents(drv, Np, Nv, S, Ec, one):
     assert flags["g_Wc"] == [0] + [1] * 10 and flags["g_Wsb"] == [0] + [1] * 10
     assert flags["g_Wcat"] == [0] + [1] * 5 and flags["g_bcat"] == [0] + [1] * 5 and flags["g_theta"] == [0] + [1] * 5
     assert flags["g_enc_w"] == [0] and flags["g_enc_b"] == [0] and flags["g_nnp_w"] == [0] and flags["g_nnp_b"] == [0]
+
+
+
+# ------------------------------------------------------------------------------------ program GNN stack (bg_pstack_*)
+@pytest.mark.parametrize("Np,L", [(320, 4), (7, 1), (33, 2)])
+def test_pstack_host_sequence_and_extents(drv, Np, L):
+    import sys
+    sys.path.insert(0, ROOT)
+    from building_gan_amd._lib import GeneratorPlan, GeneratorWeights
+    R = Ranges()
+    f, H, kin = 4, 128, 39
+    Ep = 3 * Np
+    w = GeneratorWeights(H, 32, L, 0, 6, 0, R.new("p_enc_w", H * kin * f), R.new("p_enc_b", H * f), R.new("p_msg_w", H * 2 * H * f),
+                         R.new("p_msg_b", H * f), R.new("p_upd_w", H * 3 * H * f), R.new("p_upd_b", H * f),
+                         None, None, None, None, 0, None, None, None, None, None, None, None)
+    p = GeneratorPlan(Np, 1, 1, 1, 1, 1, R.new("pp_rowptr", (2 * Np + 1) * 4), R.new("pp_col", (Ep + Np * Np) * 4),
+                      R.new("pp_scale", 2 * Np * f), R.new("prog_has", Np * f), *([None] * 13))
+    drv.bg_pstack_workspace.restype = C.c_int64
+    drv.bg_pstack_workspace.argtypes = [C.c_int64] * 4
+    nws = drv.bg_pstack_workspace(Np, H, kin, L)
+    assert nws > 0
+    work, pin, xo = R.new("workspace", nws * f), R.new("program_in", Np * kin * f), R.new("x_out", Np * H * f)
+    drv.bg_pstack_forward_f32.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_void_p]
+    drv.bg_pstack_backward_f32.argtypes = [C.c_void_p] * 8 + [C.c_int64] + [C.c_void_p] * 7
+
+    def calls_of(fn, *args):
+        drv.stub_reset()
+        rc = fn(*args)
+        return rc, [(drv.stub_call(i)[0], [drv.stub_call(i)[2 + k] for k in range(drv.stub_call(i)[1])])
+                    for i in range(drv.stub_count())]
+    rc, fwd = calls_of(drv.bg_pstack_forward_f32, C.byref(w), C.byref(p), pin, work, nws, xo, None)
+    assert rc == 0 and [k for k, _ in fwd] == [1] + [2, 1, 1] * L
+    outs = [R.new("g_enc_w", H * kin * f), R.new("g_enc_b", H * f), R.new("g_msg_w", H * 2 * H * f), R.new("g_msg_b", H * f),
+            R.new("g_upd_w", H * 3 * H * f), R.new("g_upd_b", H * f)]
+    rc, bwd = calls_of(drv.bg_pstack_backward_f32, C.byref(w), C.byref(p), R.new("pr_rowptr", (Np + 1) * 4),
+                       R.new("pr_col", Ep * 4), R.new("pf_count", Np * f), pin, R.new("g", Np * H * f), work, nws, *outs, None)
+    assert rc == 0 and [k for k, _ in bwd] == [26, 19, 17, 1, 27, 19, 17, 1, 3, 3] * L + [19, 17]
+    last_x = [a[19] for k, a in fwd if k == 1][-1]
+    assert R.check(last_x, 4, "x") == "x_out"
+    for kind, a in fwd + bwd:
+        tag = "kind %d" % kind
+        if kind == 1:
+            (tA, tB, M, Nn, n_seg), A, lda, Ks = a[0:5], a[5:9], a[9:13], a[13:17]
+            Bp, ldb, Cp, ldc = a[17:21]
+            assert M == Np
+            K = sum(Ks[:n_seg])
+            for sgm in range(n_seg):
+                R.check(A[sgm], ((M - 1) * lda[sgm] + Ks[sgm]) * f, tag + " A")
+                assert A[sgm] != Cp
+            R.check(Bp, (((Nn - 1) * ldb + K) if tB else ((K - 1) * ldb + Nn)) * f, tag + " B")
+            R.check(Cp, ((M - 1) * ldc + Nn) * f, tag + " C")
+            for q, ldq in ((a[24], a[25]), (a[31], a[32])):        # residual, pre_residual_out
+                if q:
+                    R.check(q, ((M - 1) * ldq + Nn) * f, tag + " epilogue operand")
+        elif kind == 2:
+            x, ldx, rp, col, ew, ep, rsc, rm, csc, cm, out, ldo, n_rows, Hh = a
+            assert n_rows == 2 * Np
+            R.check(x, ((Np - 1) * ldx + Hh) * f, tag); R.check(rp, (n_rows + 1) * 4, tag); R.check(rsc, n_rows * f, tag)
+            R.check(out, ((n_rows - 1) * ldo + Hh) * f, tag)
+        elif kind == 3:
+            x, ldx, rp, col, rsc, rm, csc, cm, a1, ld1, a2, ld2, ga, ldg, grow, gs, gm_, out, ldo, n_rows, Hh = a
+            assert n_rows == Np and not ga
+            R.check(x, ((Np - 1) * ldx + Hh) * f, tag + " x"); R.check(rp, (Np + 1) * 4, tag + " rowptr")
+            R.check(a1, ((Np - 1) * ld1 + Hh) * f, tag + " add1"); R.check(a2, ((Np - 1) * ld2 + Hh) * f, tag + " add2")
+            R.check(out, ((Np - 1) * ldo + Hh) * f, tag + " out")
+            R.check(rsc if rm else csc, Np * f, tag + " scale")
+            assert out not in (x, a1, a2)
+        elif kind == 17:
+            x, ldx, M, Nn, part, nb, out, accum = a
+            R.check(x, ((M - 1) * ldx + Nn) * f, tag); R.check(part, nb * Nn * f, tag); R.check(out, Nn * f, tag)
+        elif kind == 19:
+            M, Rr, A, lda, n_seg, B0, ldb0, N0, Cp, ldc, part, splits, accum = a
+            R.check(A, ((Rr - 1) * lda + M) * f, tag); R.check(B0, ((Rr - 1) * ldb0 + N0) * f, tag)
+            R.check(Cp, M * ldc * f, tag); R.check(part, splits * M * ldc * f, tag)
+        elif kind == 26:
+            g, y, out, n = a
+            for q in (g, y, out):
+                R.check(q, n * f, tag)
+            assert out != g and out != y and n == Np * H
+        elif kind == 27:
+            x, ldx, sc, out, ldo, n, Hh = a
+            R.check(x, ((n - 1) * ldx + Hh) * f, tag); R.check(sc, n * f, tag); R.check(out, ((n - 1) * ldo + Hh) * f, tag)
+        else:
+            raise AssertionError("unexpected launcher %d" % kind)

@@ -617,6 +617,35 @@ def test_graph_capture_after_eager_iterations_on_other_batches(cuda):
     assert torch.isfinite(tr.opt_d.grad).all() and torch.isfinite(tr.opt_g.grad).all()
 
 
+@pytest.mark.parametrize("preset,ragged,seed", [("small", True, 61), ("dataset", "jitter", 62)])
+def test_program_gnn_in_one_host_call_equals_op_by_op_path(cuda, preset, ragged, seed, monkeypatch):
+    """ops.ProgramStack (bg_pstack_forward_f32 / _backward_f32) against the op-by-op autograd ProgramGNN on identical
+    parameters and inputs: output rtol 2e-6 of its scale (the class-slot term is scaled once as ratio / count instead of
+    mean x ratio), every gradient to 2e-5 of its scale."""
+    from building_gan_amd import models as hm
+    from building_gan_amd.plan import build_plan
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup(preset, seed, ragged, cuda)
+    plan = build_plan(gpu)
+    torch.manual_seed(seed)
+    wgt = torch.rand(sz["Np"], 128, device=cuda) - 0.5
+    pg = Gh.programGNN
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(hm, "FUSE_PSTACK", on)
+        for p in pg.parameters():
+            p.grad = None
+        x = pg(gpu.program_class_feature, gpu.story_level_feature, gpu.program_target_ratio, pz.to(cuda), plan)
+        assert (type(x.grad_fn).__name__ == "ProgramStackBackward") == on
+        (x * wgt).sum().backward()
+        res.append((x.detach().clone(), {n: p.grad.detach().clone() for n, p in pg.named_parameters()}))
+    (x1, g1), (x0, g0) = res
+    assert float((x1 - x0).abs().max()) <= 2e-6 * float(x0.abs().max())
+    top = max(float(g.abs().max()) for g in g0.values())
+    for n in g0:
+        e = float((g1[n] - g0[n]).abs().max()) / max(float(g0[n].abs().max()), 1e-3 * top)
+        assert e <= 2e-5, (n, e)
+
+
 def test_fused_attention_forward_equals_unfused(cuda):
     """The one-launch Attention call of graph-free passes (bg_attention_fwd_f32) against the five-kernel
     autograd path on identical weights, inputs and noise: same pointers, activations to rounding."""

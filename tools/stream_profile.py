@@ -10,6 +10,8 @@ dev = torch.device("cuda:0")
 batches = [make_batch("dataset", seed=k, ragged="jitter").to(dev) for k in range(8)]
 torch.manual_seed(0)
 tr = Trainer(dev)
+if os.environ.get('BG_OVERLAP') == '1':
+    tr._overlap_stream = torch.cuda.Stream()
 def plan(b):
     b.__dict__.pop("_bg_plan", None); build_plan(b)
 for i in range(10):
