@@ -76,6 +76,8 @@ SIGNATURES = {
     "bg_fill_f32": [_p, _i64, _f, _p],
     "bg_critic_head_forward_f32": [_p, _f, _p, _i64, _p, _p],
     "bg_critic_head_backward_f32": [_p, _f, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "bg_gloss_head_forward_f32": [_p, _p, _i64, _i64, _p, _i64, _p, _p],
+    "bg_gloss_head_backward_f32": [_p, _i64, _p, _p, _i64, _p, _p],
     "bg_leaky_bwd_f32": [_p, _p, _f, _p, _i64, _p],
     "bg_rowscale_f32": [_p, _i64, _p, _p, _i64, _i64, _i64, _p],
     "bg_pstack_forward_f32": [_p, _p, _p, _p, _i64, _p, _p],
@@ -167,6 +169,8 @@ def load() -> C.CDLL:
     lib.bg_pstack_workspace.argtypes = [_i64] * 4
     lib.bg_gstack_workspace.restype = C.c_int64
     lib.bg_gstack_workspace.argtypes = [_i64] * 6
+    lib.bg_gloss_head_workspace.restype = C.c_int64
+    lib.bg_gloss_head_workspace.argtypes = [_p]
     lib.bg_critic_head_workspace.restype = C.c_int64
     lib.bg_critic_head_workspace.argtypes = [_p]
     lib.bg_abi_sizeof.restype = C.c_int64

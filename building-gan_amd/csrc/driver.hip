@@ -867,3 +867,102 @@ extern "C" int bg_pstack_backward_f32(const bgGeneratorWeights* w, const bgGener
     }
     return BG_OK;
 }
+
+// ---------------------------------------------------------------- generator objective through the frozen discriminator
+namespace {
+struct GLossBuffers {
+    float *Zl, *v, *Xs, *Xb, *hs, *hb, *vals, *valb, *part, *loss2, *dvb, *dvs, *dhb, *dXb, *T, *dhs, *dXs, *dZl, *gl;
+    int32_t *as, *ab;
+};
+GLossBuffers carve_gloss(Arena& ar, const bgCriticHead& h) {
+    const int64_t N = h.N, S = h.S, B = h.B, K1 = h.L + 1, dl = h.dl, H2 = h.H2, Hd = h.Hd;
+    GLossBuffers b;
+    b.Zl = ar.take(N * K1 * dl); b.v = ar.take(N * H2); b.Xs = ar.take(S * H2); b.Xb = ar.take(B * H2);
+    b.as = reinterpret_cast<int32_t*>(ar.take(S * H2)); b.ab = reinterpret_cast<int32_t*>(ar.take(B * H2));
+    b.hs = ar.take(S * Hd); b.hb = ar.take(B * Hd); b.vals = ar.take(S); b.valb = ar.take(B); b.part = ar.take(128);
+    b.loss2 = ar.take(4);
+    b.dvb = ar.take(B); b.dvs = ar.take(S); b.dhb = ar.take(B * Hd); b.dXb = ar.take(B * H2); b.T = ar.take(S * H2);
+    b.dhs = ar.take(S * Hd); b.dXs = ar.take(S * H2); b.dZl = ar.take(N * K1 * dl); b.gl = ar.take(N * dl);
+    return b;
+}
+}  // namespace
+
+extern "C" int64_t bg_gloss_head_workspace(const bgCriticHead* h) {
+    if (!h || critic_shape_ok(*h) != BG_OK) return -1;
+    Arena ar{nullptr, 0, 0};
+    carve_gloss(ar, *h);
+    return ar.used + 64;
+}
+
+extern "C" int bg_gloss_head_forward_f32(const bgCriticHead* hp, const float* label, int64_t ldl, int64_t n_lab,
+                                         float* workspace, int64_t workspace_floats, float* loss, bgStream s) {
+    if (!hp || !label || !workspace || !loss) return BG_ERR_ARG;
+    const bgCriticHead& h = *hp;
+    int rc = critic_shape_ok(h);
+    if (rc != BG_OK) return rc;
+    if (n_lab <= 0 || n_lab > h.dl || ldl < n_lab) return BG_ERR_ARG;
+    if (!h.Zs || !h.W || !h.b_w1 || !h.b_b1 || !h.b_w2 || !h.b_b2 || !h.s_w1 || !h.s_b1 || !h.s_w2 || !h.s_b2 || !h.wb || !h.ws ||
+        !h.st_rowptr || !h.st_col || !h.sg_rowptr || !h.sg_col || !h.a_rowptr || !h.a_col || !h.a_count || !h.blk_ptr)
+        return BG_ERR_ARG;
+    if (!bg_aligned16(workspace)) return BG_ERR_ALIGN;
+    Arena ar{workspace, 0, workspace_floats};
+    GLossBuffers b = carve_gloss(ar, h);
+    if (ar.used > workspace_floats) return BG_ERR_ARG;
+    const int64_t N = h.N, S = h.S, B = h.B, K1 = h.L + 1, ds = h.ds, dl = h.dl, H2 = h.H2, Hd = h.Hd;
+    const int64_t ldz = K1 * dl;
+    {   // label into column group 0 (zero-padded to dl), then the powers of A
+        const float* src[4] = {label, nullptr, nullptr, nullptr};
+        const int64_t lds[4] = {ldl, 0, 0, 0};
+        BG_TRY(bg_pack_columns_f32(src, lds, 1, n_lab, dl, b.Zl, ldz, N, s));
+    }
+    BG_TRY(bg_spmm_chain_f32(b.Zl, ldz, h.a_rowptr, h.a_col, h.a_count, BG_SCALE_DIV, nullptr, BG_SCALE_NONE, h.blk_ptr, h.blk_n,
+                             h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg, nullptr, 0, 0, b.Zl + dl, ldz, dl, h.L, dl, s));
+    {
+        const float* A[4] = {h.Zs, b.Zl, nullptr, nullptr};
+        const int64_t ld[4] = {K1 * ds, ldz, 0, 0}, Ks[4] = {K1 * ds, ldz, 0, 0};
+        BG_TRY(bg_gemm_f32(0, 0, N, H2, 2, A, ld, Ks, h.W, H2, b.v, H2, nullptr, nullptr, BG_ACT_NONE, 0.f, nullptr, 0, nullptr, 0,
+                           nullptr, nullptr, 0, nullptr, 0, s));
+    }
+    BG_TRY(bg_segmax_f32(b.v, H2, h.st_rowptr, h.st_col, nullptr, 0, 0, nullptr, nullptr, b.Xs, H2, b.as, S, H2, s));
+    BG_TRY(bg_segmax_f32(b.Xs, H2, h.sg_rowptr, h.sg_col, nullptr, 0, 0, nullptr, nullptr, b.Xb, H2, b.ab, B, H2, s));
+    BG_TRY(dec_linear(S, Hd, H2, b.Xs, h.s_w1, h.s_b1, b.hs, s));
+    BG_TRY(dec_linear(S, 1, Hd, b.hs, h.s_w2, h.s_b2, b.vals, s));
+    BG_TRY(dec_linear(B, Hd, H2, b.Xb, h.b_w1, h.b_b1, b.hb, s));
+    BG_TRY(dec_linear(B, 1, Hd, b.hb, h.b_w2, h.b_b2, b.valb, s));
+    BG_TRY(bg_critic_loss_f32(b.valb, h.wb, B, b.vals, h.ws, S, nullptr, 0, 0, 0, 0.f, b.part, loss, s));
+    return BG_OK;
+}
+
+extern "C" int bg_gloss_head_backward_f32(const bgCriticHead* hp, int64_t n_lab, const float* go, float* workspace,
+                                          int64_t workspace_floats, float* g_label, bgStream s) {
+    if (!hp || !go || !workspace || !g_label) return BG_ERR_ARG;
+    const bgCriticHead& h = *hp;
+    int rc = critic_shape_ok(h);
+    if (rc != BG_OK) return rc;
+    if (n_lab <= 0 || n_lab > h.dl) return BG_ERR_ARG;
+    if (!h.story_of_voxel || !h.graph_of_story || !h.at_rowptr || !h.at_col) return BG_ERR_ARG;
+    if (!bg_aligned16(workspace)) return BG_ERR_ALIGN;
+    Arena ar{workspace, 0, workspace_floats};
+    GLossBuffers b = carve_gloss(ar, h);
+    if (ar.used > workspace_floats) return BG_ERR_ARG;
+    const int64_t N = h.N, S = h.S, B = h.B, K1 = h.L + 1, ds = h.ds, dl = h.dl, H2 = h.H2, Hd = h.Hd;
+    const int64_t ldz = K1 * dl;
+    const float* Wl = h.W + K1 * ds * H2;
+    BG_TRY(bg_critic_loss_bwd_f32(go, h.wb, B, h.ws, S, nullptr, 0, 0, 0, 0.f, b.dvb, b.dvs, nullptr, s));
+    BG_TRY(mm(B, Hd, 1, b.dvb, 1, h.b_w2, Hd, 0, b.dhb, nullptr, nullptr, s));
+    BG_TRY(mm(B, H2, Hd, b.dhb, Hd, h.b_w1, H2, 0, b.dXb, nullptr, nullptr, s));
+    BG_TRY(bg_scatter_arg_f32(b.dXb, H2, b.ab, h.graph_of_story, b.T, H2, B, S, H2, s));
+    BG_TRY(mm(S, Hd, 1, b.dvs, 1, h.s_w2, Hd, 0, b.dhs, nullptr, nullptr, s));
+    BG_TRY(mm(S, H2, Hd, b.dhs, Hd, h.s_w1, H2, 0, b.dXs, nullptr, b.T, s));
+    BG_TRY(bg_scatter_arg_f32(b.dXs, H2, b.as, h.story_of_voxel, b.v, H2, S, N, H2, s));          // v is free: it takes d v
+    BG_TRY(mm(N, ldz, H2, b.v, H2, Wl, H2, 1, b.dZl, nullptr, nullptr, s));                       // d Zl = d v Wl^T
+    BG_TRY(bg_spmm_chain_f32(b.dZl + h.L * dl, ldz, h.at_rowptr, h.at_col, nullptr, BG_SCALE_NONE, h.a_count, BG_SCALE_DIV,
+                             h.blk_ptr, h.blk_n, h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg,
+                             b.dZl + (h.L - 1) * dl, ldz, -dl, b.gl, dl, 0, h.L, dl, s));
+    {
+        const float* src[4] = {b.gl, nullptr, nullptr, nullptr};
+        const int64_t lds[4] = {dl, 0, 0, 0};
+        BG_TRY(bg_pack_columns_f32(src, lds, 1, n_lab, n_lab, g_label, n_lab, N, s));
+    }
+    return BG_OK;
+}

@@ -876,6 +876,33 @@ class DiscriminatorVoxel(nn.Module):
         return ops.CriticHead.apply(W.contiguous(), bd[0].weight, bd[0].bias, bd[1].weight, bd[1].bias, sd[0].weight,
                                     sd[0].bias, sd[1].weight, sd[1].bias, Zs, Zk, plan, wb, ws, coef, gnn.layer_num, ds, dl)
 
+    def generator_objective(self, graph, label, wb, ws):
+        """<D_building(label), wb> + <D_story(label), ws> for the generator update (the discriminator frozen: only
+        ``label`` is differentiated), everything below the coefficient table by ONE host call each way
+        (ops.GLossHead).  None where it does not apply; the caller then calls forward() and forms the sums."""
+        plan = build_plan(graph)
+        gnn = self.voxelGNN_D
+        if not (FUSE_CRITIC_HEAD and COLLAPSE_D and gnn.collapse_ok and COMPOSE_BLOCKS and plan.vox_all_has
+                and gnn.layer_num > 0 and self.piecewise_linear and not any(p.requires_grad for p in self.parameters())):
+            return None
+        blocks, st, sg = plan.vox_blocks, plan.story_seg, plan.story_graph_seg
+        if (blocks is None or not plan.stories_all_nonempty or not st.row_per_workgroup or not sg.row_per_workgroup
+                or len(self.building_dec) != 2 or len(self.story_dec) != 2 or blocks.max_deg > 8):
+            return None
+        pos, feat = extract_pos(graph.voxel_feature)
+        pdm4 = _pos_terms(plan, pos)
+        L = gnn.layer_num
+        dl = (label.shape[1] + 3) // 4 * 4
+        with torch.no_grad():
+            Zs = gnn._static_powers(plan, feat, pdm4)
+            ds = Zs.shape[1] // (L + 1)
+            W = gnn.coefficients(feat.shape[1], ds, dl)
+        if not ops._chain_fits(plan.vox_mean, blocks, dl) or W.shape[1] % 4 != 0:
+            return None
+        bd, sd = self.building_dec, self.story_dec
+        return ops.GLossHead.apply(label, W.contiguous(), bd[0].weight, bd[0].bias, bd[1].weight, bd[1].bias, sd[0].weight,
+                                   sd[0].bias, sd[1].weight, sd[1].bias, Zs, plan, wb, ws, L, ds, dl)
+
     # fp32 error of the collapsed form relative to a column's largest activation ~ 2^-24 * amplification (measured:
     # tests/test_gpu_models.py::test_collapsed_discriminator_guard); beyond this bound the polynomial form would lose
     # more than north_star's 1e-4 and the layer-by-layer stack (ops.AffineStack: the reference's own evaluation order)

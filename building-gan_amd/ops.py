@@ -1310,6 +1310,63 @@ class CriticLoss(torch.autograd.Function):
         return db, ds, dg, None, None, None
 
 
+def _critic_head_struct(plan, N, L, ds, dl, H2, Hd, Zs, Zk, W, dec_b, dec_s, wb, ws):
+    """include/bgan.h bgCriticHead for a plan and the given operands (raw addresses: the caller keeps them alive)."""
+    blocks, st, sg = plan.vox_blocks, plan.story_seg, plan.story_graph_seg
+    A, AT = plan.vox_mean, plan.vox_mean.T
+    if blocks is None or st.seg_of is None or sg.seg_of is None or plan.graph_seg.seg_of is None:
+        raise _lib.BganError("critic_head: the plan lacks diagonal blocks / segment tables")
+    return _lib.CriticHead(N, plan.S, plan.B, L, ds, dl, H2, Hd, blocks.n, blocks.max_rows, blocks.max_nnz, blocks.max_deg,
+                           ptr(Zs), ptr(Zk), ptr(W), *[ptr(t) for t in dec_b], *[ptr(t) for t in dec_s], ptr(wb), ptr(ws),
+                           ptr(st.rowptr), ptr(st.col), ptr(st.seg_of), ptr(sg.rowptr), ptr(sg.col), ptr(sg.seg_of),
+                           ptr(plan.graph_seg.seg_of), ptr(A.csr.rowptr), ptr(A.csr.col), ptr(A.row_scale),
+                           ptr(AT.csr.rowptr), ptr(AT.csr.col), ptr(blocks.ptr))
+
+
+class GLossHead(torch.autograd.Function):
+    """The generator's adversarial objective through the frozen collapsed discriminator,
+    <D_building(label), wb> + <D_story(label), ws>, as ONE host call each way (bg_gloss_head_forward_f32 / _backward_f32):
+    the only differentiable input is ``label`` [N, n_lab] (the generated labels); W, the decoders, Zs are data here."""
+
+    @staticmethod
+    def forward(ctx, label, W, bw1, bb1, bw2, bb2, sw1, sb1, sw2, sb2, Zs, plan, wb, ws, L: int, ds: int, dl: int):
+        lib = _lib.load()
+        _lib.require_device(label, "gloss_head")
+        label = _f32c(label)
+        ts = (W, bw1, bb1, bw2, bb2, sw1, sb1, sw2, sb2, Zs, wb, ws)
+        if any(t.dtype != torch.float32 or not t.is_contiguous() for t in ts):
+            raise _lib.BganError("gloss_head: contiguous fp32 operands")
+        N, n_lab = label.shape
+        H2, Hd = W.shape[1], bw1.shape[0]
+        if (N != plan.Nv or tuple(W.shape) != ((L + 1) * (ds + dl), H2) or tuple(Zs.shape) != (N, (L + 1) * ds) or n_lab > dl
+                or wb.numel() < plan.B or ws.numel() < plan.S):
+            raise _lib.BganError("gloss_head: operand shapes do not fit the plan / the coefficient table")
+        h = _critic_head_struct(plan, N, L, ds, dl, H2, Hd, Zs, None, W, (bw1, bb1, bw2, bb2), (sw1, sb1, sw2, sb2), wb, ws)
+        n_ws = lib.bg_gloss_head_workspace(C.byref(h))
+        if n_ws < 0:
+            raise _lib.BganError("gloss_head: sizes not supported")
+        work = torch.empty(n_ws, dtype=torch.float32, device=label.device)
+        loss = torch.empty(2, dtype=torch.float32, device=label.device)
+        check(lib.bg_gloss_head_forward_f32(C.byref(h), ptr(label), _ld(label), n_lab, ptr(work), n_ws, ptr(loss), stream()),
+              "bg_gloss_head_forward_f32")
+        ctx.h, ctx.work, ctx.n_ws, ctx.shape = h, work, n_ws, (N, n_lab)
+        ctx.keep = (Zs, wb, ws, plan)
+        ctx.save_for_backward(W, bw1, bb1, bw2, bb2, sw1, sb1, sw2, sb2)
+        return loss[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go):
+        lib = _lib.load()
+        go = _f32c(go.reshape(1))
+        N, n_lab = ctx.shape
+        g = torch.empty(N, n_lab, dtype=torch.float32, device=go.device)
+        check(lib.bg_gloss_head_backward_f32(C.byref(ctx.h), n_lab, ptr(go), ptr(ctx.work), ctx.n_ws, ptr(g), stream()),
+              "bg_gloss_head_backward_f32")
+        ctx.work = None
+        return (g,) + (None,) * 16
+
+
 class ProgramStack(torch.autograd.Function):
     """ProgramGNN.forward -- encoder and every ProgramBlock call with its residual -- as ONE autograd node whose
     forward and backward are one host call each (bg_pstack_forward_f32 / _backward_f32).  First-order autograd.

@@ -360,8 +360,15 @@ class Trainer:
         for p in self.opt_d.params:
             p.requires_grad = False
         self.opt_g.detach_grads()
-        val_b, val_s = self.discriminator(batch, out)
-        g_loss = self._g_adversarial(val_b, val_s, Bg, Sg)
+        g_loss = None
+        plan = batch.__dict__.get("_bg_plan") if hasattr(batch, "__dict__") else None
+        if self.gan_loss in ("WGANGP", "hinge") and plan is not None and hasattr(self.discriminator, "generator_objective"):
+            # -E[D_building] - E[D_story] through the frozen discriminator: one host call each way
+            wb, ws = self._critic_weights(plan.B, plan.S, Bg, Sg, out.device)      # first halves: -1/count
+            g_loss = self.discriminator.generator_objective(batch, out, wb, ws)
+        if g_loss is None:
+            val_b, val_s = self.discriminator(batch, out)
+            g_loss = self._g_adversarial(val_b, val_s, Bg, Sg)
         stats = {"g_adv": g_loss.detach()}
         # get_program_ratio runs in every G step although its losses have zero weight by default (losses.py:65)
         ratio, _, far = self.program_ratio_fn(batch, att["hard"], mask["hard"], 6)

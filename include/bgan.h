@@ -646,6 +646,19 @@ int bg_critic_head_backward_f32(const bgCriticHead* h, float coef, const float* 
                                 int64_t workspace_floats, float* gW, float* g_b_w1, float* g_b_b1, float* g_b_w2,
                                 float* g_b_b2, float* g_s_w1, float* g_s_b1, float* g_s_w2, float* g_s_b2, bgStream stream);
 
+/* The generator's adversarial objective through the (frozen) collapsed discriminator as ONE host call each way:
+ * label [N, n_lab] (pitch ldl; the generated labels, differentiable) -> its operator powers -> v = [Zs | Zl] W -> story /
+ * graph max pooling -> decoders -> loss[0] = <D_building, wb[0..B)> + <D_story, ws[0..S)> (loss: 2 floats, the second is 0); the backward writes
+ * g_label [N, n_lab] (contiguous) = go[0] * d loss / d label.  h as for bg_critic_head_* (Zk is not read; wb / ws: the
+ * first B / S entries are used).  Workspace shared by both calls: bg_gloss_head_workspace(h) floats.
+ * replaces: discriminator(batch, out) + VolumetricDesignLoss_G's adversarial term and their backward down to the
+ * generated labels, train.py:108-112 with Model/losses.py:52-61.                                                  */
+int64_t bg_gloss_head_workspace(const bgCriticHead* h);
+int bg_gloss_head_forward_f32(const bgCriticHead* h, const float* label, int64_t ldl, int64_t n_lab, float* workspace,
+                              int64_t workspace_floats, float* loss, bgStream stream);
+int bg_gloss_head_backward_f32(const bgCriticHead* h, int64_t n_lab, const float* go, float* workspace,
+                               int64_t workspace_floats, float* g_label, bgStream stream);
+
 /* ------------------------------------------------------------------ optimiser ----------- */
 
 /* One Adam step on a flat fp32 buffer (torch.optim.Adam semantics, no weight decay/amsgrad):

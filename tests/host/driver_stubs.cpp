@@ -190,9 +190,9 @@ int bg_fill_f32(float* p, int64_t n, float, bgStream) {
 }
 int bg_pack_columns_f32(const float* const* src, const int64_t* ld, int n_src, int64_t C, int64_t group, float* dst,
                         int64_t ldd, int64_t n, bgStream) {
-    int64_t a[] = {P(dst), ldd * 4, P(src[0]), ld[0] * 4, C * 4, n};          // as a strided copy: kind 20's layout
+    int64_t a[] = {P(dst), ldd * 4, P(src[0]), ld[0] * 4, group * 4, n};      // as a strided copy: kind 20's layout (dst width)
     rec(20, a, sizeof(a) / 8);
-    return (n_src == 1 && group == C) ? 0 : -1;
+    return (n_src == 1 && group >= C) ? 0 : -1;
 }
 int hipMemsetAsync(void* dst, int value, size_t bytes, void*) {
     int64_t a[] = {P(dst), value, (int64_t)bytes};

@@ -26,7 +26,7 @@ def test_python_binding_covers_the_header():
     from building_gan_amd import _lib
     # (functions that do not return an int status are bound by hand in _lib.load())
     declared = set(_declared()) - {"bg_version", "bg_error_string", "bg_abi_sizeof", "bg_generator_forward_workspace",
-                                    "bg_d_coef_backward_workspace", "bg_critic_head_workspace", "bg_gstack_workspace", "bg_pstack_workspace"}
+                                    "bg_d_coef_backward_workspace", "bg_critic_head_workspace", "bg_gstack_workspace", "bg_pstack_workspace", "bg_gloss_head_workspace"}
     assert declared == set(_lib.SIGNATURES.keys())
     lib = _lib.load()
     assert lib.bg_version() >= 1

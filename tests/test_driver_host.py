@@ -816,3 +816,51 @@ def test_pstack_host_sequence_and_extents(drv, Np, L):
             R.check(x, ((n - 1) * ldx + Hh) * f, tag); R.check(sc, n * f, tag); R.check(out, ((n - 1) * ldo + Hh) * f, tag)
         else:
             raise AssertionError("unexpected launcher %d" % kind)
+
+
+
+@pytest.mark.parametrize("N,S,B", [(11520, 80, 8), (1001, 17, 3)])
+def test_gloss_head_host_sequence_and_extents(drv, N, S, B):
+    """bg_gloss_head_*: same struct as the critic head; label [N, 6] in, d label out."""
+    (rc_f, rc_b), _, _, R, h = _critic_run(drv, N, S, B)
+    assert rc_f == 0 and rc_b == 0
+    f = 4
+    drv.bg_gloss_head_workspace.restype = C.c_int64
+    drv.bg_gloss_head_workspace.argtypes = [C.c_void_p]
+    nws = drv.bg_gloss_head_workspace(C.byref(h))
+    assert nws > 0
+    R.r.pop("workspace"); R.r.pop("loss")
+    work, label, loss = R.new("workspace", nws * f), R.new("label", N * 6 * f), R.new("loss", 2 * f)
+    drv.bg_gloss_head_forward_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    drv.bg_gloss_head_backward_f32.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+
+    def calls_of(fn, *args):
+        drv.stub_reset()
+        rc = fn(*args)
+        return rc, [(drv.stub_call(i)[0], [drv.stub_call(i)[2 + k] for k in range(drv.stub_call(i)[1])])
+                    for i in range(drv.stub_count())]
+    rc, fwd = calls_of(drv.bg_gloss_head_forward_f32, C.byref(h), label, 6, 6, work, nws, loss, None)
+    assert rc == 0 and [k for k, _ in fwd] == [20, 14, 1, 11, 11, 1, 1, 1, 1, 15]
+    R.r.pop("go")
+    rc, bwd = calls_of(drv.bg_gloss_head_backward_f32, C.byref(h), 6, R.new("go", f), work, nws, R.new("g_label", N * 6 * f), None)
+    assert rc == 0 and [k for k, _ in bwd] == [16, 1, 1, 13, 1, 1, 13, 1, 14, 20]
+    # the generic checker of the critic head covers every launcher used here, except: two-segment product, no penalty
+    for kind, a in fwd + bwd:
+        if kind == 1 and a[4] == 2:
+            (tA, tB, M, Nn, n_seg), A, lda, Ks = a[0:5], a[5:9], a[9:13], a[13:17]
+            for sgm in range(2):
+                R.check(A[sgm], ((M - 1) * lda[sgm] + Ks[sgm]) * f, "two-segment A%d" % sgm)
+            R.check(a[17], ((Ks[0] + Ks[1] - 1) * a[18] + Nn) * f, "two-segment B")
+            R.check(a[19], ((M - 1) * a[20] + Nn) * f, "two-segment C")
+        elif kind == 15:
+            assert a[6] == 0 and a[8] == 0 and R.check(a[11], 2 * f, "loss") == "loss"
+            R.check(a[0], a[2] * f, "val_b"); R.check(a[3], a[5] * f, "val_s")
+        elif kind == 16:
+            assert a[5] == 0 and a[11] == 0
+            R.check(a[9], a[2] * f, "d_val_b"); R.check(a[10], a[4] * f, "d_val_s")
+        elif kind == 20:
+            dst, dp, src, sp, width, height = a
+            R.check(dst, (height - 1) * dp + width, "copy dst"); R.check(src, (height - 1) * sp + min(width, sp), "copy src")
+        else:
+            _check_critic_calls([(kind, a)], R, h)
+    assert R.check([a for k, a in bwd if k == 20][0][0], 4, "dst") == "g_label"

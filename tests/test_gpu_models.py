@@ -646,6 +646,35 @@ def test_program_gnn_in_one_host_call_equals_op_by_op_path(cuda, preset, ragged,
         assert e <= 2e-5, (n, e)
 
 
+@pytest.mark.parametrize("preset,ragged,seed", [("small", True, 71), ("dataset", "jitter", 72)])
+def test_generator_objective_in_one_host_call_equals_op_by_op_path(cuda, preset, ragged, seed):
+    """ops.GLossHead (bg_gloss_head_forward_f32 / _backward_f32) against discriminator(batch, label) + the sums of
+    VolumetricDesignLoss_G under autograd, the discriminator frozen: value rtol 1e-6, d / d label to 2e-5 of its max."""
+    from building_gan_amd.plan import build_plan
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup(preset, seed, ragged, cuda)
+    torch.manual_seed(seed)
+    Nv = sz["Nv"]
+    plan = build_plan(gpu)
+    B, S = plan.B, plan.S
+    for p in Dh.parameters():
+        p.requires_grad = False
+    wb = torch.full((2 * B,), -1.0 / B, device=cuda)
+    ws = torch.full((2 * S,), -1.0 / S, device=cuda)
+    base = torch.rand(Nv, 6, device=cuda)
+    la = base.clone().requires_grad_(True)
+    vb, vs = Dh(gpu, la)
+    l0 = -vb.sum() / B - vs.sum() / S
+    l0.backward()
+    plan.begin_iteration()
+    lb = base.clone().requires_grad_(True)
+    l1 = Dh.generator_objective(gpu, lb, wb, ws)
+    assert l1 is not None, "the one-call path declined this batch"
+    l1.backward()
+    torch.testing.assert_close(l1.detach().cpu(), l0.detach().cpu(), rtol=1e-6, atol=1e-7)
+    assert float((lb.grad - la.grad).abs().max()) <= 2e-5 * float(la.grad.abs().max())
+    assert float(la.grad.abs().max()) > 0
+
+
 def test_fused_attention_forward_equals_unfused(cuda):
     """The one-launch Attention call of graph-free passes (bg_attention_fwd_f32) against the five-kernel
     autograd path on identical weights, inputs and noise: same pointers, activations to rounding."""
