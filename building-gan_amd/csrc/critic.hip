@@ -285,6 +285,11 @@ __global__ void k_rowscale(const float* __restrict__ x, int64_t ldx, const float
     *reinterpret_cast<float4*>(out + r * ldo + 4 * c) = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
 }
 
+__global__ void k_iota_mod(int32_t* __restrict__ out, int64_t n, int32_t mod) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = (int32_t)(t % mod);
+}
+
 __global__ void k_add(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out, int64_t n4) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n4) return;
@@ -340,6 +345,15 @@ int bg_rowscale_f32(const float* x, int64_t ldx, const float* scale, float* out,
     if (H % 4 != 0 || ldx % 4 != 0 || ldo % 4 != 0) return BG_ERR_SHAPE;
     if (!bg_aligned16(x) || !bg_aligned16(out)) return BG_ERR_ALIGN;
     k_rowscale<<<bg_grid_for(n * (H / 4), 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(x, ldx, scale, out, ldo, n, (int)(H / 4));
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_iota_mod_i32(int32_t* out, int64_t n, int64_t mod, bgStream stream) {
+    if (n < 0 || mod <= 0 || mod >= ((int64_t)1 << 31)) return BG_ERR_ARG;
+    if (n == 0) return BG_OK;
+    if (!out) return BG_ERR_ARG;
+    k_iota_mod<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(out, n, (int32_t)mod);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -241,8 +241,8 @@ namespace {
 
 struct CriticBuffers {
     // forward (kept for the backward)
-    float *Zp[3], *Sb, *v[3], *Xs, *Xb, *hs, *hb, *vals, *valb, *hat_s, *hat_b, *gp_b, *gp_s, *G2, *X, *Ys, *acc, *part;
-    int32_t *as, *ab, *arg_s, *arg_sb, *arg_b;
+    float *Zp[3], *Sb, *v[3], *dS, *Xs, *Xb, *hs, *hb, *vals, *valb, *hat_s, *hat_b, *gp_b, *gp_s, *G2, *X, *Ys, *acc, *part;
+    int32_t *as, *ab, *arg_s, *arg_sb, *arg_b, *idx3;
     // backward
     float *dvb, *dvs, *dacc, *dYs, *dX, *dG2, *dgp_b, *dgp_s, *c_b, *c_s, *dhs, *dhb, *dXs, *dXb, *T, *splitk, *colsum;
 };
@@ -266,10 +266,16 @@ int32_t colsum_blocks(int64_t M) {                              // ops.colsum_ra
 CriticBuffers carve_critic(Arena& ar, const bgCriticHead& h) {
     const int64_t N = h.N, S = h.S, B = h.B, K1 = h.L + 1, ds = h.ds, dl = h.dl, H2 = h.H2, Hd = h.Hd;
     CriticBuffers b;
-    b.Zp[0] = ar.take(3 * N * K1 * dl);            // [3, N, K1 dl]: one piece, bg_regroup_f32 writes all three
+    // [4, N, K1 dl] in one piece: the three label sets' powers (bg_regroup_f32 writes them side by side; one product
+    // reads them as 3 N rows); in the backward d X [2 N, K1 dl] takes slots 2..3 (the sample's powers are done by then),
+    // so that the label rows' gradient is ONE product over the 4 N rows [Zp0; Zp1; dX]^T [dv0; dv1; G2]
+    b.Zp[0] = ar.take(4 * N * K1 * dl);
     b.Zp[1] = b.Zp[0] ? b.Zp[0] + N * K1 * dl : nullptr; b.Zp[2] = b.Zp[0] ? b.Zp[0] + 2 * N * K1 * dl : nullptr;
     b.Sb = ar.take(N * H2);
-    for (int p = 0; p < 3; ++p) b.v[p] = ar.take(N * H2);
+    b.v[0] = ar.take(4 * N * H2);                  // [v0; v1; v2 | G2 (2 N rows, written after v2 has been pooled)]
+    b.v[1] = b.v[0] ? b.v[0] + N * H2 : nullptr; b.v[2] = b.v[0] ? b.v[0] + 2 * N * H2 : nullptr;
+    b.dS = ar.take(N * H2);
+    b.idx3 = reinterpret_cast<int32_t*>(ar.take(3 * N));
     b.Xs = ar.take(2 * S * H2); b.Xb = ar.take(2 * B * H2);
     b.as = reinterpret_cast<int32_t*>(ar.take(2 * S * H2)); b.ab = reinterpret_cast<int32_t*>(ar.take(2 * B * H2));
     b.hs = ar.take(2 * S * Hd); b.hb = ar.take(2 * B * Hd); b.vals = ar.take(2 * S); b.valb = ar.take(2 * B);
@@ -277,17 +283,17 @@ CriticBuffers carve_critic(Arena& ar, const bgCriticHead& h) {
     b.arg_s = reinterpret_cast<int32_t*>(ar.take(S * H2)); b.arg_sb = reinterpret_cast<int32_t*>(ar.take(B * H2));
     b.arg_b = reinterpret_cast<int32_t*>(ar.take(B * H2));
     b.gp_b = ar.take(H2); b.gp_s = ar.take(H2);
-    b.G2 = ar.take(2 * N * H2); b.X = ar.take(2 * N * K1 * dl); b.Ys = ar.take(N * K1 * 2 * dl); b.acc = ar.take(N * 2 * dl);
+    b.G2 = b.v[2]; b.X = ar.take(2 * N * K1 * dl); b.Ys = ar.take(N * K1 * 2 * dl); b.acc = ar.take(N * 2 * dl);
     b.part = ar.take(128);
     b.dvb = ar.take(2 * B); b.dvs = ar.take(2 * S); b.dacc = ar.take(N * 2 * dl);
-    b.dYs = ar.take(N * K1 * 2 * dl); b.dX = ar.take(2 * N * K1 * dl); b.dG2 = ar.take(2 * N * H2);
+    b.dYs = ar.take(N * K1 * 2 * dl); b.dX = b.Zp[2]; b.dG2 = ar.take(2 * N * H2);
     b.dgp_b = ar.take(B * H2); b.dgp_s = ar.take(S * H2); b.c_b = ar.take(H2); b.c_s = ar.take(H2);
     b.dhs = ar.take(2 * S * Hd); b.dhb = ar.take(2 * B * Hd); b.dXs = ar.take(2 * S * H2); b.dXb = ar.take(2 * B * H2);
     b.T = ar.take(2 * S * H2);
     // largest split-K partial of the backward's weight-gradient products
     int64_t sk = 0;
     auto need = [&](int64_t M, int64_t Nn, int64_t R) { const int64_t x = (int64_t)tn_splits(M, Nn, R) * M * Nn; if (x > sk) sk = x; };
-    need(K1 * dl, H2, 2 * N); need(K1 * dl, H2, N); need(K1 * ds, H2, N);
+    need(K1 * dl, H2, 4 * N); need(K1 * ds, H2, N);
     need(1, Hd, 2 * S); need(Hd, H2, 2 * S); need(1, Hd, 2 * B); need(Hd, H2, 2 * B);
     b.splitk = ar.take(sk);
     b.colsum = ar.take(256 * (H2 > Hd ? H2 : Hd));
@@ -353,8 +359,13 @@ extern "C" int bg_critic_head_forward_f32(const bgCriticHead* hp, float coef, fl
     BG_TRY(bg_regroup_f32(h.Zk, b.Zp[0], N, K1, 3, dl, 1, s));
     // label-free part once, then one thin product per label set on top of it (models.py collapsed_multi)
     BG_TRY(mm(N, H2, K1 * ds, h.Zs, K1 * ds, Ws, H2, 0, b.Sb, nullptr, nullptr, s));
-    for (int p = 0; p < 3; ++p)
-        BG_TRY(mm(N, H2, K1 * dl, b.Zp[p], K1 * dl, Wl, H2, 0, b.v[p], b.Sb, nullptr, s));
+    {   // all three sets in one product over 3 N rows; row r adds S[r mod N]
+        BG_TRY(bg_iota_mod_i32(b.idx3, 3 * N, N, s));
+        const float* A[4] = {b.Zp[0], nullptr, nullptr, nullptr};
+        const int64_t ld[4] = {K1 * dl, 0, 0, 0}, Ks[4] = {K1 * dl, 0, 0, 0};
+        BG_TRY(bg_gemm_f32(0, 0, 3 * N, H2, 1, A, ld, Ks, Wl, H2, b.v[0], H2, nullptr, nullptr, BG_ACT_NONE, 0.f, nullptr, 0,
+                           b.Sb, H2, b.idx3, nullptr, 0, nullptr, 0, s));
+    }
     // D(real), D(fake): max over each story, then over the stories of each graph; both sets share one run of a decoder
     for (int p = 0; p < 2; ++p) {
         BG_TRY(bg_segmax_f32(b.v[p], H2, h.st_rowptr, h.st_col, nullptr, 0, 0, nullptr, nullptr, b.Xs + p * S * H2, H2,
@@ -418,7 +429,6 @@ extern "C" int bg_critic_head_backward_f32(const bgCriticHead* hp, float coef, c
                              nullptr, 0, 0, b.dYs + W2c, ldy, W2c, h.L, W2c, s));
     BG_TRY(bg_regroup_f32(b.dYs, b.dX, N, K1, 2, dl, 1, s));
     BG_TRY(mm(2 * N, H2, K1 * dl, b.dX, K1 * dl, Wl, H2, 0, b.dG2, nullptr, nullptr, s));                   // d G2 = dX Wl
-    BG_TRY(tn(K1 * dl, H2, 2 * N, b.dX, b.G2, gWl, b.splitk, 0, s));                                        // gWl  = dX^T G2
     BG_TRY(bg_gather_arg_f32(b.dG2, H2, b.arg_b, b.dgp_b, H2, B, H2, s));
     BG_TRY(bg_gather_arg_f32(b.dG2 + N * H2, H2, b.arg_s, b.dgp_s, H2, S, H2, s));
     // every row of d D / d pooled is the same W2 W1: its gradient is the column sum c; g W1 = W2^T c, g W2 = c W1^T
@@ -451,12 +461,12 @@ extern "C" int bg_critic_head_backward_f32(const bgCriticHead* hp, float coef, c
     BG_TRY(bg_colsum_f32(b.dhs, Hd, 2 * S, Hd, b.colsum, colsum_blocks(2 * S), g_s_b1, 0, s));
     BG_TRY(mm(2 * S, H2, Hd, b.dhs, Hd, h.s_w1, H2, 0, b.dXs, nullptr, b.T, s));          // + what arrived through the buildings
     // to the arg-max voxels (v[0], v[1] are free after the forward's pooling: they take d v), then the coefficient table
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < 2; ++p)
         BG_TRY(bg_scatter_arg_f32(b.dXs + p * S * H2, H2, b.as + p * S * H2, h.story_of_voxel, b.v[p], H2, S, N, H2, s));
-        BG_TRY(tn(K1 * dl, H2, N, b.Zp[p], b.v[p], gWl, b.splitk, 1, s));
-    }
-    BG_TRY(bg_add_f32(b.v[0], b.v[1], b.v[2], N * H2, s));
-    BG_TRY(tn(K1 * ds, H2, N, h.Zs, b.v[2], gWs, b.splitk, 0, s));
+    // label rows: Zp0^T dv0 + Zp1^T dv1 + dX^T G2 as one product over the 4 N stacked rows
+    BG_TRY(tn(K1 * dl, H2, 4 * N, b.Zp[0], b.v[0], gWl, b.splitk, 0, s));
+    BG_TRY(bg_add_f32(b.v[0], b.v[1], b.dS, N * H2, s));
+    BG_TRY(tn(K1 * ds, H2, N, h.Zs, b.dS, gWs, b.splitk, 0, s));
     return BG_OK;
 }
 

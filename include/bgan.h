@@ -601,6 +601,10 @@ int bg_regroup_f32(const float* src, float* dst, int64_t n, int64_t K, int64_t P
  * stack issue kernels only, no runtime memset / memcpy nodes). */
 int bg_fill_f32(float* p, int64_t n, float value, bgStream stream);
 
+/* out[i] = i mod `mod` (int32): the row index that lets ONE product over several row-stacked label sets read the
+ * same [mod, N] addend (bg_gemm_f32's pre_add_rows).  No reference counterpart (see bg_regroup_f32).            */
+int bg_iota_mod_i32(int32_t* out, int64_t n, int64_t mod, bgStream stream);
+
 /* out = a + b over n floats (n % 4 == 0, 16-byte aligned): the one elementwise sum the critic's backward needs
  * (the gradients of D(real) and D(fake) with respect to the shared label-free part).
  * replaces: autograd's gradient accumulation for a tensor used twice.                                      */

@@ -183,6 +183,11 @@ int bg_rowscale_f32(const float* x, int64_t ldx, const float* scale, float* out,
     rec(27, a, sizeof(a) / 8);
     return 0;
 }
+int bg_iota_mod_i32(int32_t* out, int64_t n, int64_t mod, bgStream) {
+    int64_t a[] = {P(out), n, mod};
+    rec(28, a, sizeof(a) / 8);
+    return 0;
+}
 int bg_fill_f32(float* p, int64_t n, float, bgStream) {
     int64_t a[] = {P(p), 0, n * 4};
     rec(25, a, sizeof(a) / 8);

@@ -359,7 +359,7 @@ def _check_critic_calls(calls, R, h):
         if kind == 1:
             (tA, tB, M, Nn, n_seg), A, lda, Ks = a[0:5], a[5:9], a[9:13], a[13:17]
             Bp, ldb, Cp, ldc, bias, rs, act, res, ldr, pre, ldp, rows, acc, ldacc, pro, ldpro = a[17:33]
-            assert n_seg == 1 and not rs and not res and not rows and not pro
+            assert n_seg == 1 and not rs and not res and not pro
             K = Ks[0]
             if tA:
                 assert lda[0] >= M
@@ -380,12 +380,18 @@ def _check_critic_calls(calls, R, h):
                 R.check(bias, Nn * f, tag + " bias")
             if pre:
                 assert ldp >= Nn
-                R.check(pre, ((M - 1) * ldp + Nn) * f, tag + " pre_add")
+                R.check(pre, (((N if rows else M) - 1) * ldp + Nn) * f, tag + " pre_add")
                 assert pre != Cp
+            if rows:
+                R.check(rows, M * 4, tag + " pre_add_rows")
             if acc:
                 assert ldacc >= Nn
                 R.check(acc, ((M - 1) * ldacc + Nn) * f, tag + " acc_init")
                 assert acc != Cp
+        elif kind == 28:
+            out, n, mod = a
+            R.check(out, n * 4, tag + " index")
+            assert mod == N and n == 3 * N
         elif kind == 10:
             src, dst, n, K, Pn, W, to_outer = a
             R.check(src, n * K * Pn * W * f, tag + " src")
@@ -465,9 +471,9 @@ def _check_critic_calls(calls, R, h):
 def test_critic_head_host_sequence_and_extents(drv, N, S, B):
     (rc_f, rc_b), fwd, bwd, R, h = _critic_run(drv, N, S, B)
     assert rc_f == 0 and rc_b == 0
-    assert [k for k, _ in fwd] == [10, 1, 1, 1, 1, 11, 11, 11, 11, 1, 1, 1, 1, 11, 11, 12, 1, 1, 13, 13, 1, 10, 14, 15]
-    assert [k for k, _ in bwd] == ([16, 20, 14, 10, 1, 19, 12, 12, 17, 17, 1, 1, 1, 1] + [19, 17, 1, 19, 17, 1, 13, 13]
-                                   + [19, 17, 1, 19, 17, 1] + [13, 19, 13, 19, 18, 19])
+    assert [k for k, _ in fwd] == [10, 1, 28, 1, 11, 11, 11, 11, 1, 1, 1, 1, 11, 11, 12, 1, 1, 13, 13, 1, 10, 14, 15]
+    assert [k for k, _ in bwd] == ([16, 20, 14, 10, 1, 12, 12, 17, 17, 1, 1, 1, 1] + [19, 17, 1, 19, 17, 1, 13, 13]
+                                   + [19, 17, 1, 19, 17, 1] + [13, 13, 19, 18, 19])
     _check_critic_calls(fwd, R, h)
     _check_critic_calls(bwd, R, h)
     # where the gradients land: every one of the nine outputs is written (assigned first, then accumulated into)
@@ -487,7 +493,9 @@ def test_critic_head_host_sequence_and_extents(drv, N, S, B):
     # gW: static rows assigned once, label rows assigned then accumulated twice
     gw = [(a[8], a[12]) for k, a in bwd if k == 19 and R.check(a[8], 4, "C") == "gW"]
     base = R.r["gW"][0]
-    assert [(p - base, acc) for p, acc in gw] == [(13 * 32 * 256 * 4, 0), (13 * 32 * 256 * 4, 1), (13 * 32 * 256 * 4, 1), (0, 0)]
+    assert [(p - base, acc) for p, acc in gw] == [(13 * 32 * 256 * 4, 0), (0, 0)]
+    big = [a for k, a in bwd if k == 19 and a[1] == 4 * N]
+    assert len(big) == 1 and big[0][0] == 13 * 8 and big[0][7] == 256          # one product over the 4 N stacked rows
 
 
 def test_critic_head_rejects_unsupported_sizes(drv):
