@@ -95,11 +95,12 @@ class Batch(VolumeDesignGraph):
         self.__slices__: Optional[Dict[str, List[int]]] = None
         self.__data_class__ = VolumeDesignGraph
         self.num_graphs: int = 0
+        self.num_stories: Optional[int] = None      # total stories of the batch, known at collate time (the plan needs it)
 
     @property
     def keys(self) -> List[str]:
         return [k for k, v in self.__dict__.items()
-                if v is not None and not k.startswith("_") and k != "num_graphs"]
+                if v is not None and not k.startswith("_") and k not in ("num_graphs", "num_stories")]
 
     @staticmethod
     def from_data_list(data_list: Sequence[VolumeDesignGraph],
@@ -137,6 +138,10 @@ class Batch(VolumeDesignGraph):
                 batch[k] = list(parts[k])
         for k in follow_batch:
             batch[k + "_batch"] = torch.cat(follow[k], dim=0)
+        if "voxel_floor_cluster" in cumsum:
+            # the running story offset after the last graph = the number of (dense, global) story ids: the plan
+            # otherwise reads voxel_floor_cluster.max() back from the device (one more synchronisation per batch)
+            batch.num_stories = int(cumsum["voxel_floor_cluster"])
         batch.__slices__ = slices
         return batch
 
@@ -149,6 +154,7 @@ def detach_batch(batch):
     out = Batch()
     out.__slices__ = copy.deepcopy(getattr(batch, "__slices__", None))
     out.num_graphs = getattr(batch, "num_graphs", 0)
+    out.num_stories = getattr(batch, "num_stories", None)
     for k in batch.keys:
         v = batch[k]
         out[k] = v.detach() if torch.is_tensor(v) else copy.deepcopy(v)
