@@ -318,7 +318,10 @@ class HipWorkload:
         self.trainer.train_iteration(b, i)
         nxt = self.batches[(i + 1) % n]
         nxt.__dict__.pop("_bg_plan", None)        # a fresh batch: its index plan is part of the step
-        self.prefetch_plan(nxt)
+        if self.prefetch_plan is self.build_plan:
+            self.build_plan(nxt)
+        else:
+            self.trainer.prefetch(nxt)            # plan (+ with several ranks the global counts) on a side stream
 
     def sync(self):
         import torch

@@ -118,17 +118,51 @@ class FlatAdam:
         self.t_host = st[4]
 
 
-def global_counts(batch, group=None):
-    """(graphs, stories, voxels) over all ranks -- one tiny all-reduce per batch."""
+def _local_counts(batch):
     B = int(batch.FAR.shape[0])
     Nv = int(batch.voxel_feature.shape[0])
     plan = batch.__dict__.get("_bg_plan")
-    S = plan.S if plan is not None else int(batch.voxel_floor_cluster.max().item()) + 1
+    S = plan.S if plan is not None else getattr(batch, "num_stories", None)
+    if S is None:
+        S = int(batch.voxel_floor_cluster.max().item()) + 1
+    return B, S, Nv
+
+
+def global_counts(batch, group=None):
+    """(graphs, stories, voxels) over all ranks -- one tiny all-reduce per batch, or what prefetch_counts() already
+    fetched for this batch beside the previous iteration."""
+    cached = batch.__dict__.pop("_bg_counts", None) if hasattr(batch, "__dict__") else None
+    if cached is not None and cached[0] == _world(group):
+        return cached[1]
+    B, S, Nv = _local_counts(batch)
     if _world(group) > 1:
         t = torch.tensor([B, S, Nv], dtype=torch.float64, device=batch.voxel_feature.device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         B, S, Nv = (int(x) for x in t.tolist())
     return B, S, Nv
+
+
+def prefetch_counts(batch, group=None):
+    """The global counts of a batch that a LATER iteration will use, fetched now on the plan's side stream: reading the
+    all-reduced counts back at the start of an iteration would first drain everything the previous iteration queued
+    (with one rank there is nothing to fetch).  Every rank must call this for the same batches in the same order."""
+    if _world(group) <= 1 or not hasattr(batch, "__dict__"):
+        return
+    from .plan import _PREFETCH_STREAMS
+    dev = batch.voxel_feature.device
+    B, S, Nv = _local_counts(batch)
+    if dev.type != "cuda":
+        t = torch.tensor([B, S, Nv], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    else:
+        side = _PREFETCH_STREAMS.get(dev)
+        if side is None:
+            side = _PREFETCH_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            t = torch.tensor([B, S, Nv], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            t = t.cpu()                   # waits for the side stream (and the collective it ordered behind) only
+    batch.__dict__["_bg_counts"] = (_world(group), tuple(int(x) for x in t.tolist()))
 
 
 class Trainer:
@@ -385,6 +419,13 @@ class Trainer:
         stats["g_loss"] = g_loss.detach()
         return stats
 
+    def prefetch(self, batch):
+        """What the NEXT iteration needs from its batch alone -- the index plan and, with several ranks, the global
+        counts -- issued now beside the running iteration (side stream; see plan.prefetch_plan)."""
+        from .plan import prefetch_plan
+        prefetch_plan(batch)
+        prefetch_counts(batch, self.group)
+
     # ------------------------------------------------------------------ eager iteration
     def train_iteration(self, batch, i: int, program_z=None, voxel_z=None, noise: Optional[Sequence] = None,
                         u: Optional[torch.Tensor] = None):
@@ -438,7 +479,7 @@ class Trainer:
                 stats = self.train_iteration(batch, i)
                 batch, i = fetch(it), i + 1
                 if batch is not None and dev.type == "cuda":
-                    prefetch_plan(batch)          # the next batch's index plan beside this iteration's kernels
+                    self.prefetch(batch)          # the next batch's index plan (and global counts) beside this iteration
             if epoch % eval_period == 0:
                 if model_dir is not None:
                     os.makedirs(model_dir, exist_ok=True)

@@ -77,7 +77,14 @@ def _worker(rank, world, port, ret):
         mine = Batch.from_data_list(data[rank * per:(rank + 1) * per])
         a = _slice(full, rank * per, (rank + 1) * per, pz, vz, noise, u)
         tr = _trainer()
+        # the counts fetched ahead of the iteration (train.prefetch_counts, what Trainer.prefetch / fit do for the next
+        # batch) are what the direct all-reduce gives, and are consumed once
+        from building_gan_amd.train import prefetch_counts
+        direct = global_counts(mine)
+        prefetch_counts(mine)
+        assert mine.__dict__["_bg_counts"] == (world, direct)
         counts = global_counts(mine)
+        assert counts == direct and "_bg_counts" not in mine.__dict__
         gen, stats = tr._phase_d(mine, counts, True, *a)
         tr.opt_d.all_reduce()
         d_grad = tr.opt_d.grad.clone()
