@@ -318,6 +318,7 @@ class HipWorkload:
         self.trainer.train_iteration(b, i)
         nxt = self.batches[(i + 1) % n]
         nxt.__dict__.pop("_bg_plan", None)        # a fresh batch: its index plan is part of the step
+        getattr(nxt.voxel_feature, "__dict__", {}).pop("_bg_split", None)      # (and nothing else derived from it is kept)
         if self.prefetch_plan is self.build_plan:
             self.build_plan(nxt)
         else:

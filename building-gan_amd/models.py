@@ -96,7 +96,15 @@ def run_mlp(seq: nn.Sequential, xs, row_scale=None, pad_to: int = 0):
 
 
 def extract_pos(feature):
-    return feature[:, 3:6], torch.cat((feature[:, 0:3], feature[:, 6:]), dim=-1)
+    """(pos [N, 3] view, the other columns [N, F - 3] copied together).  For a data tensor (no gradient) the copy is kept
+    on the tensor object: every pass of every iteration over a batch asks for the same split of the same features."""
+    if feature.requires_grad:
+        return feature[:, 3:6], torch.cat((feature[:, 0:3], feature[:, 6:]), dim=-1)
+    kept = getattr(feature, "_bg_split", None)
+    if kept is None or kept[0] != feature._version:
+        kept = (feature._version, torch.cat((feature[:, 0:3], feature[:, 6:]), dim=-1))
+        feature._bg_split = kept
+    return feature[:, 3:6], kept[1]
 
 
 PDM4_PAD = 1.0   # the 4th (pad) column of the position terms.  Every weight that multiplies it is zero-padded there, so

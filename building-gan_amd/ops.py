@@ -1514,15 +1514,7 @@ class CriticHead(torch.autograd.Function):
                 or bb1.numel() != Hd or sb1.numel() != Hd or bb2.numel() != 1 or sb2.numel() != 1
                 or wb.numel() != 2 * plan.B or ws.numel() != 2 * plan.S or N != plan.Nv):
             raise _lib.BganError("critic_head: operand shapes do not fit the plan / the coefficient table")
-        blocks, st, sg = plan.vox_blocks, plan.story_seg, plan.story_graph_seg
-        A, AT = plan.vox_mean, plan.vox_mean.T
-        if blocks is None or st.seg_of is None or sg.seg_of is None or plan.graph_seg.seg_of is None:
-            raise _lib.BganError("critic_head: the plan lacks diagonal blocks / segment tables")
-        h = _lib.CriticHead(N, plan.S, plan.B, L, ds, dl, H2, Hd, blocks.n, blocks.max_rows, blocks.max_nnz, blocks.max_deg,
-                            ptr(Zs), ptr(Zk), ptr(W), ptr(bw1), ptr(bb1), ptr(bw2), ptr(bb2), ptr(sw1), ptr(sb1), ptr(sw2),
-                            ptr(sb2), ptr(wb), ptr(ws), ptr(st.rowptr), ptr(st.col), ptr(st.seg_of), ptr(sg.rowptr),
-                            ptr(sg.col), ptr(sg.seg_of), ptr(plan.graph_seg.seg_of), ptr(A.csr.rowptr), ptr(A.csr.col),
-                            ptr(A.row_scale), ptr(AT.csr.rowptr), ptr(AT.csr.col), ptr(blocks.ptr))
+        h = _critic_head_struct(plan, N, L, ds, dl, H2, Hd, Zs, Zk, W, (bw1, bb1, bw2, bb2), (sw1, sb1, sw2, sb2), wb, ws)
         n_ws = lib.bg_critic_head_workspace(C.byref(h))
         if n_ws < 0:
             raise _lib.BganError("critic_head: sizes not supported")
