@@ -31,7 +31,7 @@ SIGNATURES = {
     "bg_spmm_add_f32": [_p, _i64, _p, _p, _p, _int, _p, _int, _p, _i64, _p, _i64, _p, _i64, _p, _p, _int,
                         _p, _i64, _i64, _i64, _p],
     "bg_spmm_chain_f32": [_p, _i64, _p, _p, _p, _int, _p, _int, _p, _i64, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
-                          _i64, _i64, _p],
+                          _i64, _i64, _i32, _p],
     "bg_segreduce_sum_f32": [_p, _i64, _p, _p, _p, _p, _p, _int, _p, _i32, _i64, _p, _p, _i64, _i64, _i64, _p],
     "bg_segmax_f32": [_p, _i64, _p, _p, _p, _i32, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _p],
     "bg_segmax_static_f32": [_p, _i64, _p, _p, _p, _i32, _i64, _p, _i64, _p, _i64, _i64, _p],
@@ -56,7 +56,8 @@ SIGNATURES = {
     "bg_d_coef_init_f32": [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _p],
     "bg_d_coef_init_bwd_f32": [_p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i64, _p, _p],
     "bg_spmm_chain_pair_f32": [_p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _int, _p, _int,
-                               _p, _i64, _i64, _i64, _i64, _i64, _p],
+                               _p, _i64, _i64, _i64, _i64, _i64, _i32, _p],
+    "bg_cheb_shift_f32": [_p, _p, _i64, _i64, _i64, _i32, _p],
     "bg_attention_bwd_head_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _i64,
                                   _i64, _i64, _p],
     "bg_pos_terms_f32": [_p, _i64, _p, _p, _p, _i64, _f, _p],
@@ -68,8 +69,9 @@ SIGNATURES = {
     "bg_gemm_tn_splitk_f32": [_i64, _i64, _p, _i64, _int, _p, _p, _p, _p, _i64, _p, _i32, _int, _p],
     "bg_colsum_f32": [_p, _i64, _i64, _i64, _p, _i32, _p, _int, _p],
     "bg_generator_forward_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
-    "bg_d_coef_forward_f32": [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _p],
-    "bg_d_coef_backward_f32": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "bg_d_coef_forward_f32": [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p],
+    "bg_d_coef_backward_f32": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p,
+                               _p, _p, _p, _p],
     "bg_adam_f32": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i32, _p, _p],
     "bg_regroup_f32": [_p, _p, _i64, _i64, _i64, _i64, _int, _p],
     "bg_add_f32": [_p, _p, _p, _i64, _p],
@@ -124,7 +126,7 @@ class GeneratorBackPlan(C.Structure):
 class CriticHead(C.Structure):
     """include/bgan.h: bgCriticHead."""
     _fields_ = [(n, _i64) for n in ("N", "S", "B", "L", "ds", "dl", "H2", "Hd", "blk_n", "blk_max_rows", "blk_max_nnz",
-                                    "blk_max_deg")] + \
+                                    "blk_max_deg", "basis")] + \
                [(n, _fp) for n in ("Zs", "Zk", "W", "b_w1", "b_b1", "b_w2", "b_b2", "s_w1", "s_b1", "s_w2", "s_b2", "wb", "ws",
                                    "st_rowptr", "st_col", "story_of_voxel", "sg_rowptr", "sg_col", "graph_of_story",
                                    "graph_of_voxel", "a_rowptr", "a_col", "a_count", "at_rowptr", "at_col", "blk_ptr")]

@@ -244,6 +244,27 @@ __global__ void k_d_coef_init_bwd(const float* __restrict__ G, int64_t slab, int
     }
 }
 
+// Multiplication by x in the Chebyshev basis, on a table of K row blocks of `blk4` float4 each (block j = the
+// coefficient of T_j):  x T_0 = T_1,  x T_j = (T_{j+1} + T_{j-1}) / 2.
+//   transpose == 0:  out_i = d_i X_{i-1} + X_{i+1} / 2,  d_1 = 1, d_i = 1/2 otherwise   (X_{-1} = X_K = 0)
+//   transpose == 1:  out_0 = X_1,  out_j = (X_{j-1} + X_{j+1}) / 2                     (the adjoint)
+// Blocks [0, K_out) are written.
+__global__ void k_cheb_shift(const float4* __restrict__ X, float4* __restrict__ out, int K, int K_out, int64_t blk4,
+                             int transpose) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)K_out * blk4) return;
+    const int i = (int)(t / blk4);
+    float lo = 0.5f, hi = 0.5f;
+    if (transpose) { if (i == 0) hi = 1.f; } else { if (i == 1) lo = 1.f; }
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i >= 1) { const float4 a = X[t - blk4]; r.x = lo * a.x; r.y = lo * a.y; r.z = lo * a.z; r.w = lo * a.w; }
+    if (i + 1 < K) {
+        const float4 b = X[t + blk4];
+        r.x = __fmaf_rn(hi, b.x, r.x); r.y = __fmaf_rn(hi, b.y, r.y); r.z = __fmaf_rn(hi, b.z, r.z); r.w = __fmaf_rn(hi, b.w, r.w);
+    }
+    out[t] = r;
+}
+
 // [n, K, P, W] <-> [P, n, K, W], one float4 per thread (see bg_regroup_f32)
 __global__ void k_regroup(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n, int K, int P, int W4,
                           int to_outer) {
@@ -470,6 +491,21 @@ int bg_d_coef_init_f32(const float* fe_w, const float* fe_b, const float* le_w, 
     if (n > 0x7fffffff) return BG_ERR_SHAPE;
     k_d_coef_init<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
         fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, (int)H, (int)nf, (int)nl, (int)ML, (int)ds, (int)(ds + dl), x0, e);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_cheb_shift_f32(const float* x, float* out, int64_t K, int64_t K_out, int64_t block_floats, int32_t transpose,
+                      bgStream stream) {
+    if (K < 0 || K_out < 0 || K_out > K || block_floats < 0) return BG_ERR_ARG;
+    if (K_out == 0 || block_floats == 0) return BG_OK;
+    if (!x || !out || x == out) return BG_ERR_ARG;
+    if (block_floats % 4 != 0 || K_out * (block_floats / 4) > 0x7fffffff) return BG_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)out) & 15) return BG_ERR_ALIGN;
+    const int64_t n4 = K_out * (block_floats / 4);
+    k_cheb_shift<<<bg_grid_for(n4, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(out), (int)K, (int)K_out, block_floats / 4,
+        transpose ? 1 : 0);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

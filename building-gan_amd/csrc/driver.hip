@@ -178,19 +178,27 @@ int64_t coef_splits(int64_t M, int64_t R) {          // as ops.gemm_tn_raw: M x 
 
 extern "C" int bg_d_coef_forward_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b,
                                      const float* pe, const float* Wc, int64_t ldw, const float* bc, int64_t H,
-                                     int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L,
-                                     float* xall, float* efull, bgStream s) {
+                                     int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L, int32_t basis,
+                                     float* xall, float* efull, float* shall, bgStream s) {
     if (!fe_w || !fe_b || !le_w || !le_b || !pe || !Wc || !bc || !xall || !efull) return BG_ERR_ARG;
     if (H <= 0 || L < 0 || ds < nf + ML + 5 || dl < nl || ldw < 4 * H + 4) return BG_ERR_ARG;
+    if ((basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB) || (basis == BG_CHAIN_CHEB && !shall && L > 0)) return BG_ERR_ARG;
     const int64_t H2 = 2 * H, du = ds + dl, N = (L + 1) * du, S = N + du;
     hipStream_t st = (hipStream_t)s;
     BG_HIP(hipMemsetAsync(xall, 0, sizeof(float) * (size_t)((L + 1) * S * H2), st));
     BG_HIP(hipMemsetAsync(efull, 0, sizeof(float) * (size_t)(N * H2), st));
+    if (basis == BG_CHAIN_CHEB && L > 0) BG_HIP(hipMemsetAsync(shall, 0, sizeof(float) * (size_t)((L * S + du) * H2), st));
     BG_TRY(bg_d_coef_init_f32(fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, H, nf, nl, ML, ds, dl, xall + du * H2, efull, s));
     for (int64_t m = 0; m < L; ++m) {
         const int64_t rows = N < (m + 2) * du ? N : (m + 2) * du;       // blocks above m+1 are still zero
         float* cur = xall + m * S * H2;
-        const float* A[4] = {cur + du * H2, cur, nullptr, nullptr};
+        const float* shifted = cur;                                     // monomials: one block down = a row offset
+        if (basis == BG_CHAIN_CHEB) {
+            float* sh = shall + m * S * H2 + du * H2;
+            BG_TRY(bg_cheb_shift_f32(cur + du * H2, sh, L + 1, rows / du, du * H2, 0, s));
+            shifted = sh;
+        }
+        const float* A[4] = {cur + du * H2, shifted, nullptr, nullptr};
         const int64_t ld[4] = {H2, H2, 0, 0}, Ks[4] = {H2, H2, 0, 0};
         BG_TRY(bg_gemm_f32(0, 1, rows, H2, 2, A, ld, Ks, Wc, ldw, xall + (m + 1) * S * H2 + du * H2, H2, nullptr, nullptr,
                            BG_ACT_NONE, 0.01f, cur + du * H2, H2, efull, H2, nullptr, nullptr, 0, nullptr, 0, s));
@@ -204,13 +212,14 @@ extern "C" int64_t bg_d_coef_backward_workspace(int64_t H, int64_t ds, int64_t d
     return coef_splits(H2, L * S) * H2 * 2 * H2;
 }
 
-extern "C" int bg_d_coef_backward_f32(const float* g, const float* xall, const float* Wc, int64_t ldw, int64_t H,
-                                      int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L,
-                                      float* gall, float* wab, float* partial, float* gW, float* g_bc, float* g_fe_w,
-                                      float* g_fe_b, float* g_le_w, float* g_le_b, bgStream s) {
+extern "C" int bg_d_coef_backward_f32(const float* g, const float* xall, const float* shall, const float* Wc, int64_t ldw,
+                                      int64_t H, int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L,
+                                      int32_t basis, float* sht, float* gall, float* wab, float* partial, float* gW,
+                                      float* g_bc, float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b, bgStream s) {
     if (!g || !xall || !Wc || !gall || !wab || !partial || !gW || !g_bc || !g_fe_w || !g_fe_b || !g_le_w || !g_le_b)
         return BG_ERR_ARG;
     if (H <= 0 || L < 1 || ldw < 4 * H + 4) return BG_ERR_ARG;
+    if ((basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB) || (basis == BG_CHAIN_CHEB && (!shall || !sht))) return BG_ERR_ARG;
     const int64_t H2 = 2 * H, du = ds + dl, N = (L + 1) * du, S = N + du;
     hipStream_t st = (hipStream_t)s;
     // G^m at rows [0, N) of slab m, du zero rows below it (the shift-up view reads them)
@@ -222,13 +231,18 @@ extern "C" int bg_d_coef_backward_f32(const float* g, const float* xall, const f
                             hipMemcpyDeviceToDevice, st));
     for (int64_t m = L - 1; m >= 0; --m) {
         const float* nxt = gall + (m + 1) * S * H2;
-        const float* A[4] = {nxt, nxt + du * H2, nullptr, nullptr};
+        const float* up = nxt + du * H2;                                // monomials: one block up = a row offset
+        if (basis == BG_CHAIN_CHEB) {
+            BG_TRY(bg_cheb_shift_f32(nxt, sht, L + 1, L + 1, du * H2, 1, s));
+            up = sht;
+        }
+        const float* A[4] = {nxt, up, nullptr, nullptr};
         const int64_t ld[4] = {H2, H2, 0, 0}, Ks[4] = {H2, H2, 0, 0};
         BG_TRY(bg_gemm_f32(0, 0, N, H2, 2, A, ld, Ks, wab, H2, gall + m * S * H2, H2, nullptr, nullptr, BG_ACT_NONE, 0.01f,
                            nxt, H2, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
     }
     // dWc[:, :4H] = sum_m G^{m+1 T} [X^m | shift(X^m)]: one long reduction over the stacked slabs
-    const float* B[4] = {xall + du * H2, xall, nullptr, nullptr};
+    const float* B[4] = {xall + du * H2, basis == BG_CHAIN_CHEB ? shall + du * H2 : xall, nullptr, nullptr};
     const int64_t ldb[4] = {H2, H2, 0, 0}, Ns[4] = {H2, H2, 0, 0};
     BG_TRY(bg_gemm_tn_splitk_f32(H2, L * S, gall + S * H2, H2, 2, B, ldb, Ns, gW, 2 * H2 + 4, partial,
                                  (int32_t)coef_splits(H2, L * S), 0, s));
@@ -304,6 +318,7 @@ int critic_shape_ok(const bgCriticHead& h) {
     if (h.N <= 0 || h.S <= 0 || h.B <= 0 || h.L < 1 || h.ds <= 0 || h.dl <= 0 || h.H2 <= 0 || h.Hd <= 0) return BG_ERR_ARG;
     if (h.ds % 4 || h.dl % 4 || h.H2 % 4 || h.Hd % 4 || h.H2 > 1024 || h.L > 64) return BG_ERR_SHAPE;
     if (h.blk_n <= 0 || h.blk_max_deg > 8 || h.blk_max_rows <= 0) return BG_ERR_SHAPE;
+    if (h.basis != BG_CHAIN_POWER && h.basis != BG_CHAIN_CHEB) return BG_ERR_ARG;
     return BG_OK;
 }
 
@@ -393,7 +408,8 @@ extern "C" int bg_critic_head_forward_f32(const bgCriticHead* hp, float coef, fl
     const int64_t W2c = 2 * dl, ldy = K1 * W2c;
     BG_TRY(bg_spmm_chain_f32(b.Ys + h.L * W2c, ldy, h.at_rowptr, h.at_col, nullptr, BG_SCALE_NONE, h.a_count, BG_SCALE_DIV,
                              h.blk_ptr, h.blk_n, h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg,
-                             b.Ys + (h.L - 1) * W2c, ldy, -W2c, b.acc, W2c, 0, h.L, W2c, s));
+                             b.Ys + (h.L - 1) * W2c, ldy, -W2c, b.acc, W2c, 0, h.L, W2c,
+                             h.basis ? BG_CHAIN_CLENSHAW : BG_CHAIN_POWER, s));
     BG_TRY(bg_critic_loss_f32(b.valb, h.wb, 2 * B, b.vals, h.ws, 2 * S, b.acc, dl, 2 * N, dl, coef, b.part, loss, s));
     return BG_OK;
 }
@@ -426,7 +442,7 @@ extern "C" int bg_critic_head_backward_f32(const bgCriticHead* hp, float coef, c
     }
     BG_TRY(bg_spmm_chain_f32(b.dYs, ldy, h.a_rowptr, h.a_col, h.a_count, BG_SCALE_DIV, nullptr, BG_SCALE_NONE,
                              h.blk_ptr, h.blk_n, h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg,
-                             nullptr, 0, 0, b.dYs + W2c, ldy, W2c, h.L, W2c, s));
+                             nullptr, 0, 0, b.dYs + W2c, ldy, W2c, h.L, W2c, h.basis ? BG_CHAIN_CHEB : BG_CHAIN_POWER, s));
     BG_TRY(bg_regroup_f32(b.dYs, b.dX, N, K1, 2, dl, 1, s));
     BG_TRY(mm(2 * N, H2, K1 * dl, b.dX, K1 * dl, Wl, H2, 0, b.dG2, nullptr, nullptr, s));                   // d G2 = dX Wl
     BG_TRY(bg_gather_arg_f32(b.dG2, H2, b.arg_b, b.dgp_b, H2, B, H2, s));
@@ -926,7 +942,8 @@ extern "C" int bg_gloss_head_forward_f32(const bgCriticHead* hp, const float* la
         BG_TRY(bg_pack_columns_f32(src, lds, 1, n_lab, dl, b.Zl, ldz, N, s));
     }
     BG_TRY(bg_spmm_chain_f32(b.Zl, ldz, h.a_rowptr, h.a_col, h.a_count, BG_SCALE_DIV, nullptr, BG_SCALE_NONE, h.blk_ptr, h.blk_n,
-                             h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg, nullptr, 0, 0, b.Zl + dl, ldz, dl, h.L, dl, s));
+                             h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg, nullptr, 0, 0, b.Zl + dl, ldz, dl, h.L, dl,
+                             h.basis ? BG_CHAIN_CHEB : BG_CHAIN_POWER, s));
     {
         const float* A[4] = {h.Zs, b.Zl, nullptr, nullptr};
         const int64_t ld[4] = {K1 * ds, ldz, 0, 0}, Ks[4] = {K1 * ds, ldz, 0, 0};
@@ -968,7 +985,7 @@ extern "C" int bg_gloss_head_backward_f32(const bgCriticHead* hp, int64_t n_lab,
     BG_TRY(mm(N, ldz, H2, b.v, H2, Wl, H2, 1, b.dZl, nullptr, nullptr, s));                       // d Zl = d v Wl^T
     BG_TRY(bg_spmm_chain_f32(b.dZl + h.L * dl, ldz, h.at_rowptr, h.at_col, nullptr, BG_SCALE_NONE, h.a_count, BG_SCALE_DIV,
                              h.blk_ptr, h.blk_n, h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg,
-                             b.dZl + (h.L - 1) * dl, ldz, -dl, b.gl, dl, 0, h.L, dl, s));
+                             b.dZl + (h.L - 1) * dl, ldz, -dl, b.gl, dl, 0, h.L, dl, h.basis ? BG_CHAIN_CLENSHAW : BG_CHAIN_POWER, s));
     {
         const float* src[4] = {b.gl, nullptr, nullptr, nullptr};
         const int64_t lds[4] = {dl, 0, 0, 0};

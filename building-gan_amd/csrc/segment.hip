@@ -671,6 +671,11 @@ __global__ __launch_bounds__(1024) void k_gather_story(SpmmArgs a, StoryArgs st,
 // rows ping-pong between two LDS images, the block's CSR (local column ids) and scales sit in LDS too,
 // and a workgroup barrier separates the steps.  Same slot order and scale arithmetic as k_spmm_vec, so
 // every step equals the corresponding separate launch.
+// basis != 0 turns the chain into a three-term (Chebyshev) recurrence over the same two LDS images: the image a
+// step overwrites still holds y_{k-2}, and each thread reads and writes only its own rows of it.
+//   BG_CHAIN_CHEB     y_1 = P y_0,  y_k = 2 P y_{k-1} - y_{k-2}                      (y_k = T_k(P) y_0)
+//   BG_CHAIN_CLENSHAW y_k = 2 P y_{k-1} - y_{k-2} + add_k, the last step with factor 1 (y_n = sum_j T_j(P) g_j for
+//                     x0 = g_n, add_k = g_{n-k}: Clenshaw's evaluation, the transpose of the line above)
 struct ChainArgs {
     const float* x0; int64_t ldx;
     const int32_t* rowptr; const int32_t* col;
@@ -683,7 +688,13 @@ struct ChainArgs {
     // optional second matrix under the same operator and step count (k_spmm_chain_short only): column chunks
     // blockIdx.y >= split_y belong to it (no addend)
     int split_y; const float* x0b; int64_t ldxb; float* outb; int64_t ldob; int64_t out_stepb;
+    int basis;
 };
+
+// factor of P y_{k-1} at this step of a three-term chain (the subtraction of y_{k-2} starts at step 2)
+__device__ __forceinline__ float chain_factor(int basis, int step, int n_steps) {
+    return (basis == BG_CHAIN_CHEB ? step == 1 : step == n_steps) ? 1.f : 2.f;
+}
 
 template <bool IDX_LDS>
 __global__ __launch_bounds__(1024) void k_spmm_chain(ChainArgs a) {
@@ -717,6 +728,7 @@ __global__ __launch_bounds__(1024) void k_spmm_chain(ChainArgs a) {
         float4* dst = (step & 1) ? buf1 : buf0;
         const float* addk = a.add ? a.add + (int64_t)(step - 1) * a.add_step : nullptr;
         float* outk = (a.out_step != 0 || step == a.n_steps) ? a.out + (int64_t)(step - 1) * a.out_step : nullptr;
+        const float fac = chain_factor(a.basis, step, a.n_steps);
         for (int r = tid; r < nr; r += nt) {
             const int64_t grow = (int64_t)r0 + r;
             float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -741,6 +753,10 @@ __global__ __launch_bounds__(1024) void k_spmm_chain(ChainArgs a) {
                 const float s = s_rs[r];
                 acc.x = apply_scale(acc.x, s, a.row_mode); acc.y = apply_scale(acc.y, s, a.row_mode);
                 acc.z = apply_scale(acc.z, s, a.row_mode); acc.w = apply_scale(acc.w, s, a.row_mode);
+            }
+            if (a.basis) {
+                acc.x *= fac; acc.y *= fac; acc.z *= fac; acc.w *= fac;
+                if (step >= 2) { const float4 p = dst[r]; acc.x -= p.x; acc.y -= p.y; acc.z -= p.z; acc.w -= p.w; }
             }
             if (addk) acc = bg_add4(acc, ad);
             dst[r] = acc;
@@ -837,6 +853,7 @@ __global__ __launch_bounds__(1024) void k_spmm_chain_short(ChainArgs a) {
         float4* dst = (step & 1) ? buf1 : buf0;
         const float* addk = a.add ? a.add + (int64_t)(step - 1) * a.add_step : nullptr;
         float* outk = (a.out_step != 0 || step == a.n_steps) ? a.out + (int64_t)(step - 1) * a.out_step : nullptr;
+        const float fac = chain_factor(a.basis, step, a.n_steps);
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int r = tid + i * nt;
@@ -858,6 +875,10 @@ __global__ __launch_bounds__(1024) void k_spmm_chain_short(ChainArgs a) {
                 if (a.row_mode) {
                     acc.x = apply_scale(acc.x, rs[i], a.row_mode); acc.y = apply_scale(acc.y, rs[i], a.row_mode);
                     acc.z = apply_scale(acc.z, rs[i], a.row_mode); acc.w = apply_scale(acc.w, rs[i], a.row_mode);
+                }
+                if (a.basis) {
+                    acc.x *= fac; acc.y *= fac; acc.z *= fac; acc.w *= fac;
+                    if (step >= 2) { const float4 p = dst[r]; acc.x -= p.x; acc.y -= p.y; acc.z -= p.z; acc.w -= p.w; }
                 }
                 if (addk) acc = bg_add4(acc, ad);
                 dst[r] = acc;
@@ -934,8 +955,10 @@ int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const
                       const float* row_scale, int row_mode, const float* col_scale, int col_mode,
                       const int32_t* blk_ptr, int64_t n_blk, int64_t max_rows, int64_t max_nnz, int64_t max_deg,
                       const float* add, int64_t ld_add, int64_t add_step,
-                      float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, bgStream stream) {
+                      float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, int32_t basis,
+                      bgStream stream) {
     if (n_blk < 0 || W < 0 || n_steps < 0 || max_rows < 0 || max_nnz < 0 || max_deg < 0) return BG_ERR_ARG;
+    if (basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB && basis != BG_CHAIN_CLENSHAW) return BG_ERR_ARG;
     if (n_blk == 0 || W == 0 || n_steps == 0 || max_rows == 0) return BG_OK;
     if (!x0 || !rowptr || !col || !blk_ptr || !out || ldx < W || ldo < W || (add && ld_add < W)) return BG_ERR_ARG;
     if ((row_mode && !row_scale) || (col_mode && !col_scale)) return BG_ERR_ARG;
@@ -944,7 +967,7 @@ int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const
         (add && (!bg_aligned16(add) || ld_add % 4 != 0 || add_step % 4 != 0))) return BG_ERR_ALIGN;
     if (max_rows > (1 << 20) || max_nnz > (1 << 26)) return BG_ERR_SHAPE;
     ChainArgs a{x0, ldx, rowptr, col, row_scale, row_mode, col_scale, col_mode, blk_ptr, (int)max_rows, (int)max_nnz,
-                add, ld_add, add_step, out, ldo, out_step, (int)n_steps};
+                add, ld_add, add_step, out, ldo, out_step, (int)n_steps, 0, nullptr, 0, nullptr, 0, 0, (int)basis};
     hipStream_t s = (hipStream_t)stream;
     if (max_deg <= 8 && max_rows <= 2048) {
         // short rows: indices in registers, 1 or 2 rows per thread (4 rows per thread spills)
@@ -962,8 +985,9 @@ int bg_spmm_chain_pair_f32(const float* x0, int64_t ldx, float* out, int64_t ldo
                            const int32_t* rowptr, const int32_t* col,
                            const float* row_scale, int row_mode, const float* col_scale, int col_mode,
                            const int32_t* blk_ptr, int64_t n_blk, int64_t max_rows, int64_t max_nnz, int64_t max_deg,
-                           int64_t n_steps, bgStream stream) {
+                           int64_t n_steps, int32_t basis, bgStream stream) {
     if (n_blk < 0 || W <= 0 || Wb <= 0 || n_steps < 0 || max_rows < 0 || max_nnz < 0 || max_deg < 0) return BG_ERR_ARG;
+    if (basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB) return BG_ERR_ARG;      // no addend here: no Clenshaw form
     if (n_blk == 0 || n_steps == 0 || max_rows == 0) return BG_OK;
     if (!x0 || !out || !x0b || !outb || !rowptr || !col || !blk_ptr || ldx < W || ldo < W || ldxb < Wb || ldob < Wb)
         return BG_ERR_ARG;
@@ -973,7 +997,7 @@ int bg_spmm_chain_pair_f32(const float* x0, int64_t ldx, float* out, int64_t ldo
         ldo % 4 != 0 || out_step % 4 != 0 || ldxb % 4 != 0 || ldob % 4 != 0 || out_stepb % 4 != 0) return BG_ERR_ALIGN;
     if (!(max_deg <= 8 && max_rows <= 2048)) return BG_ERR_SHAPE;      // short-row plans only: else two bg_spmm_chain_f32 calls
     ChainArgs a{x0, ldx, rowptr, col, row_scale, row_mode, col_scale, col_mode, blk_ptr, (int)max_rows, (int)max_nnz,
-                nullptr, 0, 0, out, ldo, out_step, (int)n_steps, (int)(W / 4), x0b, ldxb, outb, ldob, out_stepb};
+                nullptr, 0, 0, out, ldo, out_step, (int)n_steps, (int)(W / 4), x0b, ldxb, outb, ldob, out_stepb, (int)basis};
     hipStream_t s = (hipStream_t)stream;
     return max_deg <= 6 ? dispatch_chain_short<6>(a, n_blk, W + Wb, s) : dispatch_chain_short<8>(a, n_blk, W + Wb, s);
 }

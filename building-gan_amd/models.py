@@ -485,10 +485,15 @@ class VoxelGNN_D(nn.Module):
     # parameters by the recurrence T^{m+1}_k = T^m_k (I + Wa^T) + T^m_{k-1} Wb^T + [k=0] E.
     # One pass costs L thin gather-means (8 label columns; the label-free columns are shared by every
     # pass of an iteration) and ONE [N, (L+1)*40] x [.., 2H] GEMM instead of L GEMMs of K = 4H+4.
+    # Basis (ops.D_BASIS): the same polynomial is carried as  v_L = sum_k T_k(A) U C_k  with the Chebyshev
+    # polynomials T_k (T_{k+1} = 2 x T_k - T_{k-1}; the chain kernels run this three-term form) and the table's
+    # recurrence C^{m+1} = C^m (I + Wa^T) + (x * C^m) Wb^T + [k=0] E, where  x * C  is bg_cheb_shift_f32.  A's
+    # spectrum lies in [-1, 1], where |T_k| <= 1: the entries of C stay of the size of the polynomial's values, while
+    # the monomial coefficients T_k grow (and cancel) as the parameters train -- measured in DESIGN.md section 6.
     def _static_powers(self, plan, feat, pdm4, rider=None):
         """[N, (L+1)*ds]: A^k [feature | onehot(level) | mean dpos | 1 | 0..] for k = 0..L (label-free
         columns; no gradient).  Kept on the plan until Trainer / the caller starts the next iteration."""
-        key = ("d_static_powers", self.layer_num, self.pe.shape[0])
+        key = ("d_static_powers", self.layer_num, self.pe.shape[0], ops.D_BASIS)
         Z = plan.ops.get(key)
         if Z is None:
             ML = self.pe.shape[0]
@@ -508,7 +513,7 @@ class VoxelGNN_D(nn.Module):
 
     def coefficients(self, n_feat, ds, dl):
         """The collapsed weight, shared between calls inside DiscriminatorVoxel.shared_coefficients()."""
-        key = (ds, dl, torch.is_grad_enabled())
+        key = (ds, dl, torch.is_grad_enabled(), ops.D_BASIS)
         if self._share_coef and self._coef_cache is not None and self._coef_cache[0] == key:
             return self._coef_cache[1]
         W = self._collapsed_weight(self.block.compose(), n_feat, ds, dl)

@@ -19,6 +19,12 @@ from ._lib import check, ptr, stream
 from .plan import Csr, LinOp, SCALE_NONE
 
 ACT_NONE, ACT_LEAKY = 0, 1
+# Basis of the collapsed discriminator's polynomial in the aggregation operator A (include/bgan.h BG_CHAIN_*):
+# 1 = Chebyshev T_k(A) (default: |T_k| <= 1 on A's spectrum, the coefficient table stays well conditioned while the
+# parameters train), 0 = monomials A^k (the first formulation; its rounding amplification grew past
+# DiscriminatorVoxel.COLLAPSE_AMPLIFICATION_LIMIT within ~1000 iterations of training: DESIGN.md section 6).
+CHAIN_POWER, CHAIN_CHEB, CHAIN_CLENSHAW = 0, 1, 2
+D_BASIS = CHAIN_POWER if os.environ.get("BG_D_BASIS", "chebyshev").lower() in ("power", "monomial", "0") else CHAIN_CHEB
 FUSE_COEF_RECURRENCE = True      # PolyCoefD: the coefficient recurrence and its backward as one host call each
 
 _INPUT_GRADS_ONLY = False
@@ -219,21 +225,23 @@ def _chain_fits(op: LinOp, blocks, W: int, *ts) -> bool:
     return all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 for t in ts)
 
 
-def _chain_launch(op: LinOp, blocks, x0, ldx, add, ld_add, add_step, out, ldo, out_step, n_steps, W):
+def _chain_launch(op: LinOp, blocks, x0, ldx, add, ld_add, add_step, out, ldo, out_step, n_steps, W, basis=CHAIN_POWER):
     """x0 / add / out are raw device addresses (ints); pitches and steps in floats."""
     lib = _lib.load()
     c = op.csr
     check(lib.bg_spmm_chain_f32(x0, ldx, ptr(c.rowptr), ptr(c.col), ptr(op.row_scale), op.row_mode,
                                 ptr(op.col_scale), op.col_mode, ptr(blocks.ptr), blocks.n, blocks.max_rows,
-                                blocks.max_nnz, blocks.max_deg, add, ld_add, add_step, out, ldo, out_step, n_steps, W, stream()),
+                                blocks.max_nnz, blocks.max_deg, add, ld_add, add_step, out, ldo, out_step, n_steps, W, basis,
+                                stream()),
           "bg_spmm_chain_f32")
 
 
-def power_chain_raw(op: LinOp, Z: torch.Tensor, L: int, W: int, blocks=None) -> torch.Tensor:
+def power_chain_raw(op: LinOp, Z: torch.Tensor, L: int, W: int, blocks=None, basis=None) -> torch.Tensor:
     """In place on Z [N, (L+1)*W] (or [N, L+1, W]; row pitch = Z.stride(0)): column group k receives
-    op^k applied to column group 0, k = 1..L.  One launch when the operator is block diagonal with
-    LDS-sized blocks (plan.vox_blocks), else L launches."""
+    op^k (basis CHAIN_POWER) or T_k(op) (CHAIN_CHEB; default D_BASIS) applied to column group 0, k = 1..L.  One launch
+    when the operator is block diagonal with LDS-sized blocks (plan.vox_blocks), else L launches."""
     _lib.require_device(Z, "power_chain")
+    basis = D_BASIS if basis is None else basis
     N = Z.shape[0]
     Z2 = Z.view(N, -1)
     if Z2.dtype != torch.float32 or Z2.stride(1) != 1 or Z2.shape[1] < (L + 1) * W or N != op.csr.n_cols:
@@ -242,16 +250,21 @@ def power_chain_raw(op: LinOp, Z: torch.Tensor, L: int, W: int, blocks=None) -> 
         return Z
     if _chain_fits(op, blocks, W, Z2):
         ld = Z2.stride(0)
-        _chain_launch(op, blocks, Z2.data_ptr(), ld, None, 0, 0, Z2.data_ptr() + 4 * W, ld, W, L, W)
+        _chain_launch(op, blocks, Z2.data_ptr(), ld, None, 0, 0, Z2.data_ptr() + 4 * W, ld, W, L, W, basis)
         return Z
     for k in range(1, L + 1):
-        spmm_raw(op, Z2[:, (k - 1) * W:k * W], out=Z2[:, k * W:(k + 1) * W])
+        zk = Z2[:, k * W:(k + 1) * W]
+        spmm_raw(op, Z2[:, (k - 1) * W:k * W], out=zk)
+        if basis == CHAIN_CHEB and k >= 2:                           # T_k = 2 x T_{k-1} - T_{k-2}
+            zk.mul_(2.0).sub_(Z2[:, (k - 2) * W:(k - 1) * W])
     return Z
 
 
-def power_chain_pair_raw(op: LinOp, Z1: torch.Tensor, W1: int, Z2: torch.Tensor, W2: int, L: int, blocks=None) -> None:
+def power_chain_pair_raw(op: LinOp, Z1: torch.Tensor, W1: int, Z2: torch.Tensor, W2: int, L: int, blocks=None,
+                         basis=None) -> None:
     """power_chain_raw on two matrices under the same operator: ONE launch when both fit the short-row chain
     kernel (a chain's time does not depend on its width, so the second one rides along), else two calls."""
+    basis = D_BASIS if basis is None else basis
     N = Z1.shape[0]
     A, B = Z1.view(N, -1), Z2.view(N, -1)
     ok = (blocks is not None and L > 0 and N > 0 and blocks.max_deg <= 8 and blocks.max_rows <= 2048
@@ -259,8 +272,8 @@ def power_chain_pair_raw(op: LinOp, Z1: torch.Tensor, W1: int, Z2: torch.Tensor,
           and A.shape[1] >= (L + 1) * W1 and B.shape[1] >= (L + 1) * W2 and B.shape[0] == N and N == op.csr.n_cols
           and _chain_fits(op, blocks, W1, A) and _chain_fits(op, blocks, W2, B))
     if not ok:
-        power_chain_raw(op, Z1, L, W1, blocks)
-        power_chain_raw(op, Z2, L, W2, blocks)
+        power_chain_raw(op, Z1, L, W1, blocks, basis)
+        power_chain_raw(op, Z2, L, W2, blocks, basis)
         return
     _lib.require_device(Z1, "power_chain_pair")
     lib = _lib.load()
@@ -269,13 +282,15 @@ def power_chain_pair_raw(op: LinOp, Z1: torch.Tensor, W1: int, Z2: torch.Tensor,
                                      B.data_ptr(), B.stride(0), B.data_ptr() + 4 * W2, B.stride(0), W2, W2,
                                      ptr(c.rowptr), ptr(c.col), ptr(op.row_scale), op.row_mode, ptr(op.col_scale),
                                      op.col_mode, ptr(blocks.ptr), blocks.n, blocks.max_rows, blocks.max_nnz,
-                                     blocks.max_deg, L, stream()), "bg_spmm_chain_pair_f32")
+                                     blocks.max_deg, L, basis, stream()), "bg_spmm_chain_pair_f32")
 
 
-def horner_chain_raw(op: LinOp, Y: torch.Tensor, L: int, W: int, blocks=None) -> torch.Tensor:
-    """sum_k op^k Y_k for Y [N, (L+1)*W] (column group k = Y_k), evaluated as
-    acc = Y_L; acc = op(acc) + Y_k for k = L-1..0.  One launch under the conditions of power_chain_raw."""
+def horner_chain_raw(op: LinOp, Y: torch.Tensor, L: int, W: int, blocks=None, basis=None) -> torch.Tensor:
+    """sum_k op^k Y_k (CHAIN_POWER) or sum_k T_k(op) Y_k (CHAIN_CHEB; default D_BASIS) for Y [N, (L+1)*W] (column
+    group k = Y_k): Horner's rule acc = Y_L; acc = op(acc) + Y_k for k = L-1..0, resp. Clenshaw's
+    b_k = Y_k + 2 op(b_{k+1}) - b_{k+2}, result Y_0 + op(b_1) - b_2.  One launch under the conditions of power_chain_raw."""
     _lib.require_device(Y, "horner_chain")
+    basis = D_BASIS if basis is None else basis
     N = Y.shape[0]
     Y2 = _f32c(Y.view(N, -1))
     if Y2.shape[1] < (L + 1) * W or N != op.csr.n_cols:
@@ -286,11 +301,24 @@ def horner_chain_raw(op: LinOp, Y: torch.Tensor, L: int, W: int, blocks=None) ->
     if _chain_fits(op, blocks, W, Y2, out):
         ld = Y2.stride(0)
         base = Y2.data_ptr()
-        _chain_launch(op, blocks, base + 4 * L * W, ld, base + 4 * (L - 1) * W, ld, -W, out.data_ptr(), W, 0, L, W)
+        _chain_launch(op, blocks, base + 4 * L * W, ld, base + 4 * (L - 1) * W, ld, -W, out.data_ptr(), W, 0, L, W,
+                      CHAIN_CLENSHAW if basis == CHAIN_CHEB else CHAIN_POWER)
         return out
     acc = Y2[:, L * W:(L + 1) * W]
+    if basis != CHAIN_CHEB:
+        for k in range(L - 1, -1, -1):
+            acc = spmm_add_raw(op, acc, Y2[:, k * W:(k + 1) * W], out=out if k == 0 else None)
+        return out
+    b1, b2 = acc, None                                               # b_{k+1}, b_{k+2}
     for k in range(L - 1, -1, -1):
-        acc = spmm_add_raw(op, acc, Y2[:, k * W:(k + 1) * W], out=out if k == 0 else None)
+        t = spmm_raw(op, b1)
+        if k > 0:
+            t.mul_(2.0)
+        if b2 is not None:
+            t.sub_(b2)
+        t.add_(Y2[:, k * W:(k + 1) * W])
+        b1, b2 = t, b1
+    out.copy_(b1)
     return out
 
 
@@ -455,34 +483,38 @@ class SpMMAdd(torch.autograd.Function):
 
 
 class PowerChain(torch.autograd.Function):
-    """Z [N, L+1, W] = (x, op x, .., op^L x); the backward is a HornerChain over the transposed operator."""
+    """Z [N, L+1, W] = (x, op x, .., op^L x), or (T_0(op) x, .., T_L(op) x) in the Chebyshev basis; the backward is a
+    HornerChain over the transposed operator."""
 
     @staticmethod
-    def forward(ctx, x, op: LinOp, L: int, blocks):
+    def forward(ctx, x, op: LinOp, L: int, blocks, basis=None):
         N, W = x.shape
+        basis = D_BASIS if basis is None else basis
         Z = torch.empty(N, L + 1, W, dtype=torch.float32, device=x.device)
         Z[:, 0].copy_(x)
-        power_chain_raw(op, Z, L, W, blocks)
-        ctx.op, ctx.L, ctx.blocks = op, L, blocks
+        power_chain_raw(op, Z, L, W, blocks, basis)
+        ctx.op, ctx.L, ctx.blocks, ctx.basis = op, L, blocks, basis
         return Z
 
     @staticmethod
     def backward(ctx, G):
-        return HornerChain.apply(G, ctx.op.T, ctx.blocks), None, None, None
+        return HornerChain.apply(G, ctx.op.T, ctx.blocks, ctx.basis), None, None, None, None
 
 
 class HornerChain(torch.autograd.Function):
-    """sum_k op^k Y[:, k] for Y [N, L+1, W]; the backward is a PowerChain over the transposed operator."""
+    """sum_k op^k Y[:, k] (or sum_k T_k(op) Y[:, k]) for Y [N, L+1, W]; the backward is a PowerChain over the
+    transposed operator."""
 
     @staticmethod
-    def forward(ctx, Y, op: LinOp, blocks):
+    def forward(ctx, Y, op: LinOp, blocks, basis=None):
         N, L1, W = Y.shape
-        ctx.op, ctx.L, ctx.blocks = op, L1 - 1, blocks
-        return horner_chain_raw(op, Y.contiguous(), L1 - 1, W, blocks)
+        basis = D_BASIS if basis is None else basis
+        ctx.op, ctx.L, ctx.blocks, ctx.basis = op, L1 - 1, blocks, basis
+        return horner_chain_raw(op, Y.contiguous(), L1 - 1, W, blocks, basis)
 
     @staticmethod
     def backward(ctx, g):
-        return PowerChain.apply(g.contiguous(), ctx.op.T, ctx.L, ctx.blocks), None, None
+        return PowerChain.apply(g.contiguous(), ctx.op.T, ctx.L, ctx.blocks, ctx.basis), None, None, None
 
 
 class SpMMW(torch.autograd.Function):
@@ -1317,6 +1349,7 @@ def _critic_head_struct(plan, N, L, ds, dl, H2, Hd, Zs, Zk, W, dec_b, dec_s, wb,
     if blocks is None or st.seg_of is None or sg.seg_of is None or plan.graph_seg.seg_of is None:
         raise _lib.BganError("critic_head: the plan lacks diagonal blocks / segment tables")
     return _lib.CriticHead(N, plan.S, plan.B, L, ds, dl, H2, Hd, blocks.n, blocks.max_rows, blocks.max_nnz, blocks.max_deg,
+                           D_BASIS,
                            ptr(Zs), ptr(Zk), ptr(W), *[ptr(t) for t in dec_b], *[ptr(t) for t in dec_s], ptr(wb), ptr(ws),
                            ptr(st.rowptr), ptr(st.col), ptr(st.seg_of), ptr(sg.rowptr), ptr(sg.col), ptr(sg.seg_of),
                            ptr(plan.graph_seg.seg_of), ptr(A.csr.rowptr), ptr(A.csr.col), ptr(A.row_scale),
@@ -1658,6 +1691,17 @@ class AffineStackT(torch.autograd.Function):
         return (Us[L] if ctx.needs_input_grad[0] else None), gW, None, None
 
 
+def cheb_shift_raw(X: torch.Tensor, out: torch.Tensor, K: int, K_out: int, block_floats: int, transpose: bool) -> None:
+    """include/bgan.h bg_cheb_shift_f32: multiplication by x on K blocks of Chebyshev coefficients (or its adjoint)."""
+    lib = _lib.load()
+    _lib.require_device(X, "cheb_shift")
+    if (not X.is_contiguous() or not out.is_contiguous() or X.numel() < K * block_floats
+            or out.numel() < K_out * block_floats or X.dtype != torch.float32 or out.dtype != torch.float32):
+        raise _lib.BganError("cheb_shift: contiguous fp32 tables of K / K_out blocks expected")
+    check(lib.bg_cheb_shift_f32(ptr(X), ptr(out), K, K_out, block_floats, 1 if transpose else 0, stream()),
+          "bg_cheb_shift_f32")
+
+
 class PolyCoef(torch.autograd.Function):
     """Coefficients of the collapsed discriminator GNN (models.VoxelGNN_D.forward_collapsed).
 
@@ -1670,8 +1714,9 @@ class PolyCoef(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, Wc, X0, E, L: int):
+    def forward(ctx, Wc, X0, E, L: int, basis=None):
         du, H = X0.shape
+        basis = D_BASIS if basis is None else basis
         N = (L + 1) * du
         S = N + du                                    # slab = du zero rows + the state
         dev = X0.device
@@ -1679,21 +1724,27 @@ class PolyCoef(torch.autograd.Function):
         Xall[0, du:2 * du].copy_(X0)
         Efull = torch.zeros(N, H, dtype=torch.float32, device=dev)
         Efull[:du].copy_(E)
+        # Chebyshev basis: shift(X^m) = x * X^m (cheb_shift_raw), kept per layer for the backward at the state's rows
+        ShAll = torch.zeros(L * S + du, H, dtype=torch.float32, device=dev) if basis == CHAIN_CHEB else None
         W2 = Wc[:, :2 * H]
         for m in range(L):
             rows = min(N, (m + 2) * du)               # blocks above m+1 are still zero
             cur = Xall[m]
-            gemm_raw([cur[du:du + rows], cur[:rows]], W2, False, True, residual=cur[du:du + rows],
+            shifted = cur[:rows]                      # monomials: one block down = a row offset
+            if basis == CHAIN_CHEB:
+                shifted = ShAll[m * S + du:m * S + du + rows]
+                cheb_shift_raw(cur[du:], shifted, L + 1, rows // du, du * H, False)
+            gemm_raw([cur[du:du + rows], shifted], W2, False, True, residual=cur[du:du + rows],
                      pre_add=Efull[:rows], out=Xall[m + 1, du:du + rows])
-        ctx.L, ctx.du = L, du
-        ctx.save_for_backward(Xall, Wc)
+        ctx.L, ctx.du, ctx.basis = L, du, basis
+        ctx.save_for_backward(Xall, Wc, ShAll)
         return Xall[L, du:]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
-        Xall, Wc = ctx.saved_tensors
-        L, du = ctx.L, ctx.du
+        Xall, Wc, ShAll = ctx.saved_tensors
+        L, du, basis = ctx.L, ctx.du, ctx.basis
         H = g.shape[1]
         N = (L + 1) * du
         S = N + du
@@ -1702,22 +1753,27 @@ class PolyCoef(torch.autograd.Function):
         Gall = torch.zeros(L + 1, S, H, dtype=torch.float32, device=dev)
         Gall[L, :N].copy_(g)
         Wab = torch.cat([Wc[:, :H], Wc[:, H:2 * H]], dim=0)          # [2H, H]: G Wa + shiftup(G) Wb
+        sht = torch.empty(N, H, dtype=torch.float32, device=dev) if basis == CHAIN_CHEB else None
         for m in range(L - 1, -1, -1):
             nxt = Gall[m + 1]
-            gemm_raw([nxt[:N], nxt[du:du + N]], Wab, False, False, residual=nxt[:N], out=Gall[m, :N])
+            up = nxt[du:du + N]
+            if basis == CHAIN_CHEB:                                   # the adjoint of x * (.)
+                cheb_shift_raw(nxt, sht, L + 1, L + 1, du * H, True)
+                up = sht
+            gemm_raw([nxt[:N], up], Wab, False, False, residual=nxt[:N], out=Gall[m, :N])
         gW = gX0 = gE = None
         if ctx.needs_input_grad[0]:
             # dWc[:, :2H] = sum_m G^{m+1 T} [X^m | shift(X^m)]: slabs share one pitch, so the sum over
             # layers is one long reduction (pad rows of G are zero, whatever X rows they meet)
             Gf = Gall[1:L + 1].reshape(L * S, H)
             Xf = Xall.view((L + 1) * S, H)
-            gW2 = gemm_tn_raw(Gf, [Xf[du:du + L * S], Xf[:L * S]])
+            gW2 = gemm_tn_raw(Gf, [Xf[du:du + L * S], ShAll[du:du + L * S] if basis == CHAIN_CHEB else Xf[:L * S]])
             gW = torch.nn.functional.pad(gW2, (0, Wc.shape[1] - 2 * H))
         if ctx.needs_input_grad[1]:
             gX0 = Gall[0, :du].clone()
         if ctx.needs_input_grad[2]:
             gE = Gall[1:L + 1, :du].sum(dim=0)
-        return gW, gX0, gE, None
+        return gW, gX0, gE, None, None
 
 
 class PolyCoefD(torch.autograd.Function):
@@ -1731,7 +1787,7 @@ class PolyCoefD(torch.autograd.Function):
     Returns X^L [(L+1)*(ds+dl), 2H] as PolyCoef does."""
 
     @staticmethod
-    def forward(ctx, Wc, bc, fe_w, fe_b, le_w, le_b, pe, L: int, ds: int, dl: int):
+    def forward(ctx, Wc, bc, fe_w, fe_b, le_w, le_b, pe, L: int, ds: int, dl: int, basis=None):
         lib = _lib.load()
         _lib.require_device(Wc, "PolyCoefD")
         H2 = Wc.shape[0]
@@ -1744,18 +1800,22 @@ class PolyCoefD(torch.autograd.Function):
         S = N + du
         dev = Wc.device
         Wc2, args = _f32c(Wc), [_f32c(t).contiguous() for t in (fe_w, fe_b, le_w, le_b, pe, bc)]
+        basis = D_BASIS if basis is None else basis
+        cheb = basis == CHAIN_CHEB
+        n_x, n_e, n_sh = (L + 1) * S * H2, N * H2, ((L * S + du) * H2 if cheb else 0)
         if FUSE_COEF_RECURRENCE:
             # clear + parameter rows + the L products in one host call (shapes depend on the parameters alone)
-            buf = torch.empty((L + 1) * S * H2 + N * H2, dtype=torch.float32, device=dev)
-            Xall = buf[:(L + 1) * S * H2].view(L + 1, S, H2)
-            Efull = buf[(L + 1) * S * H2:].view(N, H2)
-            check(lib.bg_d_coef_forward_f32(ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(args[4]), ptr(Wc2),
-                                            _ld(Wc2), ptr(args[5]), H, nf, nl, ML, ds, dl, L, ptr(Xall), ptr(Efull),
-                                            stream()), "bg_d_coef_forward_f32")
+            buf = torch.empty(n_x + n_e + n_sh, dtype=torch.float32, device=dev)
         else:
-            buf = torch.zeros((L + 1) * S * H2 + N * H2, dtype=torch.float32, device=dev)     # one fill for both
-            Xall = buf[:(L + 1) * S * H2].view(L + 1, S, H2)
-            Efull = buf[(L + 1) * S * H2:].view(N, H2)
+            buf = torch.zeros(n_x + n_e + n_sh, dtype=torch.float32, device=dev)     # one fill for all three
+        Xall = buf[:n_x].view(L + 1, S, H2)
+        Efull = buf[n_x:n_x + n_e].view(N, H2)
+        ShAll = buf[n_x + n_e:].view(L * S + du, H2) if cheb else None
+        if FUSE_COEF_RECURRENCE:
+            check(lib.bg_d_coef_forward_f32(ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(args[4]), ptr(Wc2),
+                                            _ld(Wc2), ptr(args[5]), H, nf, nl, ML, ds, dl, L, basis, ptr(Xall), ptr(Efull),
+                                            ptr(ShAll), stream()), "bg_d_coef_forward_f32")
+        else:
             check(lib.bg_d_coef_init_f32(ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(args[4]), ptr(Wc2),
                                          _ld(Wc2), ptr(args[5]), H, nf, nl, ML, ds, dl, ptr(Xall[0, du:2 * du]),
                                          ptr(Efull[:du]), stream()), "bg_d_coef_init_f32")
@@ -1763,18 +1823,23 @@ class PolyCoefD(torch.autograd.Function):
             for m in range(L):
                 rows = min(N, (m + 2) * du)               # blocks above m+1 are still zero
                 cur = Xall[m]
-                gemm_raw([cur[du:du + rows], cur[:rows]], W2, False, True, residual=cur[du:du + rows],
+                shifted = cur[:rows]
+                if cheb:
+                    shifted = ShAll[m * S + du:m * S + du + rows]
+                    cheb_shift_raw(cur[du:], shifted, L + 1, rows // du, du * H2, False)
+                gemm_raw([cur[du:du + rows], shifted], W2, False, True, residual=cur[du:du + rows],
                          pre_add=Efull[:rows], out=Xall[m + 1, du:du + rows])
-        ctx.dims = (L, du, ds, dl, H, nf, nl, ML)
-        ctx.save_for_backward(Xall, Wc2)
+        ctx.dims = (L, du, ds, dl, H, nf, nl, ML, basis)
+        ctx.save_for_backward(Xall, Wc2, ShAll)
         return Xall[L, du:]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         lib = _lib.load()
-        Xall, Wc = ctx.saved_tensors
-        L, du, ds, dl, H, nf, nl, ML = ctx.dims
+        Xall, Wc, ShAll = ctx.saved_tensors
+        L, du, ds, dl, H, nf, nl, ML, basis = ctx.dims
+        cheb = basis == CHAIN_CHEB
         H2 = 2 * H
         N = (L + 1) * du
         S = N + du
@@ -1785,26 +1850,34 @@ class PolyCoefD(torch.autograd.Function):
         g_fe_b = torch.empty(H, dtype=torch.float32, device=dev)
         g_le_b = torch.empty(H, dtype=torch.float32, device=dev)
         g_bc = torch.empty(H2, dtype=torch.float32, device=dev)
+        none = (None,) * 5
         if FUSE_COEF_RECURRENCE and L >= 1 and Wc.stride(1) == 1:
             g2 = _f32c(g).contiguous()
             nws = int(lib.bg_d_coef_backward_workspace(H, ds, dl, L))
-            work = torch.empty((L + 1) * S * H2 + 2 * H2 * H2 + nws, dtype=torch.float32, device=dev)
-            Gall, Wab, partial = work[:(L + 1) * S * H2], work[(L + 1) * S * H2:(L + 1) * S * H2 + 2 * H2 * H2], \
-                work[(L + 1) * S * H2 + 2 * H2 * H2:]
-            check(lib.bg_d_coef_backward_f32(ptr(g2), ptr(Xall), ptr(Wc), _ld(Wc), H, nf, nl, ML, ds, dl, L, ptr(Gall),
-                                             ptr(Wab), ptr(partial), ptr(gW), ptr(g_bc), ptr(g_fe_w), ptr(g_fe_b),
-                                             ptr(g_le_w), ptr(g_le_b), stream()), "bg_d_coef_backward_f32")
-            return gW, g_bc, g_fe_w, g_fe_b, g_le_w, g_le_b, None, None, None, None
+            n_g, n_w, n_t = (L + 1) * S * H2, 2 * H2 * H2, (N * H2 if cheb else 0)
+            work = torch.empty(n_g + n_w + n_t + nws, dtype=torch.float32, device=dev)
+            Gall, Wab = work[:n_g], work[n_g:n_g + n_w]
+            sht = work[n_g + n_w:n_g + n_w + n_t] if cheb else None
+            partial = work[n_g + n_w + n_t:]
+            check(lib.bg_d_coef_backward_f32(ptr(g2), ptr(Xall), ptr(ShAll), ptr(Wc), _ld(Wc), H, nf, nl, ML, ds, dl, L, basis,
+                                             ptr(sht), ptr(Gall), ptr(Wab), ptr(partial), ptr(gW), ptr(g_bc), ptr(g_fe_w),
+                                             ptr(g_fe_b), ptr(g_le_w), ptr(g_le_b), stream()), "bg_d_coef_backward_f32")
+            return (gW, g_bc, g_fe_w, g_fe_b, g_le_w, g_le_b) + none
         Gall = torch.zeros(L + 1, S, H2, dtype=torch.float32, device=dev)
         Gall[L, :N].copy_(g)
         Wab = torch.cat([Wc[:, :H2], Wc[:, H2:2 * H2]], dim=0)       # [2*H2, H2]: G Wa + shiftup(G) Wb
+        sht = torch.empty(N, H2, dtype=torch.float32, device=dev) if cheb else None
         for m in range(L - 1, -1, -1):
             nxt = Gall[m + 1]
-            gemm_raw([nxt[:N], nxt[du:du + N]], Wab, False, False, residual=nxt[:N], out=Gall[m, :N])
+            up = nxt[du:du + N]
+            if cheb:
+                cheb_shift_raw(nxt, sht, L + 1, L + 1, du * H2, True)
+                up = sht
+            gemm_raw([nxt[:N], up], Wab, False, False, residual=nxt[:N], out=Gall[m, :N])
         Gf = Gall[1:L + 1].reshape(L * S, H2)
         Xf = Xall.view((L + 1) * S, H2)
-        gemm_tn_raw(Gf, [Xf[du:du + L * S], Xf[:L * S]], out=gW[:, :2 * H2])
+        gemm_tn_raw(Gf, [Xf[du:du + L * S], ShAll[du:du + L * S] if cheb else Xf[:L * S]], out=gW[:, :2 * H2])
         check(lib.bg_d_coef_init_bwd_f32(ptr(Gall), S * H2, L, H, nf, nl, ML, ds, dl, ptr(g_fe_w), ptr(g_fe_b),
                                          ptr(g_le_w), ptr(g_le_b), gW.data_ptr() + 4 * 2 * H2, 2 * H2 + 4, ptr(g_bc),
                                          stream()), "bg_d_coef_init_bwd_f32")
-        return gW, g_bc, g_fe_w, g_fe_b, g_le_w, g_le_b, None, None, None, None
+        return (gW, g_bc, g_fe_w, g_fe_b, g_le_w, g_le_b) + none

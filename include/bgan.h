@@ -152,25 +152,34 @@ int bg_spmm_add_f32(const float* x, int64_t ldx, const int32_t* rowptr, const in
  * registers).  One workgroup per (block, 4 columns) keeps the block in LDS between steps; BG_ERR_SHAPE when a block does not fit (the caller then launches the steps one by
  * one with bg_spmm_add_f32).  W % 4 == 0, 16-byte aligned operands.  Each step is the same arithmetic
  * in the same order as the separate launch.
+ * basis selects the recurrence: BG_CHAIN_POWER as above (y_k = P^k y_0: the monomial basis);
+ *   BG_CHAIN_CHEB      y_1 = P y_0, y_k = 2 P y_{k-1} - y_{k-2}  (y_k = T_k(P) y_0, Chebyshev polynomials of the
+ *                      operator: a mean-aggregation operator has its spectrum in [-1, 1], where the T_k stay bounded
+ *                      by 1 and the collapsed discriminator's coefficient table stays well conditioned);
+ *   BG_CHAIN_CLENSHAW  y_k = 2 P y_{k-1} - y_{k-2} + add_k with factor 1 at the last step: for x0 = g_n and
+ *                      add_k = g_{n-k} the result is sum_j T_j(P) g_j (Clenshaw), the transpose of BG_CHAIN_CHEB.
  * replaces: the repeated propagate() of one VoxelBlock over the SAME operator, Model/models.py:227-228
  * (12 layers of the discriminator's linear voxel GNN, evaluated as operator powers on the input columns,
  * and the transposed chain of its input gradient, Model/losses.py:83-84).                          */
+enum { BG_CHAIN_POWER = 0, BG_CHAIN_CHEB = 1, BG_CHAIN_CLENSHAW = 2 };
 int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const int32_t* col,
                       const float* row_scale, int row_mode, const float* col_scale, int col_mode,
                       const int32_t* blk_ptr, int64_t n_blk, int64_t max_rows, int64_t max_nnz, int64_t max_deg,
                       const float* add, int64_t ld_add, int64_t add_step,
-                      float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, bgStream stream);
+                      float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, int32_t basis,
+                      bgStream stream);
 
 /* bg_spmm_chain_f32 (no addend) on TWO matrices under the same operator and step count in one launch: the
  * column chunks of both fill the chip side by side (a chain's time does not depend on its width).  Short-row
  * plans only (max_deg <= 8, max_rows <= 2048), else BG_ERR_SHAPE and the caller launches them one by one.
+ * basis: BG_CHAIN_POWER or BG_CHAIN_CHEB.
  * replaces: the label-free and the label operator powers of the collapsed discriminator, Model/models.py:227-228. */
 int bg_spmm_chain_pair_f32(const float* x0, int64_t ldx, float* out, int64_t ldo, int64_t out_step, int64_t W,
                            const float* x0b, int64_t ldxb, float* outb, int64_t ldob, int64_t out_stepb, int64_t Wb,
                            const int32_t* rowptr, const int32_t* col,
                            const float* row_scale, int row_mode, const float* col_scale, int col_mode,
                            const int32_t* blk_ptr, int64_t n_blk, int64_t max_rows, int64_t max_nnz, int64_t max_deg,
-                           int64_t n_steps, bgStream stream);
+                           int64_t n_steps, int32_t basis, bgStream stream);
 
 /* Same contraction for LONG rows, two phases: phase 1 reduces chunks of at most rows_per_chunk
  * slots (chunk_ptr from bg_plan_chunks, n_chunks_ub >= chunk_ptr[n_rows]) into
@@ -372,6 +381,16 @@ int bg_d_coef_init_f32(const float* fe_w, const float* fe_b, const float* le_w, 
                        const float* Wc, int64_t ldw, const float* bc, int64_t H, int64_t nf, int64_t nl, int64_t ML,
                        int64_t ds, int64_t dl, float* x0, float* e, bgStream stream);
 
+/* Multiplication by x on a table of Chebyshev coefficients: x [K, block_floats] (block j = the coefficient of T_j,
+ * contiguous), out the same shape, blocks [0, K_out) written:
+ *   transpose == 0:  out_i = d_i x_{i-1} + x_{i+1} / 2  with d_1 = 1, d_i = 1/2 otherwise (x_{-1} = x_K = 0)
+ *   transpose != 0:  out_0 = x_1,  out_j = (x_{j-1} + x_{j+1}) / 2          (the adjoint map)
+ * block_floats % 4 == 0, 16-byte aligned, out != x.
+ * no counterpart in the reference (which evaluates its 12 layers one by one, Model/models.py:227-228): this is the
+ * layer recurrence of the collapsed discriminator written in the basis T_j(A) instead of A^j.                */
+int bg_cheb_shift_f32(const float* x, float* out, int64_t K, int64_t K_out, int64_t block_floats, int32_t transpose,
+                      bgStream stream);
+
 /* Backward of bg_d_coef_init_f32: G = L+1 slabs (pitch `slab` floats) of gradient states [.., 2H]; rows [0, du)
  * of slab 0 are d/d x0, the sum over slabs 1..L of rows [0, du) is d/d e.  Writes the gradients of fe_w, fe_b,
  * le_w, le_b (contiguous), of Wc's position block (gw_tail = &gWc[0, 4H], pitch ldw) and of bc.           */
@@ -521,13 +540,19 @@ int bg_generator_forward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan*
  *   from row du on.
  * backward: g [N, 2H] (contiguous) = d/d X^L.  gall [(L+1) S, 2H], wab [4H, 2H] and partial (floats: see
  *   bg_d_coef_backward_workspace) are workspaces; writes gW [2H, 4H+4] (pitch 4H+4) and the encoders' gradients.
+ * basis == BG_CHAIN_CHEB: row block j of a state is the coefficient of T_j(A) instead of A^j; shift(X) becomes
+ *   bg_cheb_shift_f32(X) (one more launch per layer), kept for the backward in shall [L S + du, 2H] (slab m rows
+ *   [du, du+N) = shift(X^m); cleared here); the backward needs sht [N, 2H] for the adjoint shift of a gradient state.
+ *   Both are NULL for BG_CHAIN_POWER.
  * replaces: the same 15 / 18 launches issued one by one from the host.                                  */
 int bg_d_coef_forward_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b, const float* pe,
                           const float* Wc, int64_t ldw, const float* bc, int64_t H, int64_t nf, int64_t nl, int64_t ML,
-                          int64_t ds, int64_t dl, int64_t L, float* xall, float* efull, bgStream stream);
+                          int64_t ds, int64_t dl, int64_t L, int32_t basis, float* xall, float* efull, float* shall,
+                          bgStream stream);
 int64_t bg_d_coef_backward_workspace(int64_t H, int64_t ds, int64_t dl, int64_t L);   /* floats of `partial` */
-int bg_d_coef_backward_f32(const float* g, const float* xall, const float* Wc, int64_t ldw, int64_t H, int64_t nf,
-                           int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L, float* gall, float* wab,
+int bg_d_coef_backward_f32(const float* g, const float* xall, const float* shall, const float* Wc, int64_t ldw, int64_t H,
+                           int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L, int32_t basis,
+                           float* sht, float* gall, float* wab,
                            float* partial, float* gW, float* g_bc, float* g_fe_w, float* g_fe_b, float* g_le_w,
                            float* g_le_b, bgStream stream);
 
@@ -618,6 +643,7 @@ int bg_add_f32(const float* a, const float* b, float* out, int64_t n, bgStream s
 typedef struct {
     int64_t N, S, B, L, ds, dl, H2, Hd;
     int64_t blk_n, blk_max_rows, blk_max_nnz, blk_max_deg;      /* diagonal blocks of the voxel operator (bg_spmm_chain_f32) */
+    int64_t basis;                                              /* BG_CHAIN_POWER: Zs / Zk / W in powers A^k; BG_CHAIN_CHEB: in T_k(A) */
     const float *Zs;                                            /* [N, (L+1) ds] label-free operator powers                  */
     const float *Zk;                                            /* [N, L+1, 3, dl] label powers of (real, fake, sample)      */
     const float *W;                                             /* [(L+1) ds + (L+1) dl, H2] coefficient table (rows: static | label) */

@@ -72,13 +72,33 @@ int bg_attention_fwd_f32(const float* a_, int64_t lda, const float* logits, int6
     return 0;
 }
 int bg_d_coef_init_f32(const float*, const float*, const float*, const float*, const float*, const float*, int64_t,
-                       const float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, float*, float*, bgStream) { return 0; }
-int bg_d_coef_init_bwd_f32(const float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, float*,
-                           float*, float*, float*, float*, int64_t, float*, bgStream) { return 0; }
+                       const float*, int64_t H, int64_t, int64_t, int64_t, int64_t ds, int64_t dl, float* x0, float* e, bgStream) {
+    int64_t a[] = {P(x0), P(e), (ds + dl) * 2 * H};
+    rec(30, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_d_coef_init_bwd_f32(const float* G, int64_t slab, int64_t L, int64_t H, int64_t, int64_t, int64_t, int64_t ds,
+                           int64_t dl, float*, float*, float*, float*, float* gw_tail, int64_t ldw, float*, bgStream) {
+    int64_t a[] = {P(G), slab, L, (ds + dl) * 2 * H, P(gw_tail), ldw};
+    rec(31, a, sizeof(a) / 8);
+    return 0;
+}
+// device-to-device copies of the coefficient composites
+int hipMemcpyAsync(void* dst, const void* src, size_t bytes, int, void*) {
+    int64_t a[] = {P(dst), (int64_t)bytes, P(src), (int64_t)bytes, (int64_t)bytes, 1};
+    rec(20, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_cheb_shift_f32(const float* x, float* out, int64_t K, int64_t K_out, int64_t block_floats, int32_t transpose, bgStream) {
+    int64_t a[] = {P(x), P(out), K, K_out, block_floats, transpose};
+    rec(29, a, sizeof(a) / 8);
+    return 0;
+}
 int bg_gemm_tn_splitk_f32(int64_t M, int64_t R, const float* A, int64_t lda, int n_seg, const float* const* B,
                           const int64_t* ldb, const int64_t* Ns, float* C, int64_t ldc, float* partial, int32_t splits,
                           int accumulate, bgStream) {
-    int64_t a[] = {M, R, P(A), lda, n_seg, P(B[0]), ldb[0], Ns[0], P(C), ldc, P(partial), splits, accumulate};
+    int64_t a[] = {M, R, P(A), lda, n_seg, P(B[0]), ldb[0], Ns[0], P(C), ldc, P(partial), splits, accumulate,
+                   n_seg > 1 ? P(B[1]) : 0, n_seg > 1 ? ldb[1] : 0, n_seg > 1 ? Ns[1] : 0};
     rec(19, a, sizeof(a) / 8);
     return 0;
 }
@@ -109,9 +129,9 @@ int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, const in
 int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* row_scale,
                       int row_mode, const float* col_scale, int col_mode, const int32_t* blk_ptr, int64_t n_blk,
                       int64_t max_rows, int64_t max_nnz, int64_t max_deg, const float* add, int64_t ld_add, int64_t add_step,
-                      float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, bgStream) {
+                      float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, int32_t basis, bgStream) {
     int64_t a[] = {P(x0), ldx, P(rowptr), P(col), P(row_scale), row_mode, P(col_scale), col_mode, P(blk_ptr), n_blk,
-                   max_rows, max_nnz, max_deg, P(add), ld_add, add_step, P(out), ldo, out_step, n_steps, W};
+                   max_rows, max_nnz, max_deg, P(add), ld_add, add_step, P(out), ldo, out_step, n_steps, W, basis};
     rec(14, a, sizeof(a) / 8);
     return 0;
 }

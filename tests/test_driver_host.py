@@ -307,14 +307,14 @@ def test_generator_python_binding_hands_the_right_buffers_to_the_driver(drv, mon
 
 
 # ------------------------------------------------------------------------------------ critic head (bg_critic_head_*)
-def _critic_run(lib, N, S, B, L=12, ds=32, dl=8, H2=256, Hd=128, max_rows=None):
+def _critic_run(lib, N, S, B, L=12, ds=32, dl=8, H2=256, Hd=128, max_rows=None, basis=1):
     import sys
     sys.path.insert(0, ROOT)
     from building_gan_amd._lib import CriticHead
     R = Ranges()
     f, K1, Ev = 4, L + 1, 6 * N
     max_rows = max_rows or (N + B - 1) // B
-    h = CriticHead(N, S, B, L, ds, dl, H2, Hd, B, max_rows, 6 * max_rows, 6,
+    h = CriticHead(N, S, B, L, ds, dl, H2, Hd, B, max_rows, 6 * max_rows, 6, basis,
                    R.new("Zs", N * K1 * ds * f), R.new("Zk", N * K1 * 3 * dl * f), R.new("W", K1 * (ds + dl) * H2 * f),
                    R.new("b_w1", Hd * H2 * f), R.new("b_b1", Hd * f), R.new("b_w2", Hd * f), R.new("b_b2", f),
                    R.new("s_w1", Hd * H2 * f), R.new("s_b1", Hd * f), R.new("s_w2", Hd * f), R.new("s_b2", f),
@@ -420,7 +420,9 @@ def _check_critic_calls(calls, R, h):
             R.check(out, ((n_rows - 1) * ldo + H) * f, tag + " out")
         elif kind == 14:
             (x0, ldx, rp, col, rsc, rm, csc, cm, blk, n_blk, mr, mn, md, add, ld_add, add_step, out, ldo, out_step,
-             n_steps, W) = a
+             n_steps, W, basis) = a
+            # a chain with addends sums polynomials of the operator (Horner / Clenshaw), one without makes them
+            assert basis == ((2 if add else 1) if h.basis else 0), tag
             R.check(x0, ((N - 1) * ldx + W) * f, tag + " x0")
             R.check(rp, (N + 1) * 4, tag + " rowptr")
             R.check(blk, (n_blk + 1) * 4, tag + " blk_ptr")
@@ -453,7 +455,7 @@ def _check_critic_calls(calls, R, h):
             for q in (x, y, out):
                 R.check(q, n * f, tag)
         elif kind == 19:
-            M, Rr, A, lda, n_seg, B0, ldb0, N0, Cp, ldc, part, splits, accum = a
+            M, Rr, A, lda, n_seg, B0, ldb0, N0, Cp, ldc, part, splits, accum = a[:13]
             assert n_seg == 1 and lda >= M and ldb0 >= N0 and ldc >= N0 and splits >= 1
             R.check(A, ((Rr - 1) * lda + M) * f, tag + " A")
             R.check(B0, ((Rr - 1) * ldb0 + N0) * f, tag + " B")
@@ -467,9 +469,9 @@ def _check_critic_calls(calls, R, h):
             raise AssertionError("unexpected launcher %d" % kind)
 
 
-@pytest.mark.parametrize("N,S,B", [(11520, 80, 8), (10130, 75, 8), (7, 3, 2), (1001, 17, 3)])
-def test_critic_head_host_sequence_and_extents(drv, N, S, B):
-    (rc_f, rc_b), fwd, bwd, R, h = _critic_run(drv, N, S, B)
+@pytest.mark.parametrize("N,S,B,basis", [(11520, 80, 8, 1), (10130, 75, 8, 0), (7, 3, 2, 1), (1001, 17, 3, 1)])
+def test_critic_head_host_sequence_and_extents(drv, N, S, B, basis):
+    (rc_f, rc_b), fwd, bwd, R, h = _critic_run(drv, N, S, B, basis=basis)
     assert rc_f == 0 and rc_b == 0
     assert [k for k, _ in fwd] == [10, 1, 28, 1, 11, 11, 11, 11, 1, 1, 1, 1, 11, 11, 12, 1, 1, 13, 13, 1, 10, 14, 15]
     assert [k for k, _ in bwd] == ([16, 20, 14, 10, 1, 12, 12, 17, 17, 1, 1, 1, 1] + [19, 17, 1, 19, 17, 1, 13, 13]
@@ -502,6 +504,7 @@ def test_critic_head_rejects_unsupported_sizes(drv):
     assert _critic_run(drv, 100, 10, 2, ds=30)[0] == -1          # workspace query: widths must be multiples of 4
     rc, *_ = _critic_run(drv, 100, 10, 2, L=0)
     assert rc == -1
+    assert _critic_run(drv, 100, 10, 2, basis=2)[0] == -1       # the struct's basis is POWER or CHEB
 
 
 # ------------------------------------------------------------------------------------ generator stack (bg_gstack_*)
@@ -661,7 +664,7 @@ def _check_generic(calls, R, z):
             for q in (x, y, out):
                 R.check(q, n * f, tag)
         elif kind == 19:
-            M, Rr, A, lda, n_seg, B0, ldb0, N0, Cp, ldc, part, splits, accum = a
+            M, Rr, A, lda, n_seg, B0, ldb0, N0, Cp, ldc, part, splits, accum = a[:13]
             assert lda >= M and ldb0 >= N0 and ldc >= N0 and splits >= 1
             R.check(A, ((Rr - 1) * lda + M) * f, tag + " A")
             R.check(B0, ((Rr - 1) * ldb0 + N0) * f, tag + " B0")
@@ -811,7 +814,7 @@ def test_pstack_host_sequence_and_extents(drv, Np, L):
             x, ldx, M, Nn, part, nb, out, accum = a
             R.check(x, ((M - 1) * ldx + Nn) * f, tag); R.check(part, nb * Nn * f, tag); R.check(out, Nn * f, tag)
         elif kind == 19:
-            M, Rr, A, lda, n_seg, B0, ldb0, N0, Cp, ldc, part, splits, accum = a
+            M, Rr, A, lda, n_seg, B0, ldb0, N0, Cp, ldc, part, splits, accum = a[:13]
             R.check(A, ((Rr - 1) * lda + M) * f, tag); R.check(B0, ((Rr - 1) * ldb0 + N0) * f, tag)
             R.check(Cp, M * ldc * f, tag); R.check(part, splits * M * ldc * f, tag)
         elif kind == 26:
@@ -872,3 +875,97 @@ def test_gloss_head_host_sequence_and_extents(drv, N, S, B):
         else:
             _check_critic_calls([(kind, a)], R, h)
     assert R.check([a for k, a in bwd if k == 20][0][0], 4, "dst") == "g_label"
+
+
+# ------------------------------------------------------------------------------------ coefficient recurrence (bg_d_coef_*)
+@pytest.mark.parametrize("basis", [0, 1])
+@pytest.mark.parametrize("L", [12, 1])
+def test_d_coef_host_sequence_and_extents(drv, basis, L):
+    """bg_d_coef_forward_f32 / _backward_f32: the launch sequence per basis (one bg_cheb_shift_f32 before every product in
+    the Chebyshev basis), every operand inside the buffer the caller handed in, the second reduction operand = the kept
+    shifts (Chebyshev) or the state one block down (monomials)."""
+    f, H, nf, nl, ML, ds, dl = 4, 128, 4, 6, 20, 32, 8
+    H2, du = 2 * H, ds + dl
+    N, ldw = (L + 1) * du, 4 * H + 4
+    S = N + du
+    R = Ranges()
+    par = [R.new(n, b * f) for n, b in (("fe_w", H * nf), ("fe_b", H), ("le_w", H * nl), ("le_b", H), ("pe", ML * H))]
+    Wc, bc = R.new("Wc", H2 * ldw * f), R.new("bc", H2 * f)
+    xall, efull = R.new("xall", (L + 1) * S * H2 * f), R.new("efull", N * H2 * f)
+    shall = R.new("shall", (L * S + du) * H2 * f) if basis else None
+    drv.bg_d_coef_forward_f32.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_void_p] + [C.c_int64] * 7 + [C.c_int32] + [C.c_void_p] * 4
+
+    def calls_of(fn, *args):
+        drv.stub_reset()
+        rc = fn(*args)
+        return rc, [(drv.stub_call(i)[0], [drv.stub_call(i)[2 + k] for k in range(drv.stub_call(i)[1])])
+                    for i in range(drv.stub_count())]
+    rc, fwd = calls_of(drv.bg_d_coef_forward_f32, *par, Wc, ldw, bc, H, nf, nl, ML, ds, dl, L, basis, xall, efull, shall, None)
+    assert rc == 0
+    assert [k for k, _ in fwd] == [25] * (3 if basis else 2) + [30] + ([29, 1] if basis else [1]) * L
+    cleared = {R.check(a[0], a[2], "memset"): a[2] for k, a in fwd if k == 25}
+    assert cleared == {n: R.r[n][1] for n in (("xall", "efull", "shall") if basis else ("xall", "efull"))}
+    m = 0
+    for k, a in fwd:
+        if k == 30:
+            assert R.check(a[0], a[2] * f, "x0") == "xall" and a[0] == xall + du * H2 * f and a[1] == efull
+        elif k == 29:
+            x, out, K, K_out, blk, tr = a
+            assert (K, blk, tr) == (L + 1, du * H2, 0) and K_out == min(L + 1, m + 2)
+            assert x == xall + (m * S + du) * H2 * f and out == shall + (m * S + du) * H2 * f
+            R.check(x, K * blk * f, "shift in"); R.check(out, K_out * blk * f, "shift out")
+        elif k == 1:
+            (tA, tB, M, Nn, n_seg), A, lda, Ks = a[0:5], a[5:9], a[9:13], a[13:17]
+            assert (tA, tB, Nn, n_seg, list(Ks[:2])) == (0, 1, H2, 2, [H2, H2]) and M == min(N, (m + 2) * du)
+            assert A[0] == xall + (m * S + du) * H2 * f
+            assert A[1] == ((shall + (m * S + du) * H2 * f) if basis else (xall + m * S * H2 * f))
+            for sgm in range(2):
+                R.check(A[sgm], M * H2 * f, "A%d" % sgm)
+            assert a[19] == xall + ((m + 1) * S + du) * H2 * f and a[24] == A[0] and a[26] == efull
+            R.check(a[19], M * H2 * f, "C"); R.check(a[26], M * H2 * f, "pre_add")
+            m += 1
+    assert m == L
+    # ---- backward
+    drv.bg_d_coef_backward_workspace.restype = C.c_int64
+    drv.bg_d_coef_backward_workspace.argtypes = [C.c_int64] * 4
+    nws = drv.bg_d_coef_backward_workspace(H, ds, dl, L)
+    assert nws > 0
+    g, gall, wab = R.new("g", N * H2 * f), R.new("gall", (L + 1) * S * H2 * f), R.new("wab", 2 * H2 * H2 * f)
+    sht = R.new("sht", N * H2 * f) if basis else None
+    partial, gW = R.new("partial", nws * f), R.new("gW", H2 * ldw * f)
+    outs = [R.new(n, b * f) for n, b in (("g_bc", H2), ("g_fe_w", H * nf), ("g_fe_b", H), ("g_le_w", H * nl), ("g_le_b", H))]
+    drv.bg_d_coef_backward_f32.argtypes = [C.c_void_p] * 4 + [C.c_int64] * 8 + [C.c_int32] + [C.c_void_p] * 11
+    rc, bwd = calls_of(drv.bg_d_coef_backward_f32, g, xall, shall, Wc, ldw, H, nf, nl, ML, ds, dl, L, basis, sht, gall, wab,
+                       partial, gW, *outs, None)
+    assert rc == 0
+    assert [k for k, _ in bwd] == [25, 20, 20, 20] + ([29, 1] if basis else [1]) * L + [19, 31]
+    m = L - 1
+    for k, a in bwd:
+        if k == 25:
+            assert R.check(a[0], a[2], "memset") == "gall" and a[2] == R.r["gall"][1]
+        elif k == 20:
+            dst, dp, src, sp, width, height = a
+            R.check(dst, (height - 1) * dp + width, "copy dst"); R.check(src, (height - 1) * sp + width, "copy src")
+        elif k == 29:
+            x, out, K, K_out, blk, tr = a
+            assert (K, K_out, blk, tr) == (L + 1, L + 1, du * H2, 1) and x == gall + (m + 1) * S * H2 * f and out == sht
+        elif k == 1:
+            A = a[5:9]
+            assert a[2] == N and A[0] == gall + (m + 1) * S * H2 * f and a[19] == gall + m * S * H2 * f
+            assert A[1] == (sht if basis else A[0] + du * H2 * f)
+            R.check(A[1], N * H2 * f, "shifted gradient state")
+            m -= 1
+        elif k == 19:
+            M, Rr, A, lda, n_seg, B0, ldb0, N0, Cp, ldc, part, splits, accum, B1, ldb1, N1 = a
+            assert (M, Rr, n_seg, N0, N1, accum) == (H2, L * S, 2, H2, H2, 0) and A == gall + S * H2 * f
+            assert B0 == xall + du * H2 * f and B1 == ((shall + du * H2 * f) if basis else xall)
+            R.check(A, Rr * H2 * f, "G"); R.check(B0, Rr * H2 * f, "X"); R.check(B1, Rr * H2 * f, "shift(X)")
+            assert R.check(Cp, ((M - 1) * ldc + N0 + N1) * f, "gW") == "gW" and ldc == ldw
+            R.check(part, splits * M * (N0 + N1) * f, "partial")
+        elif k == 31:
+            assert a[0] == gall and a[1] == S * H2 and a[4] == gW + 2 * H2 * f
+    assert m == -1
+    if basis:        # the Chebyshev form without its extra buffers is refused, not run
+        assert drv.bg_d_coef_forward_f32(*par, Wc, ldw, bc, H, nf, nl, ML, ds, dl, L, 1, xall, efull, None, None) != 0
+        assert drv.bg_d_coef_backward_f32(g, xall, shall, Wc, ldw, H, nf, nl, ML, ds, dl, L, 1, None, gall, wab, partial, gW,
+                                          *outs, None) != 0

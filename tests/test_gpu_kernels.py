@@ -572,12 +572,22 @@ def test_splitk_small_output_reduce(cuda):
     assert float((out.cpu().double() - ref).abs().max()) < 1e-3
 
 
+def _cheb_dense(A, L):
+    """[T_0(A), .., T_L(A)] in fp64 (dense)."""
+    T = [torch.eye(A.shape[0], dtype=torch.float64), A]
+    for k in range(2, L + 1):
+        T.append(2 * A @ T[-1] - T[-2])
+    return T[:L + 1]
+
+
+@pytest.mark.parametrize("basis", [0, 1])
 @pytest.mark.parametrize("preset,ragged,W,L", [("small", True, 8, 5), ("dataset", False, 32, 12), ("dataset", False, 24, 12),
-                                               ("tiny", False, 4, 1)])
-def test_operator_chain_matches_separate_launches(cuda, preset, ragged, W, L):
+                                               ("tiny", False, 4, 1), ("tiny", False, 4, 2)])
+def test_operator_chain_matches_separate_launches(cuda, preset, ragged, W, L, basis):
     """bg_spmm_chain_f32 (a workgroup per graph, rows resident in LDS between steps) against the same steps
     as separate bg_spmm_f32 / bg_spmm_add_f32 launches: same slot order and scale arithmetic, so the
-    mean-aggregation powers are bit-exact; and against the dense fp64 operator."""
+    mean-aggregation powers are bit-exact; and against the dense fp64 operator.  basis 1: the three-term (Chebyshev /
+    Clenshaw) forms of the same kernels against the same recurrences run launch by launch, and against T_k(A) in fp64."""
     from building_gan_amd import ops
     g, p = _plan(_batch(preset, 3, ragged), cuda)
     blocks = p.vox_blocks
@@ -595,13 +605,13 @@ def test_operator_chain_matches_separate_launches(cuda, preset, ragged, W, L):
             Z = torch.zeros(N, (L + 1) * W + 4, device=cuda)
             Z[:, :W] = x
             Zref = Z.clone()
-            ops.power_chain_raw(op, Z, L, W, blk)
-            ops.power_chain_raw(op, Zref, L, W, None)              # L separate launches
+            ops.power_chain_raw(op, Z, L, W, blk, basis)
+            ops.power_chain_raw(op, Zref, L, W, None, basis)       # L separate launches
             assert torch.equal(Z, Zref)
-            # Horner form with addends
+            # Horner / Clenshaw form with addends
             Y = (torch.rand(N, L + 1, W, generator=gen) * 2 - 1).to(cuda)
-            acc = ops.horner_chain_raw(op, Y, L, W, blk)
-            ref = ops.horner_chain_raw(op, Y, L, W, None)
+            acc = ops.horner_chain_raw(op, Y, L, W, blk, basis)
+            ref = ops.horner_chain_raw(op, Y, L, W, None, basis)
             assert torch.equal(acc, ref)
     # dense fp64 statement of the mean-aggregation operator (oracle: scatter-mean over in-edges)
     ve = g.voxel_edge.cpu()
@@ -610,15 +620,23 @@ def test_operator_chain_matches_separate_launches(cuda, preset, ragged, W, L):
     A = A / A.sum(1, keepdim=True).clamp(min=1)
     Z = torch.zeros(N, L + 1, W, device=cuda)
     Z[:, 0] = x
-    ops.power_chain_raw(p.vox_mean, Z, L, W, blocks)
-    cur = x.double().cpu()
+    ops.power_chain_raw(p.vox_mean, Z, L, W, blocks, basis)
+    vecs = [x.double().cpu()]                                     # p_k(A) x by the recurrence on vectors
     for k in range(1, L + 1):
-        cur = A @ cur
-        np.testing.assert_allclose(Z[:, k].cpu().numpy(), cur.numpy(), rtol=RTOL, atol=ATOL)
+        nxt = A @ vecs[-1]
+        vecs.append(2 * nxt - vecs[-2] if (basis and k >= 2) else nxt)
+        np.testing.assert_allclose(Z[:, k].cpu().numpy(), vecs[k].numpy(), rtol=RTOL, atol=ATOL)
+    if N <= 4096:       # sum_k p_k(A^T) Y_k against the dense polynomials
+        polys = _cheb_dense(A, L) if basis else [torch.linalg.matrix_power(A, k) for k in range(L + 1)]
+        Y = (torch.rand(N, L + 1, W, generator=gen) * 2 - 1)
+        acc = ops.horner_chain_raw(p.vox_mean.T, Y.to(cuda), L, W, blocks, basis)
+        ref = sum(polys[k].t() @ Y[:, k].double() for k in range(L + 1))
+        np.testing.assert_allclose(acc.cpu().numpy(), ref.numpy(), rtol=RTOL, atol=ATOL * (L + 1))
 
 
-def test_operator_chain_autograd_pair(cuda):
-    """PowerChain / HornerChain are each other's backward: gradients against a dense fp64 statement."""
+@pytest.mark.parametrize("basis", [0, 1])
+def test_operator_chain_autograd_pair(cuda, basis):
+    """PowerChain / HornerChain are each other's backward (in either basis): gradients against a dense fp64 statement."""
     from building_gan_amd import ops
     g, p = _plan(_batch("small", 4, True), cuda)
     N, W, L = p.Nv, 8, 4
@@ -630,26 +648,28 @@ def test_operator_chain_autograd_pair(cuda):
     x = (torch.rand(N, W, generator=gen) * 2 - 1)
     Gz = (torch.rand(N, L + 1, W, generator=gen) * 2 - 1)
     xd = x.double().requires_grad_(True)
-    Zd = torch.stack([torch.linalg.matrix_power(A, k) @ xd for k in range(L + 1)], dim=1)
+    polys = _cheb_dense(A, L) if basis else [torch.linalg.matrix_power(A, k) for k in range(L + 1)]
+    Zd = torch.stack([polys[k] @ xd for k in range(L + 1)], dim=1)
     (Zd * Gz.double()).sum().backward()
     xg = x.to(cuda).requires_grad_(True)
-    Z = ops.PowerChain.apply(xg, p.vox_mean, L, p.vox_blocks)
+    Z = ops.PowerChain.apply(xg, p.vox_mean, L, p.vox_blocks, basis)
     (Z * Gz.to(cuda)).sum().backward()
     np.testing.assert_allclose(Z.detach().cpu().numpy(), Zd.detach().numpy(), rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xd.grad.numpy(), rtol=RTOL, atol=ATOL)
     # Horner over the transposed operator, gradient with respect to every addend
     Yd = Gz.double().requires_grad_(True)
-    out_d = sum(torch.linalg.matrix_power(A.t(), k) @ Yd[:, k] for k in range(L + 1))
+    out_d = sum(polys[k].t() @ Yd[:, k] for k in range(L + 1))
     (out_d * x.double()).sum().backward()
     Yg = Gz.to(cuda).requires_grad_(True)
-    out = ops.HornerChain.apply(Yg, p.vox_mean.T, p.vox_blocks)
+    out = ops.HornerChain.apply(Yg, p.vox_mean.T, p.vox_blocks, basis)
     (out * x.to(cuda)).sum().backward()
     np.testing.assert_allclose(out.detach().cpu().numpy(), out_d.detach().numpy(), rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(Yg.grad.cpu().numpy(), Yd.grad.numpy(), rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("basis", [0, 1])
 @pytest.mark.parametrize("preset,ragged", [("small", True), ("dataset", False)])
-def test_operator_chain_pair_equals_two_chains(cuda, preset, ragged):
+def test_operator_chain_pair_equals_two_chains(cuda, preset, ragged, basis):
     """bg_spmm_chain_pair_f32 (the powers of two matrices of different width and pitch in ONE launch) against
     two bg_spmm_chain_f32 launches: identical bits, for both register-index variants; a plan outside the
     short-row kernel falls back to the two launches."""
@@ -665,9 +685,9 @@ def test_operator_chain_pair_equals_two_chains(cuda, preset, ragged):
         Z1 = torch.zeros(N, (L + 1) * W1, device=cuda); Z1[:, :W1] = x1
         Z2 = torch.zeros(N, (L + 1) * W2 + 8, device=cuda); Z2[:, :W2] = x2
         R1, R2 = Z1.clone(), Z2.clone()
-        ops.power_chain_pair_raw(p.vox_mean, Z1, W1, Z2, W2, L, blk)
-        ops.power_chain_raw(p.vox_mean, R1, L, W1, blk)
-        ops.power_chain_raw(p.vox_mean, R2, L, W2, blk)
+        ops.power_chain_pair_raw(p.vox_mean, Z1, W1, Z2, W2, L, blk, basis)
+        ops.power_chain_raw(p.vox_mean, R1, L, W1, blk, basis)
+        ops.power_chain_raw(p.vox_mean, R2, L, W2, blk, basis)
         assert torch.equal(Z1, R1) and torch.equal(Z2, R2)
         assert float(Z1[:, -W1:].abs().max()) > 0 and float(Z2[:, L * W2:(L + 1) * W2].abs().max()) > 0
 
@@ -684,8 +704,37 @@ def test_operator_chain_rejects_oversized_blocks(cuda):
     c = p.vox_mean.csr
     rc = lib.bg_spmm_chain_f32(x.data_ptr(), 8, c.rowptr.data_ptr(), c.col.data_ptr(), None, 0, None, 0,
                                big.ptr.data_ptr(), big.n, big.max_rows, big.max_nnz, 6, None, 0, 0,
-                               x.data_ptr() + 16, 8, 0, 1, 4, torch.cuda.current_stream().cuda_stream)
+                               x.data_ptr() + 16, 8, 0, 1, 4, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == -2
+    ok = p.vox_blocks
+    rc = lib.bg_spmm_chain_f32(x.data_ptr(), 8, c.rowptr.data_ptr(), c.col.data_ptr(), None, 0, None, 0,
+                               ok.ptr.data_ptr(), ok.n, ok.max_rows, ok.max_nnz, 6, None, 0, 0,
+                               x.data_ptr() + 16, 8, 0, 1, 4, 3, torch.cuda.current_stream().cuda_stream)
+    assert rc == -1                                                   # an unknown basis is an argument error
+
+
+def test_chebyshev_shift_and_its_adjoint(cuda):
+    """bg_cheb_shift_f32: multiplication by x on a table of Chebyshev coefficients against the polynomial identity
+    (numpy.polynomial.chebyshev.chebmulx) and <shift(X), G> == <X, shift^T(G)> for the transposed form."""
+    from building_gan_amd import ops
+    gen = torch.Generator().manual_seed(41)
+    K, blk = 7, 24
+    X = torch.randn(K, blk, generator=gen)
+    X[-1] = 0                                                         # a degree K-2 polynomial: x * p fits K blocks
+    G = torch.randn(K, blk, generator=gen)
+    out = torch.full((K, blk), float("nan"), device=cuda)
+    ops.cheb_shift_raw(X.to(cuda), out, K, K, blk, False)
+    ref = np.stack([np.polynomial.chebyshev.chebmulx(X[:-1, j].double().numpy()) for j in range(blk)], axis=1)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    part = torch.full((K, blk), 7.0, device=cuda)                     # K_out < K leaves the other blocks alone
+    ops.cheb_shift_raw(X.to(cuda), part, K, 3, blk, False)
+    assert torch.equal(part[:3], out[:3]) and bool((part[3:] == 7.0).all())
+    Xf = torch.randn(K, blk, generator=gen)                           # the adjoint pairing holds for any table
+    sh = torch.empty(K, blk, device=cuda); sht = torch.empty(K, blk, device=cuda)
+    ops.cheb_shift_raw(Xf.to(cuda), sh, K, K, blk, False)
+    ops.cheb_shift_raw(G.to(cuda), sht, K, K, blk, True)
+    lhs = float((sh.double().cpu() * G.double()).sum()); rhs = float((Xf.double() * sht.double().cpu()).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
 
 
 def test_gp_sample_matches_reference_formula(cuda):

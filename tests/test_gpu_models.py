@@ -11,6 +11,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+
+@pytest.fixture(params=[1, 0], ids=["chebyshev", "monomial"])
+def d_basis(request):
+    """Run a test under both bases of the collapsed discriminator (ops.D_BASIS: T_k(A), the default, and A^k)."""
+    from building_gan_amd import ops
+    old = ops.D_BASIS
+    ops.D_BASIS = request.param
+    yield request.param
+    ops.D_BASIS = old
+
+
 def _setup(preset, seed, ragged, dev, layers=(4, 12)):
     from building_gan_amd import models as hm
     from building_gan_amd.synthetic import batch_sizes, make_batch
@@ -105,7 +116,7 @@ def test_generator_forward_parity(cuda, preset, ragged):
 
 
 @pytest.mark.parametrize("preset,ragged", [("tiny", False), ("small", True)])
-def test_discriminator_forward_backward_parity(cuda, preset, ragged):
+def test_discriminator_forward_backward_parity(cuda, preset, ragged, d_basis):
     cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup(preset, 12, ragged, cuda)
     lab_o = cpu.voxel_label.clone().requires_grad_(True)
     lab_h = gpu.voxel_label.clone().requires_grad_(True)
@@ -120,7 +131,7 @@ def test_discriminator_forward_backward_parity(cuda, preset, ragged):
     _assert_grads_close(Do.named_parameters(), Dh.named_parameters(), 2e-4, "D")
 
 
-def test_gradient_penalty_double_backward_parity(cuda):
+def test_gradient_penalty_double_backward_parity(cuda, d_basis):
     from building_gan_amd.graph import detach_batch
     from building_gan_amd.losses import compute_gradient_penalty as gp_h
     from oracle.objectives import compute_gradient_penalty as gp_o
@@ -137,7 +148,7 @@ def test_gradient_penalty_double_backward_parity(cuda):
     _assert_grads_close(Do.named_parameters(), Dh.named_parameters(), 1e-4, "penalty")
 
 
-def test_generator_backward_through_discriminator(cuda):
+def test_generator_backward_through_discriminator(cuda, d_basis):
     from oracle.objectives import g_loss_fn
     from building_gan_amd.losses import VolumetricDesignLoss_G
     cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 14, True, cuda)
@@ -301,7 +312,7 @@ def test_stack_node_equals_per_layer_nodes(cuda):
         assert float((a - c).abs().max()) <= 1e-3 * scale, n
 
 
-def test_collapsed_discriminator_accuracy_against_fp64(cuda):
+def test_collapsed_discriminator_accuracy_against_fp64(cuda, d_basis):
     """The polynomial (collapsed) evaluation of the linear discriminator GNN and the layer-by-layer
     stack are two fp32 roundings of the same function: measure both against the oracle run in
     float64 on dataset-sized graphs and require the collapsed one to be within the fp32 tolerance."""
@@ -421,7 +432,7 @@ def test_collapsed_discriminator_guard(cuda):
     assert torch.isfinite(s1["d_loss"]).all() and torch.isfinite(tr.opt_d.grad).all()
 
 
-def test_fused_critic_terms_match_separate_passes_and_oracle_gradients(cuda):
+def test_fused_critic_terms_match_separate_passes_and_oracle_gradients(cuda, d_basis):
     """critic_terms (one pass for D(real), D(fake) and the closed-form penalty gradients) against the
     oracle's three separate passes with torch.autograd.grad (reference losses.py:83-84)."""
     from building_gan_amd.util import softmax_to_hard
@@ -479,7 +490,7 @@ def test_trainer_other_objectives_match_oracle(cuda, gan_loss):
 
 
 @pytest.mark.parametrize("preset,ragged,seed", [("small", True, 31), ("small", "jitter", 32), ("dataset", "jitter", 33)])
-def test_critic_head_in_one_host_call_equals_op_by_op_path(cuda, preset, ragged, seed):
+def test_critic_head_in_one_host_call_equals_op_by_op_path(cuda, preset, ragged, seed, d_basis):
     """ops.CriticHead (bg_critic_head_forward_f32 / _backward_f32: everything of a WGAN-GP critic update below the
     coefficient table, forward and hand-derived backward, as one host call each) against critic_terms + CriticLoss
     (the same kernels launched op by op under autograd) on identical parameters, labels and sample point: objective
@@ -647,7 +658,7 @@ def test_program_gnn_in_one_host_call_equals_op_by_op_path(cuda, preset, ragged,
 
 
 @pytest.mark.parametrize("preset,ragged,seed", [("small", True, 71), ("dataset", "jitter", 72)])
-def test_generator_objective_in_one_host_call_equals_op_by_op_path(cuda, preset, ragged, seed):
+def test_generator_objective_in_one_host_call_equals_op_by_op_path(cuda, preset, ragged, seed, d_basis):
     """ops.GLossHead (bg_gloss_head_forward_f32 / _backward_f32) against discriminator(batch, label) + the sums of
     VolumetricDesignLoss_G under autograd, the discriminator frozen: value rtol 1e-6, d / d label to 2e-5 of its max."""
     from building_gan_amd.plan import build_plan
@@ -881,7 +892,7 @@ def test_shared_weight_gradient_buffers_fail_loudly_on_partial_backward(cuda):
         loss.backward()                                        # the first call is cut off from the loss
 
 
-def test_coefficient_inputs_by_one_launch_equal_cat_construction(cuda):
+def test_coefficient_inputs_by_one_launch_equal_cat_construction(cuda, d_basis):
     """ops.PolyCoefD (X0 / E written into the recurrence's buffers by bg_d_coef_init_f32, parameter gradients
     read out by bg_d_coef_init_bwd_f32) against the cat / transpose construction feeding ops.PolyCoef: the
     collapsed weight bit for bit, every discriminator gradient to fp32 rounding (the sum over the layers'
@@ -910,7 +921,7 @@ def test_coefficient_inputs_by_one_launch_equal_cat_construction(cuda):
         assert float((a - r).abs().max()) <= 2e-5 * scale, n
 
 
-def test_coefficient_recurrence_in_one_host_call_equals_separate_launches(cuda):
+def test_coefficient_recurrence_in_one_host_call_equals_separate_launches(cuda, d_basis):
     """ops.FUSE_COEF_RECURRENCE (bg_d_coef_forward_f32 / bg_d_coef_backward_f32: the recurrence's launches issued by
     one C call each way) against the same launches issued one by one from the host: the collapsed weight, the
     critic's outputs and every discriminator gradient bit for bit."""
