@@ -432,6 +432,53 @@ def test_collapsed_discriminator_guard(cuda):
     assert torch.isfinite(s1["d_loss"]).all() and torch.isfinite(tr.opt_d.grad).all()
 
 
+def test_collapsed_discriminator_stays_conditioned_while_training(cuda):
+    """The reason for the Chebyshev basis: train the synthetic stream for 1000 iterations, then on the
+    TRAINED parameters (i) the guard's amplification in the basis T_k(A) is far below its limit and the collapsed form is
+    still on, (ii) the collapsed GNN output equals the oracle run layer by layer in float64 to the fp32 tolerance of the
+    untrained case, (iii) the same parameters in the monomial basis A^k amplify several times more (printed; on the
+    trajectories measured in tools/basis_conditioning.py it passes the limit within ~1000 iterations)."""
+    from building_gan_amd import ops
+    from building_gan_amd.plan import build_plan
+    from building_gan_amd.synthetic import make_batch
+    from building_gan_amd.train import Trainer
+    from oracle import networks as om
+    assert ops.D_BASIS == ops.CHAIN_CHEB                       # the default
+    cpu = [make_batch("dataset", seed=k, ragged="jitter") for k in range(4)]
+    gpu = [b.to(cuda) for b in cpu]
+    torch.manual_seed(2)
+    tr = Trainer(cuda, collapse_check_every=250)
+    D = tr.discriminator
+    for i in range(1000):
+        b = gpu[i % 4]
+        b.__dict__.pop("_bg_plan", None)
+        tr.train_iteration(b, i)
+    assert D.voxelGNN_D.collapse_ok
+    amp_c = D.guard_collapse(gpu[0])
+    try:
+        ops.D_BASIS = ops.CHAIN_POWER
+        gpu[0].__dict__.pop("_bg_plan", None)
+        amp_m = D.guard_collapse(gpu[0])
+    finally:
+        ops.D_BASIS = ops.CHAIN_CHEB
+        gpu[0].__dict__.pop("_bg_plan", None)
+        D.guard_collapse(gpu[0])
+    Do = om.DiscriminatorVoxel(7, 6, 128, 12)
+    Do.load_state_dict({k: v.cpu() for k, v in D.state_dict().items()})
+    D64 = Do.double()
+    c = cpu[0]
+    with torch.no_grad():
+        v64 = D64.voxelGNN_D(c.voxel_feature.double(), c.voxel_label.double(), c.voxel_edge, c.voxel_feature_batch,
+                             c.voxel_floor_cluster, c.voxel_feature_batch)
+        v = D.voxelGNN_D(gpu[0].voxel_feature, gpu[0].voxel_label, build_plan(gpu[0])).cpu().double()
+    err = float(((v - v64).abs().amax(0) / v64.abs().amax(0)).max())
+    print("after 1000 iterations: amplification Chebyshev %.1f, monomial %.1f (limit %.1f); collapsed output vs float64 "
+          "oracle, error / column max %.2e" % (amp_c, amp_m, D.COLLAPSE_AMPLIFICATION_LIMIT, err))
+    assert D.voxelGNN_D.collapse_ok and amp_c <= D.COLLAPSE_AMPLIFICATION_LIMIT / 3
+    assert err <= 2e-5
+    assert amp_m >= 2 * amp_c
+
+
 def test_fused_critic_terms_match_separate_passes_and_oracle_gradients(cuda, d_basis):
     """critic_terms (one pass for D(real), D(fake) and the closed-form penalty gradients) against the
     oracle's three separate passes with torch.autograd.grad (reference losses.py:83-84)."""
