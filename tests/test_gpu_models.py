@@ -445,7 +445,7 @@ def test_collapsed_discriminator_stays_conditioned_while_training(cuda):
     from oracle import networks as om
     assert ops.D_BASIS == ops.CHAIN_CHEB                       # the default
     cpu = [make_batch("dataset", seed=k, ragged="jitter") for k in range(4)]
-    gpu = [b.to(cuda) for b in cpu]
+    gpu = [copy.deepcopy(b).to(cuda) for b in cpu]            # Batch.to moves in place
     torch.manual_seed(2)
     tr = Trainer(cuda, collapse_check_every=250)
     D = tr.discriminator

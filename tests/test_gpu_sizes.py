@@ -331,9 +331,12 @@ def test_generator_backward_and_penalty_against_float64(cuda, preset, graphs):
         assert ed_h[n] <= max(GRAD64_BAR["penalty"], 2 * ed_o[n]), ("penalty", n, ed_h[n], ed_o[n])
     for n in eg_h:
         assert eg_h[n] <= max(GRAD64_BAR["generator"], 2 * eg_o[n]), ("generator", n, eg_h[n], eg_o[n])
-    # and the two fp32 paths against each other
+    # and the two fp32 paths against each other -- meaningful where the fp32 oracle itself agrees with float64; where
+    # it picked another arg-max voxel than float64 did (its own error jumps to ~3e-2 at dataset size) the HIP path may
+    # side with float64 instead (it does in the Chebyshev basis: 5e-4 from float64), so the bound is the oracle's own error
     for (n, p), (_, po) in zip(Gh.named_parameters(), Go.named_parameters()):
-        assert _rel(p.grad.cpu(), po.grad) <= 1e-3, ("generator, HIP vs fp32 oracle", n)
+        bound = 1e-3 if eg_o[n] <= 1e-3 else 2 * eg_o[n]
+        assert _rel(p.grad.cpu(), po.grad) <= bound, ("generator, HIP vs fp32 oracle", n, eg_h[n], eg_o[n])
 
 
 GRAD64_BAR = {"generator": 3e-5, "penalty": 3e-5}
