@@ -58,6 +58,8 @@ SIGNATURES = {
     "bg_spmm_chain_pair_f32": [_p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _int, _p, _int,
                                _p, _i64, _i64, _i64, _i64, _i64, _i32, _p],
     "bg_cheb_shift_f32": [_p, _p, _i64, _i64, _i64, _i32, _p],
+    "bg_cheb_shift_slabs_f32": [_p, _p, _i64, _i64, _i64, _i64, _i64, _i32, _p],
+    "bg_gemm_cheb_f32": [_int, _i64, _i64, _p, _i64, _i64, _i64, _i64, _int, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p],
     "bg_attention_bwd_head_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _i64,
                                   _i64, _i64, _p],
     "bg_pos_terms_f32": [_p, _i64, _p, _p, _p, _i64, _f, _p],
@@ -69,8 +71,8 @@ SIGNATURES = {
     "bg_gemm_tn_splitk_f32": [_i64, _i64, _p, _i64, _int, _p, _p, _p, _p, _i64, _p, _i32, _int, _p],
     "bg_colsum_f32": [_p, _i64, _i64, _i64, _p, _i32, _p, _int, _p],
     "bg_generator_forward_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
-    "bg_d_coef_forward_f32": [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p],
-    "bg_d_coef_backward_f32": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p,
+    "bg_d_coef_forward_f32": [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _p, _p, _p],
+    "bg_d_coef_backward_f32": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p,
                                _p, _p, _p, _p],
     "bg_adam_f32": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i32, _p, _p],
     "bg_regroup_f32": [_p, _p, _i64, _i64, _i64, _i64, _int, _p],

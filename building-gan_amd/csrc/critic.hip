@@ -265,6 +265,26 @@ __global__ void k_cheb_shift(const float4* __restrict__ X, float4* __restrict__ 
     out[t] = r;
 }
 
+// The same map on a run of tables laid out with a period: block b of the run is coefficient block (b % period) - lead of
+// its table; blocks outside [0, K) (padding between tables) are written as zeros.
+__global__ void k_cheb_shift_slabs(const float4* __restrict__ X, float4* __restrict__ out, int64_t n_blocks, int period,
+                                   int lead, int K, int64_t blk4, int transpose) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_blocks * blk4) return;
+    const int i = (int)((t / blk4) % period) - lead;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i >= 0 && i < K) {
+        float lo = 0.5f, hi = 0.5f;
+        if (transpose) { if (i == 0) hi = 1.f; } else { if (i == 1) lo = 1.f; }
+        if (i >= 1) { const float4 a = X[t - blk4]; r.x = lo * a.x; r.y = lo * a.y; r.z = lo * a.z; r.w = lo * a.w; }
+        if (i + 1 < K) {
+            const float4 b = X[t + blk4];
+            r.x = __fmaf_rn(hi, b.x, r.x); r.y = __fmaf_rn(hi, b.y, r.y); r.z = __fmaf_rn(hi, b.z, r.z); r.w = __fmaf_rn(hi, b.w, r.w);
+        }
+    }
+    out[t] = r;
+}
+
 // [n, K, P, W] <-> [P, n, K, W], one float4 per thread (see bg_regroup_f32)
 __global__ void k_regroup(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n, int K, int P, int W4,
                           int to_outer) {
@@ -506,6 +526,21 @@ int bg_cheb_shift_f32(const float* x, float* out, int64_t K, int64_t K_out, int6
     k_cheb_shift<<<bg_grid_for(n4, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
         reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(out), (int)K, (int)K_out, block_floats / 4,
         transpose ? 1 : 0);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_cheb_shift_slabs_f32(const float* x, float* out, int64_t n_blocks, int64_t period, int64_t lead, int64_t K,
+                            int64_t block_floats, int32_t transpose, bgStream stream) {
+    if (n_blocks < 0 || period <= 0 || lead < 0 || K < 0 || lead + K > period || block_floats < 0) return BG_ERR_ARG;
+    if (n_blocks == 0 || block_floats == 0) return BG_OK;
+    if (!x || !out || x == out) return BG_ERR_ARG;
+    if (block_floats % 4 != 0 || n_blocks * (block_floats / 4) > 0x7fffffff || period > 0x7fffffff) return BG_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)out) & 15) return BG_ERR_ALIGN;
+    const int64_t n4 = n_blocks * (block_floats / 4);
+    k_cheb_shift_slabs<<<bg_grid_for(n4, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(out), n_blocks, (int)period, (int)lead, (int)K,
+        block_floats / 4, transpose ? 1 : 0);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -179,28 +179,28 @@ int64_t coef_splits(int64_t M, int64_t R) {          // as ops.gemm_tn_raw: M x 
 extern "C" int bg_d_coef_forward_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b,
                                      const float* pe, const float* Wc, int64_t ldw, const float* bc, int64_t H,
                                      int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L, int32_t basis,
-                                     float* xall, float* efull, float* shall, bgStream s) {
+                                     float* xall, float* efull, bgStream s) {
     if (!fe_w || !fe_b || !le_w || !le_b || !pe || !Wc || !bc || !xall || !efull) return BG_ERR_ARG;
     if (H <= 0 || L < 0 || ds < nf + ML + 5 || dl < nl || ldw < 4 * H + 4) return BG_ERR_ARG;
-    if ((basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB) || (basis == BG_CHAIN_CHEB && !shall && L > 0)) return BG_ERR_ARG;
+    if (basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB) return BG_ERR_ARG;
     const int64_t H2 = 2 * H, du = ds + dl, N = (L + 1) * du, S = N + du;
     hipStream_t st = (hipStream_t)s;
     BG_HIP(hipMemsetAsync(xall, 0, sizeof(float) * (size_t)((L + 1) * S * H2), st));
     BG_HIP(hipMemsetAsync(efull, 0, sizeof(float) * (size_t)(N * H2), st));
-    if (basis == BG_CHAIN_CHEB && L > 0) BG_HIP(hipMemsetAsync(shall, 0, sizeof(float) * (size_t)((L * S + du) * H2), st));
     BG_TRY(bg_d_coef_init_f32(fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, H, nf, nl, ML, ds, dl, xall + du * H2, efull, s));
     for (int64_t m = 0; m < L; ++m) {
         const int64_t rows = N < (m + 2) * du ? N : (m + 2) * du;       // blocks above m+1 are still zero
         float* cur = xall + m * S * H2;
-        const float* shifted = cur;                                     // monomials: one block down = a row offset
+        float* nxt = xall + (m + 1) * S * H2 + du * H2;
         if (basis == BG_CHAIN_CHEB) {
-            float* sh = shall + m * S * H2 + du * H2;
-            BG_TRY(bg_cheb_shift_f32(cur + du * H2, sh, L + 1, rows / du, du * H2, 0, s));
-            shifted = sh;
+            // second operand = x * X^m, formed while the product loads it (no separate shift launch)
+            BG_TRY(bg_gemm_cheb_f32(1, rows, H2, cur + du * H2, H2, H2, du, L + 1, 0, Wc, ldw, nxt, H2, cur + du * H2, H2,
+                                    efull, H2, s));
+            continue;
         }
-        const float* A[4] = {cur + du * H2, shifted, nullptr, nullptr};
+        const float* A[4] = {cur + du * H2, cur, nullptr, nullptr};     // monomials: one block down = a row offset
         const int64_t ld[4] = {H2, H2, 0, 0}, Ks[4] = {H2, H2, 0, 0};
-        BG_TRY(bg_gemm_f32(0, 1, rows, H2, 2, A, ld, Ks, Wc, ldw, xall + (m + 1) * S * H2 + du * H2, H2, nullptr, nullptr,
+        BG_TRY(bg_gemm_f32(0, 1, rows, H2, 2, A, ld, Ks, Wc, ldw, nxt, H2, nullptr, nullptr,
                            BG_ACT_NONE, 0.01f, cur + du * H2, H2, efull, H2, nullptr, nullptr, 0, nullptr, 0, s));
     }
     return BG_OK;
@@ -212,14 +212,14 @@ extern "C" int64_t bg_d_coef_backward_workspace(int64_t H, int64_t ds, int64_t d
     return coef_splits(H2, L * S) * H2 * 2 * H2;
 }
 
-extern "C" int bg_d_coef_backward_f32(const float* g, const float* xall, const float* shall, const float* Wc, int64_t ldw,
+extern "C" int bg_d_coef_backward_f32(const float* g, const float* xall, const float* Wc, int64_t ldw,
                                       int64_t H, int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L,
-                                      int32_t basis, float* sht, float* gall, float* wab, float* partial, float* gW,
+                                      int32_t basis, float* shall, float* gall, float* wab, float* partial, float* gW,
                                       float* g_bc, float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b, bgStream s) {
     if (!g || !xall || !Wc || !gall || !wab || !partial || !gW || !g_bc || !g_fe_w || !g_fe_b || !g_le_w || !g_le_b)
         return BG_ERR_ARG;
     if (H <= 0 || L < 1 || ldw < 4 * H + 4) return BG_ERR_ARG;
-    if ((basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB) || (basis == BG_CHAIN_CHEB && (!shall || !sht))) return BG_ERR_ARG;
+    if ((basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB) || (basis == BG_CHAIN_CHEB && !shall)) return BG_ERR_ARG;
     const int64_t H2 = 2 * H, du = ds + dl, N = (L + 1) * du, S = N + du;
     hipStream_t st = (hipStream_t)s;
     // G^m at rows [0, N) of slab m, du zero rows below it (the shift-up view reads them)
@@ -231,17 +231,19 @@ extern "C" int bg_d_coef_backward_f32(const float* g, const float* xall, const f
                             hipMemcpyDeviceToDevice, st));
     for (int64_t m = L - 1; m >= 0; --m) {
         const float* nxt = gall + (m + 1) * S * H2;
-        const float* up = nxt + du * H2;                                // monomials: one block up = a row offset
-        if (basis == BG_CHAIN_CHEB) {
-            BG_TRY(bg_cheb_shift_f32(nxt, sht, L + 1, L + 1, du * H2, 1, s));
-            up = sht;
+        if (basis == BG_CHAIN_CHEB) {                                   // second operand = the adjoint shift of G^{m+1}
+            BG_TRY(bg_gemm_cheb_f32(0, N, H2, nxt, H2, H2, du, L + 1, 1, wab, H2, gall + m * S * H2, H2, nxt, H2, nullptr, 0, s));
+            continue;
         }
-        const float* A[4] = {nxt, up, nullptr, nullptr};
+        const float* A[4] = {nxt, nxt + du * H2, nullptr, nullptr};     // monomials: one block up = a row offset
         const int64_t ld[4] = {H2, H2, 0, 0}, Ks[4] = {H2, H2, 0, 0};
         BG_TRY(bg_gemm_f32(0, 0, N, H2, 2, A, ld, Ks, wab, H2, gall + m * S * H2, H2, nullptr, nullptr, BG_ACT_NONE, 0.01f,
                            nxt, H2, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
     }
-    // dWc[:, :4H] = sum_m G^{m+1 T} [X^m | shift(X^m)]: one long reduction over the stacked slabs
+    // dWc[:, :4H] = sum_m G^{m+1 T} [X^m | shift(X^m)]: one long reduction over the stacked slabs.  Chebyshev: the
+    // shifts of ALL layers' states by one launch (slabs of L+2 blocks: one of padding, then the L+1 coefficients)
+    if (basis == BG_CHAIN_CHEB)
+        BG_TRY(bg_cheb_shift_slabs_f32(xall, shall, L * (L + 2) + 1, L + 2, 1, L + 1, du * H2, 0, s));
     const float* B[4] = {xall + du * H2, basis == BG_CHAIN_CHEB ? shall + du * H2 : xall, nullptr, nullptr};
     const int64_t ldb[4] = {H2, H2, 0, 0}, Ns[4] = {H2, H2, 0, 0};
     BG_TRY(bg_gemm_tn_splitk_f32(H2, L * S, gall + S * H2, H2, 2, B, ldb, Ns, gW, 2 * H2 + 4, partial,

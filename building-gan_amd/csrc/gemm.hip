@@ -38,6 +38,9 @@ struct GemmArgs {
     // 1-D launch: gx column tiles x gy row tiles x splits; xcd != 0 remaps the linear block id so that
     // consecutive logical tiles (column tiles of one row panel, tiles of one K split) share an XCD's L2
     int gx, gy, xcd;
+    // k_gemm_skinny only: segment 1 is not read as stored but as the Chebyshev shift of the table A[1] (row blocks of
+    // cheb_R rows, cheb_K blocks; cheb_T: the adjoint map) -- the arithmetic of k_cheb_shift (critic.hip), applied on load
+    int cheb_R, cheb_K, cheb_T;
 };
 
 template <int ROWS, bool KC, bool VEC, int BK>
@@ -692,6 +695,15 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_skinny(GemmArgs g) {
 
     int n_groups = 0;
     for (int s = 0; s < g.n_seg; ++s) n_groups += (int)((g.Ks[s] + 7) >> 3);
+    // shifted second segment: this lane's row takes c_lo * (row one block down) + c_hi * (row one block up)
+    float c_lo = 0.f, c_hi = 0.f;
+    bool has_lo = false, has_hi = false;
+    if (g.cheb_R) {
+        const int i = (int)(arow / g.cheb_R);
+        has_lo = i >= 1; has_hi = i + 1 < g.cheb_K;
+        c_lo = 0.5f; c_hi = 0.5f;
+        if (g.cheb_T) { if (i == 0) c_hi = 1.f; } else { if (i == 1) c_lo = 1.f; }
+    }
 
     f32x16 acc;
 #pragma unroll
@@ -713,7 +725,21 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_skinny(GemmArgs g) {
                 }
                 const int64_t k = 8 * (int64_t)gi + 4 * h;
                 if (k < g.Ks[seg]) {                              // K_s % 4 == 0: a 4-chunk is all in or all out
-                    af[j] = bg_ld4(g.A[seg] + arow * g.lda[seg] + k);
+                    if (g.cheb_R && seg == 1) {
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (has_lo) {
+                            const float4 a = bg_ld4(g.A[1] + (arow - g.cheb_R) * g.lda[1] + k);
+                            v.x = c_lo * a.x; v.y = c_lo * a.y; v.z = c_lo * a.z; v.w = c_lo * a.w;
+                        }
+                        if (has_hi) {
+                            const float4 b = bg_ld4(g.A[1] + (arow + g.cheb_R) * g.lda[1] + k);
+                            v.x = __fmaf_rn(c_hi, b.x, v.x); v.y = __fmaf_rn(c_hi, b.y, v.y);
+                            v.z = __fmaf_rn(c_hi, b.z, v.z); v.w = __fmaf_rn(c_hi, b.w, v.w);
+                        }
+                        af[j] = v;
+                    } else {
+                        af[j] = bg_ld4(g.A[seg] + arow * g.lda[seg] + k);
+                    }
                     if (B_KC) {
                         bf[j] = bg_ld4(g.B + bcol * g.ldb + koff + k);
                     } else {
@@ -1162,6 +1188,28 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
             if (bk == 64) return launch_gemm<64, 64, 64, false>(transA, transB, vec, g, 1, st);
             return launch_gemm<64, 64, 32, false>(transA, transB, vec, g, 1, st);
     }
+}
+
+int bg_gemm_cheb_f32(int transB, int64_t M, int64_t N, const float* X, int64_t ldx, int64_t K, int64_t block_rows,
+                     int64_t n_blocks, int transpose, const float* B, int64_t ldb, float* C, int64_t ldc,
+                     const float* residual, int64_t ldr, const float* pre_add, int64_t ldp, bgStream stream) {
+    if (M < 0 || N < 0 || K <= 0 || block_rows <= 0 || n_blocks <= 0) return BG_ERR_ARG;
+    if (M == 0 || N == 0) return BG_OK;
+    if (!X || !B || !C || ldx < K || ldc < N || (residual && ldr < N) || (pre_add && ldp < N)) return BG_ERR_ARG;
+    if (M > block_rows * n_blocks || ldb < (transB ? 2 * K : N)) return BG_ERR_ARG;
+    if (C == X) return BG_ERR_ARG;                         // rows one block away are read while others are written
+    if (K % 4 != 0 || 2 * K > 4096 || ((M + 31) / 32) * ((N + 31) / 32) > skinny_max_tiles() ||
+        block_rows * n_blocks > 0x7fffffff) return BG_ERR_SHAPE;
+    if (!operand_vec_ok(X, ldx, true, K, M) || !operand_vec_ok(B, ldb, transB != 0, 4, N)) return BG_ERR_ALIGN;
+    GemmArgs g{};
+    g.n_seg = 2;
+    g.A[0] = X; g.A[1] = X; g.lda[0] = ldx; g.lda[1] = ldx; g.Ks[0] = K; g.Ks[1] = K;
+    g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.act = BG_ACT_NONE; g.slope = 0.01f;
+    g.residual = residual; g.ldr = ldr; g.pre_add = pre_add; g.ldp = ldp;
+    g.M = M; g.N = N;
+    g.cheb_R = (int)block_rows; g.cheb_K = (int)n_blocks; g.cheb_T = transpose ? 1 : 0;
+    return launch_gemm_skinny(transB, g, (hipStream_t)stream);
 }
 
 int bg_gemm_tn_splitk_f32(int64_t M, int64_t R, const float* A, int64_t lda,

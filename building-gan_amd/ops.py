@@ -1702,6 +1702,16 @@ def cheb_shift_raw(X: torch.Tensor, out: torch.Tensor, K: int, K_out: int, block
           "bg_cheb_shift_f32")
 
 
+def _coef_shifts(Xall: torch.Tensor, L: int, du: int, H2: int) -> torch.Tensor:
+    """shift(X^m) of every layer's state by one launch: [L S + du, H2] laid out like Xall's first L slabs."""
+    lib = _lib.load()
+    S = (L + 2) * du
+    out = torch.empty(L * S + du, H2, dtype=torch.float32, device=Xall.device)
+    check(lib.bg_cheb_shift_slabs_f32(ptr(Xall), ptr(out), L * (L + 2) + 1, L + 2, 1, L + 1, du * H2, 0, stream()),
+          "bg_cheb_shift_slabs_f32")
+    return out
+
+
 class PolyCoef(torch.autograd.Function):
     """Coefficients of the collapsed discriminator GNN (models.VoxelGNN_D.forward_collapsed).
 
@@ -1802,7 +1812,8 @@ class PolyCoefD(torch.autograd.Function):
         Wc2, args = _f32c(Wc), [_f32c(t).contiguous() for t in (fe_w, fe_b, le_w, le_b, pe, bc)]
         basis = D_BASIS if basis is None else basis
         cheb = basis == CHAIN_CHEB
-        n_x, n_e, n_sh = (L + 1) * S * H2, N * H2, ((L * S + du) * H2 if cheb else 0)
+        n_x, n_e = (L + 1) * S * H2, N * H2
+        n_sh = (L * S + du) * H2 if (cheb and not FUSE_COEF_RECURRENCE) else 0       # the one-call form keeps no shifts
         if FUSE_COEF_RECURRENCE:
             # clear + parameter rows + the L products in one host call (shapes depend on the parameters alone)
             buf = torch.empty(n_x + n_e + n_sh, dtype=torch.float32, device=dev)
@@ -1810,11 +1821,11 @@ class PolyCoefD(torch.autograd.Function):
             buf = torch.zeros(n_x + n_e + n_sh, dtype=torch.float32, device=dev)     # one fill for all three
         Xall = buf[:n_x].view(L + 1, S, H2)
         Efull = buf[n_x:n_x + n_e].view(N, H2)
-        ShAll = buf[n_x + n_e:].view(L * S + du, H2) if cheb else None
+        ShAll = buf[n_x + n_e:].view(L * S + du, H2) if n_sh else None
         if FUSE_COEF_RECURRENCE:
             check(lib.bg_d_coef_forward_f32(ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(args[4]), ptr(Wc2),
                                             _ld(Wc2), ptr(args[5]), H, nf, nl, ML, ds, dl, L, basis, ptr(Xall), ptr(Efull),
-                                            ptr(ShAll), stream()), "bg_d_coef_forward_f32")
+                                            stream()), "bg_d_coef_forward_f32")
         else:
             check(lib.bg_d_coef_init_f32(ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(args[4]), ptr(Wc2),
                                          _ld(Wc2), ptr(args[5]), H, nf, nl, ML, ds, dl, ptr(Xall[0, du:2 * du]),
@@ -1854,13 +1865,13 @@ class PolyCoefD(torch.autograd.Function):
         if FUSE_COEF_RECURRENCE and L >= 1 and Wc.stride(1) == 1:
             g2 = _f32c(g).contiguous()
             nws = int(lib.bg_d_coef_backward_workspace(H, ds, dl, L))
-            n_g, n_w, n_t = (L + 1) * S * H2, 2 * H2 * H2, (N * H2 if cheb else 0)
+            n_g, n_w, n_t = (L + 1) * S * H2, 2 * H2 * H2, ((L * S + du) * H2 if cheb else 0)
             work = torch.empty(n_g + n_w + n_t + nws, dtype=torch.float32, device=dev)
             Gall, Wab = work[:n_g], work[n_g:n_g + n_w]
-            sht = work[n_g + n_w:n_g + n_w + n_t] if cheb else None
+            shall = work[n_g + n_w:n_g + n_w + n_t] if cheb else None      # rebuilt there by one launch
             partial = work[n_g + n_w + n_t:]
-            check(lib.bg_d_coef_backward_f32(ptr(g2), ptr(Xall), ptr(ShAll), ptr(Wc), _ld(Wc), H, nf, nl, ML, ds, dl, L, basis,
-                                             ptr(sht), ptr(Gall), ptr(Wab), ptr(partial), ptr(gW), ptr(g_bc), ptr(g_fe_w),
+            check(lib.bg_d_coef_backward_f32(ptr(g2), ptr(Xall), ptr(Wc), _ld(Wc), H, nf, nl, ML, ds, dl, L, basis,
+                                             ptr(shall), ptr(Gall), ptr(Wab), ptr(partial), ptr(gW), ptr(g_bc), ptr(g_fe_w),
                                              ptr(g_fe_b), ptr(g_le_w), ptr(g_le_b), stream()), "bg_d_coef_backward_f32")
             return (gW, g_bc, g_fe_w, g_fe_b, g_le_w, g_le_b) + none
         Gall = torch.zeros(L + 1, S, H2, dtype=torch.float32, device=dev)
@@ -1876,6 +1887,8 @@ class PolyCoefD(torch.autograd.Function):
             gemm_raw([nxt[:N], up], Wab, False, False, residual=nxt[:N], out=Gall[m, :N])
         Gf = Gall[1:L + 1].reshape(L * S, H2)
         Xf = Xall.view((L + 1) * S, H2)
+        if cheb and ShAll is None:                                    # the forward ran as one host call
+            ShAll = _coef_shifts(Xall, L, du, H2)
         gemm_tn_raw(Gf, [Xf[du:du + L * S], ShAll[du:du + L * S] if cheb else Xf[:L * S]], out=gW[:, :2 * H2])
         check(lib.bg_d_coef_init_bwd_f32(ptr(Gall), S * H2, L, H, nf, nl, ML, ds, dl, ptr(g_fe_w), ptr(g_fe_b),
                                          ptr(g_le_w), ptr(g_le_b), gW.data_ptr() + 4 * 2 * H2, 2 * H2 + 4, ptr(g_bc),

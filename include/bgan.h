@@ -391,6 +391,24 @@ int bg_d_coef_init_f32(const float* fe_w, const float* fe_b, const float* le_w, 
 int bg_cheb_shift_f32(const float* x, float* out, int64_t K, int64_t K_out, int64_t block_floats, int32_t transpose,
                       bgStream stream);
 
+/* bg_cheb_shift_f32 on a RUN of tables laid out with a period: block b of the run (b < n_blocks) is coefficient block
+ * (b % period) - lead of its table; blocks outside [0, K) are padding and are written as zeros.  x must extend one block
+ * past the run unless the run's last block is padding or a table's last coefficient.
+ * no counterpart in the reference: the shifts of all layers' states of the coefficient recurrence by one launch.   */
+int bg_cheb_shift_slabs_f32(const float* x, float* out, int64_t n_blocks, int64_t period, int64_t lead, int64_t K,
+                            int64_t block_floats, int32_t transpose, bgStream stream);
+
+/* C [M, N] = [X | shift(X)] op(B) (+ pre_add) (+ residual): a two-segment product whose second operand is the
+ * bg_cheb_shift_f32 image of the first's table, formed on load (identical arithmetic, so the result equals
+ * bg_cheb_shift_f32 followed by bg_gemm_f32 bit for bit).  X [>= M rows, K] (pitch ldx) is a table of n_blocks row
+ * blocks of block_rows rows, M <= n_blocks * block_rows; op(B) = B^T with B [N, 2K] (transB) or B [2K, N]; C != X.
+ * Skinny shapes only (<= 256 output tiles of 32 x 32, 2K <= 4096, K % 4 == 0, 16-byte operands): else BG_ERR_SHAPE /
+ * BG_ERR_ALIGN and the caller runs the two launches.
+ * no counterpart in the reference: one layer of the collapsed discriminator's coefficient recurrence, Chebyshev basis. */
+int bg_gemm_cheb_f32(int transB, int64_t M, int64_t N, const float* X, int64_t ldx, int64_t K, int64_t block_rows,
+                     int64_t n_blocks, int transpose, const float* B, int64_t ldb, float* C, int64_t ldc,
+                     const float* residual, int64_t ldr, const float* pre_add, int64_t ldp, bgStream stream);
+
 /* Backward of bg_d_coef_init_f32: G = L+1 slabs (pitch `slab` floats) of gradient states [.., 2H]; rows [0, du)
  * of slab 0 are d/d x0, the sum over slabs 1..L of rows [0, du) is d/d e.  Writes the gradients of fe_w, fe_b,
  * le_w, le_b (contiguous), of Wc's position block (gw_tail = &gWc[0, 4H], pitch ldw) and of bc.           */
@@ -540,19 +558,18 @@ int bg_generator_forward_f32(const bgGeneratorWeights* w, const bgGeneratorPlan*
  *   from row du on.
  * backward: g [N, 2H] (contiguous) = d/d X^L.  gall [(L+1) S, 2H], wab [4H, 2H] and partial (floats: see
  *   bg_d_coef_backward_workspace) are workspaces; writes gW [2H, 4H+4] (pitch 4H+4) and the encoders' gradients.
- * basis == BG_CHAIN_CHEB: row block j of a state is the coefficient of T_j(A) instead of A^j; shift(X) becomes
- *   bg_cheb_shift_f32(X) (one more launch per layer), kept for the backward in shall [L S + du, 2H] (slab m rows
- *   [du, du+N) = shift(X^m); cleared here); the backward needs sht [N, 2H] for the adjoint shift of a gradient state.
- *   Both are NULL for BG_CHAIN_POWER.
+ * basis == BG_CHAIN_CHEB: row block j of a state is the coefficient of T_j(A) instead of A^j; shift(X) becomes the
+ *   multiplication-by-x map of bg_cheb_shift_f32, formed by bg_gemm_cheb_f32 while it loads the operand (no extra
+ *   launch); the backward rebuilds the shifts of all layers' states with one bg_cheb_shift_slabs_f32 launch into
+ *   shall [L S + du, 2H] (workspace; NULL for BG_CHAIN_POWER) for the weight gradient.
  * replaces: the same 15 / 18 launches issued one by one from the host.                                  */
 int bg_d_coef_forward_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b, const float* pe,
                           const float* Wc, int64_t ldw, const float* bc, int64_t H, int64_t nf, int64_t nl, int64_t ML,
-                          int64_t ds, int64_t dl, int64_t L, int32_t basis, float* xall, float* efull, float* shall,
-                          bgStream stream);
+                          int64_t ds, int64_t dl, int64_t L, int32_t basis, float* xall, float* efull, bgStream stream);
 int64_t bg_d_coef_backward_workspace(int64_t H, int64_t ds, int64_t dl, int64_t L);   /* floats of `partial` */
-int bg_d_coef_backward_f32(const float* g, const float* xall, const float* shall, const float* Wc, int64_t ldw, int64_t H,
+int bg_d_coef_backward_f32(const float* g, const float* xall, const float* Wc, int64_t ldw, int64_t H,
                            int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L, int32_t basis,
-                           float* sht, float* gall, float* wab,
+                           float* shall, float* gall, float* wab,
                            float* partial, float* gW, float* g_bc, float* g_fe_w, float* g_fe_b, float* g_le_w,
                            float* g_le_b, bgStream stream);
 

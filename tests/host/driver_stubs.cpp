@@ -94,6 +94,20 @@ int bg_cheb_shift_f32(const float* x, float* out, int64_t K, int64_t K_out, int6
     rec(29, a, sizeof(a) / 8);
     return 0;
 }
+int bg_cheb_shift_slabs_f32(const float* x, float* out, int64_t n_blocks, int64_t period, int64_t lead, int64_t K,
+                            int64_t block_floats, int32_t transpose, bgStream) {
+    int64_t a[] = {P(x), P(out), n_blocks, period, lead, K, block_floats, transpose};
+    rec(33, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_gemm_cheb_f32(int transB, int64_t M, int64_t N, const float* X, int64_t ldx, int64_t K, int64_t block_rows,
+                     int64_t n_blocks, int transpose, const float* B, int64_t ldb, float* C, int64_t ldc,
+                     const float* residual, int64_t ldr, const float* pre_add, int64_t ldp, bgStream) {
+    int64_t a[] = {transB, M, N, P(X), ldx, K, block_rows, n_blocks, transpose, P(B), ldb, P(C), ldc, P(residual), ldr,
+                   P(pre_add), ldp};
+    rec(32, a, sizeof(a) / 8);
+    return 0;
+}
 int bg_gemm_tn_splitk_f32(int64_t M, int64_t R, const float* A, int64_t lda, int n_seg, const float* const* B,
                           const int64_t* ldb, const int64_t* Ns, float* C, int64_t ldc, float* partial, int32_t splits,
                           int accumulate, bgStream) {

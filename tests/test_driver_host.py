@@ -881,9 +881,10 @@ def test_gloss_head_host_sequence_and_extents(drv, N, S, B):
 @pytest.mark.parametrize("basis", [0, 1])
 @pytest.mark.parametrize("L", [12, 1])
 def test_d_coef_host_sequence_and_extents(drv, basis, L):
-    """bg_d_coef_forward_f32 / _backward_f32: the launch sequence per basis (one bg_cheb_shift_f32 before every product in
-    the Chebyshev basis), every operand inside the buffer the caller handed in, the second reduction operand = the kept
-    shifts (Chebyshev) or the state one block down (monomials)."""
+    """bg_d_coef_forward_f32 / _backward_f32: the launch sequence per basis (Chebyshev: every product is the shift-on-load
+    form bg_gemm_cheb_f32, the backward rebuilds all layers' shifts with ONE bg_cheb_shift_slabs_f32 launch), every operand
+    inside the buffer the caller handed in, the second reduction operand = the rebuilt shifts (Chebyshev) or the state one
+    block down (monomials)."""
     f, H, nf, nl, ML, ds, dl = 4, 128, 4, 6, 20, 32, 8
     H2, du = 2 * H, ds + dl
     N, ldw = (L + 1) * du, 4 * H + 4
@@ -892,33 +893,34 @@ def test_d_coef_host_sequence_and_extents(drv, basis, L):
     par = [R.new(n, b * f) for n, b in (("fe_w", H * nf), ("fe_b", H), ("le_w", H * nl), ("le_b", H), ("pe", ML * H))]
     Wc, bc = R.new("Wc", H2 * ldw * f), R.new("bc", H2 * f)
     xall, efull = R.new("xall", (L + 1) * S * H2 * f), R.new("efull", N * H2 * f)
-    shall = R.new("shall", (L * S + du) * H2 * f) if basis else None
-    drv.bg_d_coef_forward_f32.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_void_p] + [C.c_int64] * 7 + [C.c_int32] + [C.c_void_p] * 4
+    drv.bg_d_coef_forward_f32.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_void_p] + [C.c_int64] * 7 + [C.c_int32] + [C.c_void_p] * 3
 
     def calls_of(fn, *args):
         drv.stub_reset()
         rc = fn(*args)
         return rc, [(drv.stub_call(i)[0], [drv.stub_call(i)[2 + k] for k in range(drv.stub_call(i)[1])])
                     for i in range(drv.stub_count())]
-    rc, fwd = calls_of(drv.bg_d_coef_forward_f32, *par, Wc, ldw, bc, H, nf, nl, ML, ds, dl, L, basis, xall, efull, shall, None)
+    rc, fwd = calls_of(drv.bg_d_coef_forward_f32, *par, Wc, ldw, bc, H, nf, nl, ML, ds, dl, L, basis, xall, efull, None)
     assert rc == 0
-    assert [k for k, _ in fwd] == [25] * (3 if basis else 2) + [30] + ([29, 1] if basis else [1]) * L
+    assert [k for k, _ in fwd] == [25, 25, 30] + [32 if basis else 1] * L
     cleared = {R.check(a[0], a[2], "memset"): a[2] for k, a in fwd if k == 25}
-    assert cleared == {n: R.r[n][1] for n in (("xall", "efull", "shall") if basis else ("xall", "efull"))}
+    assert cleared == {n: R.r[n][1] for n in ("xall", "efull")}
     m = 0
     for k, a in fwd:
         if k == 30:
             assert R.check(a[0], a[2] * f, "x0") == "xall" and a[0] == xall + du * H2 * f and a[1] == efull
-        elif k == 29:
-            x, out, K, K_out, blk, tr = a
-            assert (K, blk, tr) == (L + 1, du * H2, 0) and K_out == min(L + 1, m + 2)
-            assert x == xall + (m * S + du) * H2 * f and out == shall + (m * S + du) * H2 * f
-            R.check(x, K * blk * f, "shift in"); R.check(out, K_out * blk * f, "shift out")
+        elif k == 32:
+            tB, M, Nn, X, ldx, K, br, nb, tr, B, ldb, Cp, ldc, res, ldr, pre, ldp = a
+            assert (tB, Nn, ldx, K, br, nb, tr) == (1, H2, H2, H2, du, L + 1, 0) and M == min(N, (m + 2) * du)
+            assert X == xall + (m * S + du) * H2 * f and res == X and pre == efull and B == Wc and ldb == ldw
+            assert Cp == xall + ((m + 1) * S + du) * H2 * f
+            R.check(X, nb * br * H2 * f, "table"); R.check(Cp, M * H2 * f, "C"); R.check(pre, M * H2 * f, "pre_add")
+            R.check(B, ((Nn - 1) * ldb + 2 * K) * f, "B")
+            m += 1
         elif k == 1:
             (tA, tB, M, Nn, n_seg), A, lda, Ks = a[0:5], a[5:9], a[9:13], a[13:17]
             assert (tA, tB, Nn, n_seg, list(Ks[:2])) == (0, 1, H2, 2, [H2, H2]) and M == min(N, (m + 2) * du)
-            assert A[0] == xall + (m * S + du) * H2 * f
-            assert A[1] == ((shall + (m * S + du) * H2 * f) if basis else (xall + m * S * H2 * f))
+            assert A[0] == xall + (m * S + du) * H2 * f and A[1] == xall + m * S * H2 * f
             for sgm in range(2):
                 R.check(A[sgm], M * H2 * f, "A%d" % sgm)
             assert a[19] == xall + ((m + 1) * S + du) * H2 * f and a[24] == A[0] and a[26] == efull
@@ -931,14 +933,14 @@ def test_d_coef_host_sequence_and_extents(drv, basis, L):
     nws = drv.bg_d_coef_backward_workspace(H, ds, dl, L)
     assert nws > 0
     g, gall, wab = R.new("g", N * H2 * f), R.new("gall", (L + 1) * S * H2 * f), R.new("wab", 2 * H2 * H2 * f)
-    sht = R.new("sht", N * H2 * f) if basis else None
+    shall = R.new("shall", (L * S + du) * H2 * f) if basis else None
     partial, gW = R.new("partial", nws * f), R.new("gW", H2 * ldw * f)
     outs = [R.new(n, b * f) for n, b in (("g_bc", H2), ("g_fe_w", H * nf), ("g_fe_b", H), ("g_le_w", H * nl), ("g_le_b", H))]
-    drv.bg_d_coef_backward_f32.argtypes = [C.c_void_p] * 4 + [C.c_int64] * 8 + [C.c_int32] + [C.c_void_p] * 11
-    rc, bwd = calls_of(drv.bg_d_coef_backward_f32, g, xall, shall, Wc, ldw, H, nf, nl, ML, ds, dl, L, basis, sht, gall, wab,
+    drv.bg_d_coef_backward_f32.argtypes = [C.c_void_p] * 3 + [C.c_int64] * 8 + [C.c_int32] + [C.c_void_p] * 11
+    rc, bwd = calls_of(drv.bg_d_coef_backward_f32, g, xall, Wc, ldw, H, nf, nl, ML, ds, dl, L, basis, shall, gall, wab,
                        partial, gW, *outs, None)
     assert rc == 0
-    assert [k for k, _ in bwd] == [25, 20, 20, 20] + ([29, 1] if basis else [1]) * L + [19, 31]
+    assert [k for k, _ in bwd] == [25, 20, 20, 20] + [32 if basis else 1] * L + ([33] if basis else []) + [19, 31]
     m = L - 1
     for k, a in bwd:
         if k == 25:
@@ -946,15 +948,23 @@ def test_d_coef_host_sequence_and_extents(drv, basis, L):
         elif k == 20:
             dst, dp, src, sp, width, height = a
             R.check(dst, (height - 1) * dp + width, "copy dst"); R.check(src, (height - 1) * sp + width, "copy src")
-        elif k == 29:
-            x, out, K, K_out, blk, tr = a
-            assert (K, K_out, blk, tr) == (L + 1, L + 1, du * H2, 1) and x == gall + (m + 1) * S * H2 * f and out == sht
+        elif k == 32:
+            tB, M, Nn, X, ldx, K, br, nb, tr, B, ldb, Cp, ldc, res, ldr, pre, ldp = a
+            assert (tB, M, Nn, K, br, nb, tr, pre) == (0, N, H2, H2, du, L + 1, 1, 0)
+            assert X == gall + (m + 1) * S * H2 * f and res == X and Cp == gall + m * S * H2 * f and B == wab and ldb == H2
+            R.check(X, N * H2 * f, "G"); R.check(Cp, N * H2 * f, "G out"); R.check(B, 2 * K * H2 * f, "Wab")
+            m -= 1
         elif k == 1:
             A = a[5:9]
             assert a[2] == N and A[0] == gall + (m + 1) * S * H2 * f and a[19] == gall + m * S * H2 * f
-            assert A[1] == (sht if basis else A[0] + du * H2 * f)
+            assert A[1] == A[0] + du * H2 * f
             R.check(A[1], N * H2 * f, "shifted gradient state")
             m -= 1
+        elif k == 33:
+            x, out, nb, period, lead, K, blk, tr = a
+            assert (x, out, nb, period, lead, K, blk, tr) == (xall, shall, L * (L + 2) + 1, L + 2, 1, L + 1, du * H2, 0)
+            assert nb * blk * f == R.r["shall"][1]                      # every float of the workspace is written
+            R.check(x, (nb + 1) * blk * f, "xall read one block ahead")
         elif k == 19:
             M, Rr, A, lda, n_seg, B0, ldb0, N0, Cp, ldc, part, splits, accum, B1, ldb1, N1 = a
             assert (M, Rr, n_seg, N0, N1, accum) == (H2, L * S, 2, H2, H2, 0) and A == gall + S * H2 * f
@@ -965,7 +975,6 @@ def test_d_coef_host_sequence_and_extents(drv, basis, L):
         elif k == 31:
             assert a[0] == gall and a[1] == S * H2 and a[4] == gW + 2 * H2 * f
     assert m == -1
-    if basis:        # the Chebyshev form without its extra buffers is refused, not run
-        assert drv.bg_d_coef_forward_f32(*par, Wc, ldw, bc, H, nf, nl, ML, ds, dl, L, 1, xall, efull, None, None) != 0
-        assert drv.bg_d_coef_backward_f32(g, xall, shall, Wc, ldw, H, nf, nl, ML, ds, dl, L, 1, None, gall, wab, partial, gW,
+    if basis:        # the Chebyshev form without its workspace is refused, not run
+        assert drv.bg_d_coef_backward_f32(g, xall, Wc, ldw, H, nf, nl, ML, ds, dl, L, 1, None, gall, wab, partial, gW,
                                           *outs, None) != 0

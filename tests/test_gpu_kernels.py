@@ -936,3 +936,56 @@ def test_pos_terms_and_static_columns(cuda):
     onehot = torch.nn.functional.one_hot(p.level.cpu().long(), ML).float()
     expect = torch.cat([feat, onehot, got.cpu(), torch.ones(p.Nv, 1), torch.zeros(p.Nv, ds - 4 - ML - 5)], dim=1)
     assert torch.equal(Z[:, :ds].cpu(), expect) and bool((Z[:, ds:] == -7.0).all())
+
+
+@pytest.mark.parametrize("transpose", [False, True])
+@pytest.mark.parametrize("K1,R,K,N,M", [(13, 40, 256, 256, 520), (13, 40, 256, 256, 80), (5, 12, 64, 96, 50), (2, 8, 32, 32, 16)])
+def test_shift_on_load_product_equals_shift_then_product(cuda, K1, R, K, N, M, transpose):
+    """bg_gemm_cheb_f32 (second operand = the Chebyshev shift of the first's table, formed while the product loads it)
+    against bg_cheb_shift_f32 followed by bg_gemm_f32: bit for bit, for both maps, both layouts of B, partial row counts
+    (the recurrence's early layers), with and without addends."""
+    from building_gan_amd import _lib, ops
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(47)
+    X = (torch.rand(K1 * R, K, generator=gen) * 2 - 1).to(cuda)
+    sh = torch.empty_like(X)
+    ops.cheb_shift_raw(X, sh, K1, K1, R * K, transpose)
+    for transB in (True, False):
+        B = (torch.rand((N, 2 * K) if transB else (2 * K, N), generator=gen) * 2 - 1).to(cuda)
+        for addends in (True, False):
+            res = X[:M, :N].contiguous() if addends and N <= K else None
+            pre = (torch.rand(M, N, generator=gen) * 2 - 1).to(cuda) if addends else None
+            ref = ops.gemm_raw([X[:M], sh[:M]], B, False, transB, residual=res, pre_add=pre)
+            out = torch.full((M, N), float("nan"), device=cuda)
+            rc = lib.bg_gemm_cheb_f32(1 if transB else 0, M, N, X.data_ptr(), K, K, R, K1, 1 if transpose else 0, B.data_ptr(),
+                                      B.stride(0), out.data_ptr(), N, res.data_ptr() if res is not None else None, N,
+                                      pre.data_ptr() if pre is not None else None, N, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+            assert torch.equal(out, ref), (transB, addends)
+    # shapes outside the skinny kernel and aliasing are refused
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.bg_gemm_cheb_f32(1, M, N, X.data_ptr(), K, K, R, K1, 0, X.data_ptr(), 2 * K, X.data_ptr(), N, None, 0, None, 0, st) == -1
+    big = torch.zeros(1, device=cuda)
+    assert lib.bg_gemm_cheb_f32(1, 1 << 14, 1 << 10, X.data_ptr(), K, K, 1 << 14, 1, 0, X.data_ptr(), 2 * K, big.data_ptr(), 1 << 10,
+                                None, 0, None, 0, st) == -2
+
+
+def test_shift_of_stacked_tables_by_one_launch(cuda):
+    """bg_cheb_shift_slabs_f32 (the shifts of all layers' states of the coefficient recurrence at once: slabs of one padding
+    block + K coefficient blocks) against bg_cheb_shift_f32 per slab; padding blocks come out as zeros."""
+    from building_gan_amd import _lib, ops
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(48)
+    L, du, H2 = 5, 12, 32
+    K, P, blk = L + 1, L + 2, du * H2
+    X = torch.randn(L + 1, P, du, H2, generator=gen).to(cuda)
+    X[:, 0] = 0                                                      # the padding block of every slab
+    out = torch.full((L * P + 1, du, H2), float("nan"), device=cuda)
+    assert lib.bg_cheb_shift_slabs_f32(X.data_ptr(), out.data_ptr(), L * P + 1, P, 1, K, blk, 0,
+                                       torch.cuda.current_stream().cuda_stream) == 0
+    for m in range(L):
+        ref = torch.empty(K, du, H2, device=cuda)
+        ops.cheb_shift_raw(X[m, 1:].contiguous(), ref, K, K, blk, False)
+        assert torch.equal(out[m * P + 1:(m + 1) * P], ref), m
+        assert bool((out[m * P] == 0).all())
+    assert bool((out[L * P] == 0).all())
