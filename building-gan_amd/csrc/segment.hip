@@ -796,6 +796,63 @@ int launch_chain(const ChainArgs& a, int64_t n_blk, int64_t W, size_t lds, hipSt
     return BG_OK;
 }
 
+// Step loop of k_spmm_chain_short.  KIND: 1 = rows divided by rs, unit column weights (the mean-aggregation operator);
+// 2 = column weights only (its transpose); 0 = whatever the arguments say.  Same arithmetic in every KIND.
+template <int RPT, int DEG, bool HAS_ADD, int KIND>
+__device__ __forceinline__ void chain_short_steps(const ChainArgs& a, float4* buf0, float4* buf1,
+                                                  const int32_t (&cols)[RPT][DEG], const float (&wts)[RPT][DEG],
+                                                  const float (&rs)[RPT], int nr, int32_t r0, int cc, int tid, int nt) {
+    const bool use_w = KIND == 2 || (KIND == 0 && a.col_mode);
+    float4 ad_next[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        ad_next[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int r = tid + i * nt;
+        if (HAS_ADD && r < nr) ad_next[i] = bg_ld4(a.add + ((int64_t)r0 + r) * a.ld_add + cc);
+    }
+    for (int step = 1; step <= a.n_steps; ++step) {
+        const float4* src = (step & 1) ? buf0 : buf1;
+        float4* dst = (step & 1) ? buf1 : buf0;
+        float* outk = (a.out_step != 0 || step == a.n_steps) ? a.out + (int64_t)(step - 1) * a.out_step : nullptr;
+        const float fac = chain_factor(a.basis, step, a.n_steps);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int r = tid + i * nt;
+            if (r < nr) {
+                const int64_t grow = (int64_t)r0 + r;
+                const float4 ad = ad_next[i];
+                if (HAS_ADD && step < a.n_steps)       // the next step's addend travels while this step computes
+                    ad_next[i] = bg_ld4(a.add + (int64_t)step * a.add_step + grow * a.ld_add + cc);
+                float4 v[DEG];
+#pragma unroll
+                for (int j = 0; j < DEG; ++j) v[j] = src[cols[i][j]];
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (use_w) {
+#pragma unroll
+                    for (int j = 0; j < DEG; ++j) acc = bg_fma4(wts[i][j], v[j], acc);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < DEG; ++j) acc = bg_add4(acc, v[j]);
+                }
+                if (KIND == 1) {
+                    acc.x = acc.x / rs[i]; acc.y = acc.y / rs[i]; acc.z = acc.z / rs[i]; acc.w = acc.w / rs[i];
+                } else if (KIND == 0 && a.row_mode) {
+                    acc.x = apply_scale(acc.x, rs[i], a.row_mode); acc.y = apply_scale(acc.y, rs[i], a.row_mode);
+                    acc.z = apply_scale(acc.z, rs[i], a.row_mode); acc.w = apply_scale(acc.w, rs[i], a.row_mode);
+                }
+                if (a.basis) {
+                    acc.x *= fac; acc.y *= fac; acc.z *= fac; acc.w *= fac;
+                    if (step >= 2) { const float4 p = dst[r]; acc.x -= p.x; acc.y -= p.y; acc.z -= p.z; acc.w -= p.w; }
+                }
+                if (HAS_ADD) acc = bg_add4(acc, ad);
+                dst[r] = acc;
+                if (outk) bg_st4(outk + grow * a.ldo + cc, acc);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Fast form for short rows (every row of the operator has at most DEG slots, as on voxel grids: six
 // neighbours): each thread keeps the local column ids (and column weights) of its RPT rows in registers,
 // rows shorter than DEG are padded with a slot that points at an all-zero LDS row (x + 0 = x exactly),
@@ -848,44 +905,18 @@ __global__ __launch_bounds__(1024) void k_spmm_chain_short(ChainArgs a) {
         }
     }
     __syncthreads();
-    for (int step = 1; step <= a.n_steps; ++step) {
-        const float4* src = (step & 1) ? buf0 : buf1;
-        float4* dst = (step & 1) ? buf1 : buf0;
-        const float* addk = a.add ? a.add + (int64_t)(step - 1) * a.add_step : nullptr;
-        float* outk = (a.out_step != 0 || step == a.n_steps) ? a.out + (int64_t)(step - 1) * a.out_step : nullptr;
-        const float fac = chain_factor(a.basis, step, a.n_steps);
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int r = tid + i * nt;
-            if (r < nr) {
-                const int64_t grow = (int64_t)r0 + r;
-                float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (addk) ad = bg_ld4(addk + grow * a.ld_add + cc);
-                float4 v[DEG];
-#pragma unroll
-                for (int j = 0; j < DEG; ++j) v[j] = src[cols[i][j]];
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.col_mode) {
-#pragma unroll
-                    for (int j = 0; j < DEG; ++j) acc = bg_fma4(wts[i][j], v[j], acc);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < DEG; ++j) acc = bg_add4(acc, v[j]);
-                }
-                if (a.row_mode) {
-                    acc.x = apply_scale(acc.x, rs[i], a.row_mode); acc.y = apply_scale(acc.y, rs[i], a.row_mode);
-                    acc.z = apply_scale(acc.z, rs[i], a.row_mode); acc.w = apply_scale(acc.w, rs[i], a.row_mode);
-                }
-                if (a.basis) {
-                    acc.x *= fac; acc.y *= fac; acc.z *= fac; acc.w *= fac;
-                    if (step >= 2) { const float4 p = dst[r]; acc.x -= p.x; acc.y -= p.y; acc.z -= p.z; acc.w -= p.w; }
-                }
-                if (addk) acc = bg_add4(acc, ad);
-                dst[r] = acc;
-                if (outk) bg_st4(outk + grow * a.ldo + cc, acc);
-            }
-        }
-        __syncthreads();
+    // the step loop, specialised on what is uniform for the launch (no runtime mode tests, and no load -- hence no
+    // wait on the previous step's global stores, which share the load counter -- in a chain without addends)
+    const bool row_div_only = a.row_mode == BG_SCALE_DIV && !a.col_mode;
+    const bool col_only = !a.row_mode && a.col_mode;
+    if (a.add) {
+        if (row_div_only) chain_short_steps<RPT, DEG, true, 1>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
+        else if (col_only) chain_short_steps<RPT, DEG, true, 2>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
+        else chain_short_steps<RPT, DEG, true, 0>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
+    } else {
+        if (row_div_only) chain_short_steps<RPT, DEG, false, 1>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
+        else if (col_only) chain_short_steps<RPT, DEG, false, 2>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
+        else chain_short_steps<RPT, DEG, false, 0>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
     }
 }
 
@@ -915,7 +946,9 @@ int dispatch_chain_short(const ChainArgs& a, int64_t n_blk, int64_t W, hipStream
     if (a.max_rows <= 256) return launch_chain_short<1, DEG>(a, n_blk, W, 256, s);
     if (a.max_rows <= 512) return launch_chain_short<1, DEG>(a, n_blk, W, 512, s);
     if (a.max_rows <= 1024) return launch_chain_short<1, DEG>(a, n_blk, W, 1024, s);
-    return launch_chain_short<2, DEG>(a, n_blk, W, 1024, s);
+    if (a.max_rows <= 2048) return launch_chain_short<2, DEG>(a, n_blk, W, 1024, s);
+    if constexpr (DEG <= 6) return launch_chain_short<3, DEG>(a, n_blk, W, 1024, s);   // 8 slots x 3 rows spill
+    return BG_ERR_SHAPE;
 }
 
 }  // namespace
@@ -969,8 +1002,8 @@ int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const
     ChainArgs a{x0, ldx, rowptr, col, row_scale, row_mode, col_scale, col_mode, blk_ptr, (int)max_rows, (int)max_nnz,
                 add, ld_add, add_step, out, ldo, out_step, (int)n_steps, 0, nullptr, 0, nullptr, 0, 0, (int)basis};
     hipStream_t s = (hipStream_t)stream;
-    if (max_deg <= 8 && max_rows <= 2048) {
-        // short rows: indices in registers, 1 or 2 rows per thread (4 rows per thread spills)
+    if (max_deg <= 8 && max_rows <= (max_deg <= 6 ? 3072 : 2048)) {
+        // short rows: indices in registers, 1 to 3 rows per thread (4 rows per thread spills, 3 do with 8 slots)
         return max_deg <= 6 ? dispatch_chain_short<6>(a, n_blk, W, s) : dispatch_chain_short<8>(a, n_blk, W, s);
     }
     size_t lds = chain_lds_bytes(max_rows, max_nnz, true);
@@ -995,7 +1028,7 @@ int bg_spmm_chain_pair_f32(const float* x0, int64_t ldx, float* out, int64_t ldo
     if (W % 4 != 0 || Wb % 4 != 0 || n_blk > 65535 || (W + Wb) / 4 > 65535 || n_steps > (1 << 20)) return BG_ERR_SHAPE;
     if (!bg_aligned16(x0) || !bg_aligned16(out) || !bg_aligned16(x0b) || !bg_aligned16(outb) || ldx % 4 != 0 ||
         ldo % 4 != 0 || out_step % 4 != 0 || ldxb % 4 != 0 || ldob % 4 != 0 || out_stepb % 4 != 0) return BG_ERR_ALIGN;
-    if (!(max_deg <= 8 && max_rows <= 2048)) return BG_ERR_SHAPE;      // short-row plans only: else two bg_spmm_chain_f32 calls
+    if (!(max_deg <= 8 && max_rows <= (max_deg <= 6 ? 3072 : 2048))) return BG_ERR_SHAPE;      // short-row plans only: else two bg_spmm_chain_f32 calls
     ChainArgs a{x0, ldx, rowptr, col, row_scale, row_mode, col_scale, col_mode, blk_ptr, (int)max_rows, (int)max_nnz,
                 nullptr, 0, 0, out, ldo, out_step, (int)n_steps, (int)(W / 4), x0b, ldxb, outb, ldob, out_stepb, (int)basis};
     hipStream_t s = (hipStream_t)stream;

@@ -267,7 +267,7 @@ def power_chain_pair_raw(op: LinOp, Z1: torch.Tensor, W1: int, Z2: torch.Tensor,
     basis = D_BASIS if basis is None else basis
     N = Z1.shape[0]
     A, B = Z1.view(N, -1), Z2.view(N, -1)
-    ok = (blocks is not None and L > 0 and N > 0 and blocks.max_deg <= 8 and blocks.max_rows <= 2048
+    ok = (blocks is not None and L > 0 and N > 0 and blocks.max_deg <= 8 and blocks.max_rows <= (3072 if blocks.max_deg <= 6 else 2048)
           and A.dtype == torch.float32 and B.dtype == torch.float32 and A.stride(1) == 1 and B.stride(1) == 1
           and A.shape[1] >= (L + 1) * W1 and B.shape[1] >= (L + 1) * W2 and B.shape[0] == N and N == op.csr.n_cols
           and _chain_fits(op, blocks, W1, A) and _chain_fits(op, blocks, W2, B))

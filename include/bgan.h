@@ -171,7 +171,7 @@ int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const
 
 /* bg_spmm_chain_f32 (no addend) on TWO matrices under the same operator and step count in one launch: the
  * column chunks of both fill the chip side by side (a chain's time does not depend on its width).  Short-row
- * plans only (max_deg <= 8, max_rows <= 2048), else BG_ERR_SHAPE and the caller launches them one by one.
+ * plans only (max_deg <= 8 and max_rows <= 2048, or max_deg <= 6 and max_rows <= 3072), else BG_ERR_SHAPE and the caller launches them one by one.
  * basis: BG_CHAIN_POWER or BG_CHAIN_CHEB.
  * replaces: the label-free and the label operator powers of the collapsed discriminator, Model/models.py:227-228. */
 int bg_spmm_chain_pair_f32(const float* x0, int64_t ldx, float* out, int64_t ldo, int64_t out_step, int64_t W,

@@ -635,6 +635,39 @@ def test_operator_chain_matches_separate_launches(cuda, preset, ragged, W, L, ba
 
 
 @pytest.mark.parametrize("basis", [0, 1])
+def test_operator_chain_three_rows_per_thread(cuda, basis):
+    """Graphs of 2,049..3,072 voxels (the jittered dataset stream has them: 14 x 14 x 11 = 2,156) stay in the register-index
+    chain kernel with three rows per thread: bit-exact against the separate launches and against the LDS-index kernel
+    (which 8-slot plans of that size take), powers / Horner / pair forms, both bases."""
+    from building_gan_amd import ops
+    import dataclasses
+    g, p = _plan(_batch("dataset", 2, "jitter"), cuda)
+    blocks = p.vox_blocks
+    assert 2048 < blocks.max_rows <= 3072 and blocks.max_deg <= 6
+    gen = torch.Generator().manual_seed(8)
+    N, W, L = p.Nv, 8, 12
+    x = (torch.rand(N, W, generator=gen) * 2 - 1).to(cuda)
+    Y = (torch.rand(N, L + 1, W, generator=gen) * 2 - 1).to(cuda)
+    general = dataclasses.replace(blocks, max_deg=8)                 # 8 slots x 3 rows would spill: the LDS-index kernel
+    for op in (p.vox_mean, p.vox_mean.T):
+        outs = []
+        for blk in (blocks, general, None):
+            Z = torch.zeros(N, (L + 1) * W, device=cuda)
+            Z[:, :W] = x
+            ops.power_chain_raw(op, Z, L, W, blk, basis)
+            outs.append((Z, ops.horner_chain_raw(op, Y, L, W, blk, basis)))
+        for Z, acc in outs[:2]:
+            assert torch.equal(Z, outs[2][0]) and torch.equal(acc, outs[2][1])
+    Z1 = torch.zeros(N, (L + 1) * W, device=cuda); Z1[:, :W] = x
+    Z2 = torch.zeros(N, (L + 1) * 4, device=cuda); Z2[:, :4] = x[:, :4]
+    R1, R2 = Z1.clone(), Z2.clone()
+    ops.power_chain_pair_raw(p.vox_mean, Z1, W, Z2, 4, L, blocks, basis)
+    ops.power_chain_raw(p.vox_mean, R1, L, W, None, basis)
+    ops.power_chain_raw(p.vox_mean, R2, L, 4, None, basis)
+    assert torch.equal(Z1, R1) and torch.equal(Z2, R2)
+
+
+@pytest.mark.parametrize("basis", [0, 1])
 def test_operator_chain_autograd_pair(cuda, basis):
     """PowerChain / HornerChain are each other's backward (in either basis): gradients against a dense fp64 statement."""
     from building_gan_amd import ops
