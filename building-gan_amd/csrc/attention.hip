@@ -206,21 +206,37 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
         wd1[j] = Wd ? Wd[ldwd + lane + 64 * j] : 0.f;
     }
     for (int64_t v = wave_id; v < n_vox; v += n_waves) {
-        float vv[CPL];
+        // A voxel's time is its chain of DEPENDENT memory round trips, so the loads are grouped by what they depend
+        // on: (1) everything addressed by v alone, (2) the cross edges' program ids and noise, (3) the NN_p rows AND the
+        // program feature rows of the first four edges (both need only the ids).  Same arithmetic in the same order.
+        float vv[CPL], av[CPL];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) vv[j] = V[v * ldv + lane + 64 * j];
+        for (int j = 0; j < CPL; ++j) { vv[j] = V[v * ldv + lane + 64 * j]; av[j] = A[v * lda + lane + 64 * j]; }
+        const int32_t b = rowptr[v], e = rowptr[v + 1];
+        const float em0 = exp_mask[2 * v], em1 = exp_mask[2 * v + 1];
+        float l0 = 0.f, l1 = 0.f;
+        if (!Wd) { l0 = logits[v * ldl]; l1 = logits[v * ldl + 1]; }
+        const int deg = e - b;
+        const int32_t my_col = lane < deg ? col[b + lane] : 0;
+        const float my_exp = lane < deg ? exp_att[b + lane] : 1.f;
+        float bv[4][CPL], xv0[4][CPL];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int32_t c = __shfl(my_col, i < deg ? i : 0, 64);
+            const float* bp = B + (int64_t)c * ldb;
+            const float* xp = X + (int64_t)c * ldx;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) { bv[i][j] = bp[lane + 64 * j]; xv0[i][j] = xp[lane + 64 * j]; }
+        }
         // ---- mask logits: given, or the composed two-row decoder applied to the voxel's features here
-        float l0, l1;
         if (Wd) {
             float d0 = 0.f, d1 = 0.f;
 #pragma unroll
             for (int j = 0; j < CPL; ++j) { d0 = fmaf(vv[j], wd0[j], d0); d1 = fmaf(vv[j], wd1[j], d1); }
             l0 = bg_wave_sum(d0) + bd[0]; l1 = bg_wave_sum(d1) + bd[1];
-        } else {
-            l0 = logits[v * ldl]; l1 = logits[v * ldl + 1];
         }
         // ---- two-way mask (k_mask_gumbel)
-        const float z0 = l0 - logf(exp_mask[2 * v]), z1 = l1 - logf(exp_mask[2 * v + 1]);
+        const float z0 = l0 - logf(em0), z1 = l1 - logf(em1);
         const float zm = fmaxf(z0, z1);
         const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
         const float esum = e0 + e1;
@@ -228,25 +244,18 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
         const float one0 = s0 >= s1 ? 1.f : 0.f;
         if (lane == 0) { soft0[v] = s0; hard0[v] = (one0 - s0) + s0; }
         // ---- logits of the voxel's cross edges (k_cross_logits); lane j keeps edge j's y = (att + gumbel) / tau.
-        // Lane j first fetches edge j's program node and noise (one coalesced load each); the program rows of
-        // four edges are then requested together, so a voxel pays one memory round trip per four edges
-        // instead of two dependent ones (index, then row) per edge.  Same arithmetic in the same order.
-        float av[CPL];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) av[j] = A[v * lda + lane + 64 * j];
-        const int32_t b = rowptr[v], e = rowptr[v + 1];
-        const int deg = e - b;
-        const int32_t my_col = lane < deg ? col[b + lane] : 0;
-        const float my_exp = lane < deg ? exp_att[b + lane] : 1.f;
+        // The program rows of four edges are requested together, so a voxel pays one memory round trip per four
+        // edges instead of two dependent ones (index, then row) per edge.
         float y = -3.402823466e+38f;
         for (int k0 = 0; k0 < deg; k0 += 4) {
-            float bv[4][CPL];
+            if (k0 > 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int32_t c = __shfl(my_col, k0 + i < deg ? k0 + i : k0, 64);
-                const float* bp = B + (int64_t)c * ldb;
+                for (int i = 0; i < 4; ++i) {
+                    const int32_t c = __shfl(my_col, k0 + i < deg ? k0 + i : k0, 64);
+                    const float* bp = B + (int64_t)c * ldb;
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) bv[i][j] = bp[lane + 64 * j];
+                    for (int j = 0; j < CPL; ++j) bv[i][j] = bp[lane + 64 * j];
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -284,10 +293,15 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
             float xv[4][CPL];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int32_t c = __shfl(my_col, k0 + i < deg ? k0 + i : k0, 64);
-                const float* xp = X + (int64_t)c * ldx;
+                if (k0 == 0) {                                       // wave-uniform: the rows fetched at the top
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) xv[i][j] = xp[lane + 64 * j];
+                    for (int j = 0; j < CPL; ++j) xv[i][j] = xv0[i][j];
+                } else {
+                    const int32_t c = __shfl(my_col, k0 + i < deg ? k0 + i : k0, 64);
+                    const float* xp = X + (int64_t)c * ldx;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) xv[i][j] = xp[lane + 64 * j];
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
