@@ -58,6 +58,7 @@ SIGNATURES = {
     "bg_spmm_chain_pair_f32": [_p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _int, _p, _int,
                                _p, _i64, _i64, _i64, _i64, _i64, _i32, _p],
     "bg_cheb_shift_f32": [_p, _p, _i64, _i64, _i64, _i32, _p],
+    "bg_tile_f32": [_p, _p, _i64, _i64, _p],
     "bg_cheb_shift_slabs_f32": [_p, _p, _i64, _i64, _i64, _i64, _i64, _i32, _p],
     "bg_gemm_cheb_f32": [_int, _i64, _i64, _p, _i64, _i64, _i64, _i64, _int, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p],
     "bg_attention_bwd_head_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _i64,

@@ -300,6 +300,12 @@ __global__ void k_regroup(const float4* __restrict__ src, float4* __restrict__ d
     if (to_outer) dst[outer] = src[t]; else dst[t] = src[outer];
 }
 
+// dst[r][i] = src[i] for r < reps (one float4 per thread of dst)
+__global__ void k_tile4(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4, int64_t total4) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total4) dst[t] = src[t % n4];
+}
+
 __global__ void k_fill4(float4* __restrict__ p, int64_t n4, float v) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n4) p[t] = make_float4(v, v, v, v);
@@ -511,6 +517,19 @@ int bg_d_coef_init_f32(const float* fe_w, const float* fe_b, const float* le_w, 
     if (n > 0x7fffffff) return BG_ERR_SHAPE;
     k_d_coef_init<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
         fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, (int)H, (int)nf, (int)nl, (int)ML, (int)ds, (int)(ds + dl), x0, e);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_tile_f32(const float* src, float* dst, int64_t n, int64_t reps, bgStream stream) {
+    if (n < 0 || reps < 0) return BG_ERR_ARG;
+    if (n == 0 || reps == 0) return BG_OK;
+    if (!src || !dst) return BG_ERR_ARG;
+    if (n % 4 != 0 || (n / 4) * reps > 0x7fffffffLL * 256) return BG_ERR_SHAPE;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return BG_ERR_ALIGN;
+    const int64_t total4 = (n / 4) * reps;
+    k_tile4<<<bg_grid_for(total4, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n / 4, total4);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -499,8 +499,11 @@ struct GStack {
     float *nnp, *posb, *v[65], *gm[32], *y[32], *a[32], *soft0[32], *soft[32];
     float *pq, *term, *h0, *ha;                                                   // forward scratch
     // backward scratch
-    float *g0, *g1, *gz, *gterm, *story, *sb, *gx, *gsb, *g_story, *G_al, *gg, *d_att, *dpre, *dth_p, *gb_acc, *gx_acc,
-          *tmpNp, *zero, *splitk, *colsum;
+    // Per-call pieces whose weight-gradient products run ONCE over all calls are carved as contiguous stacks (call i at
+    // base + i * rows * width): the block inputs vb, aggregates gm, and in the backward gz / gterm / story / sb; the
+    // attention inputs va, G_al, dth_p.  pdm4_rep = the position columns repeated per block call (third operand there).
+    float *vb, *va, *gm_all, *gz_all, *gterm_all, *story_all, *sb_all, *G_al_all, *dth_all, *pdm4_rep;
+    float *g0, *g1, *gx, *gsb, *g_story, *gg, *d_att, *dpre, *gb_acc, *gx_acc, *tmpNp, *zero, *splitk, *colsum;
 };
 
 int32_t tn_splits_multi(int64_t M, const int64_t* Ns, int n_seg, int64_t R) {     // ops.gemm_tn_raw's rule
@@ -536,14 +539,21 @@ int carve_gstack(Arena& ar, int64_t Np, int64_t Nv, int64_t S, int64_t Ec, int64
     int rc = gstack_ops(L, g);
     if (rc != BG_OK) return rc;
     g.nnp = ar.take(Np * H); g.posb = ar.take(Nv * H);
-    for (int64_t k = 0; k <= g.n_ops; ++k) g.v[k] = ar.take(Nv * H);
-    for (int64_t i = 0; i < g.n_blk; ++i) { g.gm[i] = ar.take(Nv * H); g.y[i] = ar.take(Nv * H); }
+    const int64_t nb = cross_logit_blocks(Nv);
+    // a call's input is the previous call's output: block inputs and attention inputs in one contiguous stack each
+    g.vb = ar.take(g.n_blk * Nv * H); g.va = ar.take(g.n_att * Nv * H);
+    for (int64_t k = 0; k < g.n_ops; ++k) g.v[k] = (g.kind[k] == 1 ? g.vb : g.va) + (int64_t)g.idx[k] * Nv * H;
+    g.v[g.n_ops] = ar.take(Nv * H);
+    g.gm_all = ar.take(g.n_blk * Nv * H);
+    for (int64_t i = 0; i < g.n_blk; ++i) { g.gm[i] = g.gm_all + i * Nv * H; g.y[i] = ar.take(Nv * H); }
     for (int64_t c = 0; c < g.n_att; ++c) { g.a[c] = ar.take(Nv * H); g.soft0[c] = ar.take(Nv); g.soft[c] = ar.take(Ec); }
     g.pq = ar.take(S * 2 * H); g.term = ar.take(S * H); g.h0 = ar.take(Nv); g.ha = ar.take(Ec);
-    g.g0 = ar.take(Nv * H); g.g1 = ar.take(Nv * H); g.gz = ar.take(Nv * H); g.gterm = ar.take(S * H); g.story = ar.take(S * H);
-    g.sb = ar.take(S * H); g.gx = ar.take(Nv * 2 * H); g.gsb = ar.take(S * 2 * H); g.g_story = ar.take(S * H);
-    g.G_al = ar.take(Nv * (H + 4)); g.gg = ar.take(Nv * H); g.d_att = ar.take(Ec); g.dpre = ar.take(Ec * H);
-    g.dth_p = ar.take((int64_t)cross_logit_blocks(Nv) * H);
+    g.g0 = ar.take(Nv * H); g.g1 = ar.take(Nv * H);
+    g.gz_all = ar.take(g.n_blk * Nv * H); g.gterm_all = ar.take(g.n_blk * S * H); g.story_all = ar.take(g.n_blk * S * H);
+    g.sb_all = ar.take(g.n_blk * S * H); g.pdm4_rep = ar.take(g.n_blk * Nv * 4);
+    g.gx = ar.take(Nv * 2 * H); g.gsb = ar.take(S * 2 * H); g.g_story = ar.take(S * H);
+    g.G_al_all = ar.take(g.n_att * Nv * (H + 4)); g.gg = ar.take(Nv * H); g.d_att = ar.take(Ec); g.dpre = ar.take(Ec * H);
+    g.dth_all = ar.take(g.n_att * nb * H);
     g.gb_acc = ar.take(Np * H); g.gx_acc = ar.take(Np * H); g.tmpNp = ar.take(Np * H); g.zero = ar.take(Nv * H);
     int64_t sk = 0;
     auto need = [&](int64_t M, std::initializer_list<int64_t> ns, int64_t R) {
@@ -552,7 +562,8 @@ int carve_gstack(Arena& ar, int64_t Np, int64_t Nv, int64_t S, int64_t Ec, int64
         const int64_t x = (int64_t)tn_splits_multi(M, Ns, n, R) * M * N;
         if (x > sk) sk = x;
     };
-    need(H, {H, H, 4}, Nv); need(H, {H, H}, S); need(H + 4, {H}, Nv); need(H, {4}, Nv); need(H, {H}, Np);
+    need(H, {H, H, 4}, g.n_blk * Nv); need(H, {H, H}, g.n_blk * S); need(H + 4, {H}, g.n_att * Nv); need(H, {4}, Nv);
+    need(H, {H}, Np);
     g.splitk = ar.take(sk);
     g.colsum = ar.take(256 * (H + 4));
     return BG_OK;
@@ -668,9 +679,11 @@ extern "C" int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGener
             const bool last = c == g.n_att - 1;
             const float* soft0 = last ? mask_soft : g.soft0[c];
             const float* soft = last ? att_soft : g.soft[c];
+            float* G_al = g.G_al_all + (int64_t)c * Nv * (H + 4);
+            float* dth_p = g.dth_all + (int64_t)c * nb * H;
             BG_TRY(bg_attention_bwd_head_f32(gin, H, x, H, soft0, soft, p->cx_rowptr, p->cx_col, last ? g_att_soft : nullptr,
                                              last ? g_att_hard : nullptr, last ? g_mask_soft : nullptr,
-                                             last ? g_mask_hard : nullptr, -1.0f, g.gg, H, g.d_att, g.G_al + H, H + 4, Nv, H, s));
+                                             last ? g_mask_hard : nullptr, -1.0f, g.gg, H, g.d_att, G_al + H, H + 4, Nv, H, s));
             if (!last) {                       // (the last call's gg is zero: nothing reaches x through its gather)
                 float* dst = have_np ? g.tmpNp : g.gx_acc;
                 if (bp->cp_one_launch)
@@ -681,8 +694,8 @@ extern "C" int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGener
                                        BG_SCALE_NONE, dst, H, Np, H, s));
                 if (have_np) BG_TRY(bg_add_f32(g.gx_acc, g.tmpNp, g.gx_acc, Np * H, s));
             }
-            BG_TRY(bg_cross_logits_bwd_f32(g.a[c], H, g.nnp, H, w->theta, p->cx_rowptr, p->cx_col, g.d_att, g.dpre, g.G_al,
-                                           H + 4, g.dth_p, nb, Nv, H, s));
+            BG_TRY(bg_cross_logits_bwd_f32(g.a[c], H, g.nnp, H, w->theta, p->cx_rowptr, p->cx_col, g.d_att, g.dpre, G_al,
+                                           H + 4, dth_p, nb, Nv, H, s));
             {
                 float* dst = have_att ? g.tmpNp : g.gb_acc;
                 if (bp->cp_one_launch)
@@ -694,15 +707,8 @@ extern "C" int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGener
                 if (have_att) BG_TRY(bg_add_f32(g.gb_acc, g.tmpNp, g.gb_acc, Np * H, s));
             }
             if (!last && !have_np) have_np = true;
-            BG_TRY(bg_colsum_f32(g.dth_p, H, nb, H, g.colsum, colsum_blocks(nb), g_theta, have_att ? 1 : 0, s));
-            {
-                const float* Bs[4] = {v, nullptr, nullptr, nullptr};
-                const int64_t ldb[4] = {H, 0, 0, 0}, Ns[4] = {H, 0, 0, 0};
-                BG_TRY(tn_multi(H + 4, Nv, g.G_al, 1, Bs, ldb, Ns, g_Wcat, g.splitk, have_att ? 1 : 0, s));
-            }
-            BG_TRY(bg_colsum_f32(g.G_al, H + 4, Nv, H + 4, g.colsum, colsum_blocks(Nv), g_bcat, have_att ? 1 : 0, s));
-            {
-                const float* A[4] = {g.G_al, nullptr, nullptr, nullptr};
+            {   // (the weight gradients of all attention calls: one product / column sum each after the loop)
+                const float* A[4] = {G_al, nullptr, nullptr, nullptr};
                 const int64_t ld[4] = {H + 4, 0, 0, 0}, Ks[4] = {H + 4, 0, 0, 0};
                 BG_TRY(bg_gemm_f32(0, 0, Nv, H, 1, A, ld, Ks, w->Wcat, H, gout, H, nullptr, nullptr, BG_ACT_NONE, 0.f, gin, H,
                                    nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
@@ -710,26 +716,20 @@ extern "C" int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGener
             have_att = true;
         } else {
             const int i = g.idx[k];
-            BG_TRY(bg_story_bwd_f32(gin, H, g.y[i], H, v, H, p->st_rowptr, p->st_col, p->st_count, 0.01f, g.gz, H, g.gterm, H,
-                                    g.story, H, S, H, s));
+            float* gz = g.gz_all + (int64_t)i * Nv * H;
+            float* gterm = g.gterm_all + (int64_t)i * S * H;
+            float* story = g.story_all + (int64_t)i * S * H;
+            BG_TRY(bg_story_bwd_f32(gin, H, g.y[i], H, v, H, p->st_rowptr, p->st_col, p->st_count, 0.01f, gz, H, gterm, H,
+                                    story, H, S, H, s));
+            // (the weight gradients of all block calls: one product each after the loop, over the stacked gz / gterm)
+            BG_TRY(bg_spmm_f32(story, H, p->sb_rowptr, p->sb_col, nullptr, nullptr, p->sb_count, BG_SCALE_DIV, nullptr,
+                               BG_SCALE_NONE, g.sb_all + (int64_t)i * S * H, H, S, H, s));
             {
-                const float* Bs[4] = {v, g.gm[i], pdm4, nullptr};
-                const int64_t ldb[4] = {H, H, 4, 0}, Ns[4] = {H, H, 4, 0};
-                BG_TRY(tn_multi(H, Nv, g.gz, 3, Bs, ldb, Ns, g_Wc, g.splitk, have_blk ? 1 : 0, s));
-            }
-            BG_TRY(bg_spmm_f32(g.story, H, p->sb_rowptr, p->sb_col, nullptr, nullptr, p->sb_count, BG_SCALE_DIV, nullptr,
-                               BG_SCALE_NONE, g.sb, H, S, H, s));
-            {
-                const float* Bs[4] = {g.story, g.sb, nullptr, nullptr};
-                const int64_t ldb[4] = {H, H, 0, 0}, Ns[4] = {H, H, 0, 0};
-                BG_TRY(tn_multi(H, S, g.gterm, 2, Bs, ldb, Ns, g_Wsb, g.splitk, have_blk ? 1 : 0, s));
-            }
-            {
-                const float* A[4] = {g.gz, nullptr, nullptr, nullptr};
+                const float* A[4] = {gz, nullptr, nullptr, nullptr};
                 const int64_t ld[4] = {H, 0, 0, 0}, Ks[4] = {H, 0, 0, 0};
                 BG_TRY(bg_gemm_f32(0, 0, Nv, 2 * H, 1, A, ld, Ks, w->Wc, w->ldwc, g.gx, 2 * H, nullptr, nullptr, BG_ACT_NONE, 0.f,
                                    nullptr, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
-                A[0] = g.gterm;
+                A[0] = gterm;
                 BG_TRY(bg_gemm_f32(0, 0, S, 2 * H, 1, A, ld, Ks, w->Wsb, 2 * H, g.gsb, 2 * H, nullptr, nullptr, BG_ACT_NONE, 0.f,
                                    nullptr, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
             }
@@ -741,6 +741,23 @@ extern "C" int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGener
             have_blk = true;
         }
         gin = gout;
+    }
+    // shared weights: the sum over the calls IS the reduction dimension of one product over the stacked rows
+    if (have_blk) {
+        BG_TRY(bg_tile_f32(pdm4, g.pdm4_rep, Nv * 4, g.n_blk, s));
+        const float* Bs[4] = {g.vb, g.gm_all, g.pdm4_rep, nullptr};
+        const int64_t ldb[4] = {H, H, 4, 0}, Ns[4] = {H, H, 4, 0};
+        BG_TRY(tn_multi(H, g.n_blk * Nv, g.gz_all, 3, Bs, ldb, Ns, g_Wc, g.splitk, 0, s));
+        const float* Bt[4] = {g.story_all, g.sb_all, nullptr, nullptr};
+        const int64_t ldt[4] = {H, H, 0, 0}, Nt[4] = {H, H, 0, 0};
+        BG_TRY(tn_multi(H, g.n_blk * S, g.gterm_all, 2, Bt, ldt, Nt, g_Wsb, g.splitk, 0, s));
+    }
+    if (have_att) {
+        const float* Bs[4] = {g.va, nullptr, nullptr, nullptr};
+        const int64_t ldb[4] = {H, 0, 0, 0}, Ns[4] = {H, 0, 0, 0};
+        BG_TRY(tn_multi(H + 4, g.n_att * Nv, g.G_al_all, 1, Bs, ldb, Ns, g_Wcat, g.splitk, 0, s));
+        BG_TRY(bg_colsum_f32(g.G_al_all, H + 4, g.n_att * Nv, H + 4, g.colsum, colsum_blocks(g.n_att * Nv), g_bcat, 0, s));
+        BG_TRY(bg_colsum_f32(g.dth_all, H, g.n_att * nb, H, g.colsum, colsum_blocks(g.n_att * nb), g_theta, 0, s));
     }
     // encoder and NN_p
     {

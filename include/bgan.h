@@ -651,6 +651,10 @@ int bg_iota_mod_i32(int32_t* out, int64_t n, int64_t mod, bgStream stream);
  * (the gradients of D(real) and D(fake) with respect to the shared label-free part).
  * replaces: autograd's gradient accumulation for a tensor used twice.                                      */
 int bg_add_f32(const float* a, const float* b, float* out, int64_t n, bgStream stream);
+/* dst [reps, n] = src [n] repeated (n % 4 == 0, 16-byte aligned).
+ * no counterpart in the reference: the position columns stacked once per generator-block call, so that the weight gradient
+ * of all calls of the shared block (Model/models.py:198-200) is ONE product over the stacked rows.             */
+int bg_tile_f32(const float* src, float* dst, int64_t n, int64_t reps, bgStream stream);
 
 /* Everything one WGAN-GP critic update evaluates AFTER the collapsed GNN's coefficient table W and the operator powers
  * exist -- D(real), D(fake), the closed-form penalty gradients at the sample point, the objective -- and its

@@ -222,6 +222,11 @@ int bg_iota_mod_i32(int32_t* out, int64_t n, int64_t mod, bgStream) {
     rec(28, a, sizeof(a) / 8);
     return 0;
 }
+int bg_tile_f32(const float* src, float* dst, int64_t n, int64_t reps, bgStream) {
+    int64_t a[] = {P(src), P(dst), n, reps};
+    rec(34, a, sizeof(a) / 8);
+    return 0;
+}
 int bg_fill_f32(float* p, int64_t n, float, bgStream) {
     int64_t a[] = {P(p), 0, n * 4};
     rec(25, a, sizeof(a) / 8);

@@ -700,6 +700,9 @@ def _check_generic(calls, R, z):
         elif kind == 25:
             dst, val, nbytes = a
             R.check(dst, nbytes, tag + " memset")
+        elif kind == 34:
+            src, dst, n, reps = a
+            R.check(src, n * 4, tag + " src"); R.check(dst, n * reps * 4, tag + " dst")
         else:
             raise AssertionError("unexpected launcher %d" % kind)
 
@@ -715,10 +718,11 @@ def test_gstack_host_sequence_and_extents(drv, Np, Nv, S, Ec, one):
     _check_generic(fwd, R, z)
     _check_generic(bwd, R, z)
     red = 24 if one else 2
-    att_last = [22, 23, red, 17, 19, 17, 1]
-    att_first_np = [22, red, 23, red, 18, 17, 19, 17, 1]                  # first call that reaches x: assigns g_x's sum
-    att = [22, red, 18, 23, red, 18, 17, 19, 17, 1]
-    blk = [21, 19, 2, 19, 1, 1, 3, 3]
+    # (no weight-gradient product inside the loop: the shared weights' gradients are ONE product each over the stacked calls)
+    att_last = [22, 23, red, 1]
+    att_first_np = [22, red, 23, red, 18, 1]                              # first call that reaches x: assigns g_x's sum
+    att = [22, red, 18, 23, red, 18, 1]
+    blk = [21, 2, 1, 1, 3, 3]
     seq = [25] + att_last
     n_att_seen = 1
     for i in range(10, -1, -1):                                           # ops in reverse: ..., block i, (attention before it)
@@ -728,7 +732,7 @@ def test_gstack_host_sequence_and_extents(drv, Np, Nv, S, Ec, one):
         if (i - 1) % 2 == 0 and (i - 1) != 0 and i - 1 >= 0:             # an attention call follows block i-1
             seq += att_first_np if n_att_seen == 1 else att
             n_att_seen += 1
-    seq += (att_first_np if n_att_seen == 1 else att) + [19, 17, 19, 17, 1]
+    seq += (att_first_np if n_att_seen == 1 else att) + [34, 19, 19] + [19, 17, 17] + [19, 17, 19, 17, 1]
     assert [k for k, _ in bwd] == seq
     # the forward's saved pieces live in the workspace; the last call writes the caller's outputs
     att_calls = [a for k, a in fwd if k == 5]
@@ -740,8 +744,19 @@ def test_gstack_host_sequence_and_extents(drv, Np, Nv, S, Ec, one):
             flags.setdefault(R.check(a[8], 4, "C"), []).append(a[12])
         elif k == 17 and R.check(a[6], 4, "out") != "workspace":
             flags.setdefault(R.check(a[6], 4, "out"), []).append(a[7])
-    assert flags["g_Wc"] == [0] + [1] * 10 and flags["g_Wsb"] == [0] + [1] * 10
-    assert flags["g_Wcat"] == [0] + [1] * 5 and flags["g_bcat"] == [0] + [1] * 5 and flags["g_theta"] == [0] + [1] * 5
+    assert flags["g_Wc"] == [0] and flags["g_Wsb"] == [0]
+    assert flags["g_Wcat"] == [0] and flags["g_bcat"] == [0] and flags["g_theta"] == [0]
+    # the stacked products reduce over every call's rows: 11 block calls, 6 attention calls
+    stacked = {R.check(a[8], 4, "C"): a[1] for k, a in bwd if k == 19}
+    assert stacked["g_Wc"] == 11 * Nv and stacked["g_Wsb"] == 11 * S and stacked["g_Wcat"] == 6 * Nv
+    tile = [a for k, a in bwd if k == 34]
+    assert len(tile) == 1 and R.check(tile[0][0], Nv * 4 * 4, "pdm4") == "pdm4" and tile[0][2:] == [Nv * 4, 11]
+    R.check(tile[0][1], 11 * Nv * 4 * 4, "pdm4 stack")
+    # every call's slice of a stack is written by that call and only that call: 11 distinct gz / 6 distinct G_al targets
+    gz_targets = [a[9] for k, a in bwd if k == 21]
+    assert len(set(gz_targets)) == 11 and max(gz_targets) - min(gz_targets) == 10 * Nv * 128 * 4
+    gal_targets = [a[9] for k, a in bwd if k == 23]
+    assert len(set(gal_targets)) == 6 and max(gal_targets) - min(gal_targets) == 5 * Nv * 132 * 4
     assert flags["g_enc_w"] == [0] and flags["g_enc_b"] == [0] and flags["g_nnp_w"] == [0] and flags["g_nnp_b"] == [0]
 
 
