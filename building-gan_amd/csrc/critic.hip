@@ -204,7 +204,7 @@ __global__ void k_d_static_cols(const float* __restrict__ feat, int64_t ldf, int
 __global__ void k_d_coef_init(const float* __restrict__ fe_w, const float* __restrict__ fe_b,
                               const float* __restrict__ le_w, const float* __restrict__ le_b,
                               const float* __restrict__ pe, const float* __restrict__ Wc, int64_t ldw,
-                              const float* __restrict__ bc, int H, int nf, int nl, int ML, int ds, int du,
+                              const float* __restrict__ bc, int64_t ld_bc, int H, int nf, int nl, int ML, int ds, int du,
                               float* __restrict__ x0, float* __restrict__ e) {
     const int H2 = 2 * H;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,7 +215,7 @@ __global__ void k_d_coef_init(const float* __restrict__ fe_w, const float* __res
     if (r < nf) { if (c < H) xv = fe_w[c * nf + r]; }
     else if (r < nf + ML) { if (c < H) xv = pe[(r - nf) * H + c]; }
     else if (r < rb) ev = Wc[(int64_t)c * ldw + 2 * H2 + (r - nf - ML)];
-    else if (r == rb) { xv = c < H ? fe_b[c] : le_b[c - H]; ev = bc[c]; }
+    else if (r == rb) { xv = c < H ? fe_b[c] : le_b[c - H]; ev = bc[(int64_t)c * ld_bc]; }
     else if (r >= ds && r < ds + nl) { if (c >= H) xv = le_w[(c - H) * nl + (r - ds)]; }
     x0[t] = xv;
     e[t] = ev;
@@ -226,7 +226,8 @@ __global__ void k_d_coef_init(const float* __restrict__ fe_w, const float* __res
 __global__ void k_d_coef_init_bwd(const float* __restrict__ G, int64_t slab, int L, int H, int nf, int nl, int ML,
                                   int ds, int du, float* __restrict__ g_fe_w, float* __restrict__ g_fe_b,
                                   float* __restrict__ g_le_w, float* __restrict__ g_le_b,
-                                  float* __restrict__ gw_tail, int64_t ldw, float* __restrict__ g_bc) {
+                                  float* __restrict__ gw_tail, int64_t ldw, float* __restrict__ g_bc, int64_t ld_gbc,
+                                  int zero_pad) {
     const int H2 = 2 * H;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= du * H2) return;
@@ -240,8 +241,43 @@ __global__ void k_d_coef_init_bwd(const float* __restrict__ G, int64_t slab, int
         float s = 0.f;
         for (int m = 1; m <= L; ++m) s = __fadd_rn(s, G[(int64_t)m * slab + t]);
         if (r < rb) gw_tail[(int64_t)c * ldw + (r - nf - ML)] = s;
-        else g_bc[c] = s;
+        else {
+            g_bc[(int64_t)c * ld_gbc] = s;
+            if (zero_pad) {                          // columns 5..7 after the position block: the pad of a [.., 4H+8] row
+                float* q = gw_tail + (int64_t)c * ldw;
+                q[5] = 0.f; q[6] = 0.f; q[7] = 0.f;
+            }
+        }
     }
+}
+
+// models.VoxelBlock.compose for the discriminator's block (no story terms), P = 2 H2 + 8 columns per row:
+//   wm_ext [H2, P] = [Wm | 0 | bm | 0 0 0]   (second operand of the product Wu2 wm_ext)
+//   r      [H2, P] = [Wu1 | 0 .. | bu at column 2 H2 + 4 | 0 0 0]   (what the product's epilogue adds)
+// so that  Wu2 wm_ext + r = [Wc (2 H2 + 4 columns) | bc | 0 0 0].
+__global__ void k_d_compose_prep(const float* __restrict__ Wm, int64_t ldwm, const float* __restrict__ bm,
+                                 const float* __restrict__ Wu, int64_t ldwu, const float* __restrict__ bu, int H2,
+                                 float* __restrict__ wm_ext, float* __restrict__ r) {
+    const int P = 2 * H2 + 8;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)H2 * P) return;
+    const int o = (int)(t / P), c = (int)(t % P);
+    wm_ext[t] = c < 2 * H2 + 3 ? Wm[(int64_t)o * ldwm + c] : (c == 2 * H2 + 4 ? bm[o] : 0.f);
+    r[t] = c < H2 ? Wu[(int64_t)o * ldwu + c] : (c == 2 * H2 + 4 ? bu[o] : 0.f);
+}
+
+// Its backward's last step: gp [H2, P] = d / d [Wc | bc | pad], gwm_ext [H2, P] = Wu2^T gp  ->  the parameters' gradients
+// (g_Wu's second half is written by the product gp wm_ext^T itself).
+__global__ void k_d_compose_bwd_finish(const float* __restrict__ gp, const float* __restrict__ gwm_ext, int H2,
+                                       float* __restrict__ g_Wm, float* __restrict__ g_bm, float* __restrict__ g_Wu,
+                                       float* __restrict__ g_bu) {
+    const int P = 2 * H2 + 8;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)H2 * P) return;
+    const int o = (int)(t / P), c = (int)(t % P);
+    if (c < 2 * H2 + 3) g_Wm[(int64_t)o * (2 * H2 + 3) + c] = gwm_ext[t];
+    if (c < H2) g_Wu[(int64_t)o * (2 * H2) + c] = gp[t];
+    if (c == 2 * H2 + 4) { g_bm[o] = gwm_ext[t]; g_bu[o] = gp[t]; }
 }
 
 // Multiplication by x in the Chebyshev basis, on a table of K row blocks of `blk4` float4 each (block j = the
@@ -508,15 +544,45 @@ int bg_d_static_cols_f32(const float* feat, int64_t ldf, int64_t nf, const int32
     return BG_OK;
 }
 
-int bg_d_coef_init_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b, const float* pe,
-                       const float* Wc, int64_t ldw, const float* bc, int64_t H, int64_t nf, int64_t nl, int64_t ML,
-                       int64_t ds, int64_t dl, float* x0, float* e, bgStream stream) {
-    if (H <= 0 || nf < 0 || nl < 0 || ML < 0 || ds < nf + ML + 5 || dl < nl || ldw < 4 * H + 4) return BG_ERR_ARG;
+int bg_d_coef_init_strided_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b,
+                               const float* pe, const float* Wc, int64_t ldw, const float* bc, int64_t ld_bc, int64_t H,
+                               int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, float* x0, float* e,
+                               bgStream stream) {
+    if (H <= 0 || nf < 0 || nl < 0 || ML < 0 || ds < nf + ML + 5 || dl < nl || ldw < 4 * H + 4 || ld_bc < 1) return BG_ERR_ARG;
     if (!fe_w || !fe_b || !le_w || !le_b || !pe || !Wc || !bc || !x0 || !e) return BG_ERR_ARG;
     const int64_t n = (ds + dl) * 2 * H;
     if (n > 0x7fffffff) return BG_ERR_SHAPE;
     k_d_coef_init<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
-        fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, (int)H, (int)nf, (int)nl, (int)ML, (int)ds, (int)(ds + dl), x0, e);
+        fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, ld_bc, (int)H, (int)nf, (int)nl, (int)ML, (int)ds, (int)(ds + dl), x0, e);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_d_coef_init_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b, const float* pe,
+                       const float* Wc, int64_t ldw, const float* bc, int64_t H, int64_t nf, int64_t nl, int64_t ML,
+                       int64_t ds, int64_t dl, float* x0, float* e, bgStream stream) {
+    return bg_d_coef_init_strided_f32(fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, 1, H, nf, nl, ML, ds, dl, x0, e, stream);
+}
+
+int bg_d_compose_prep_f32(const float* Wm, int64_t ldwm, const float* bm, const float* Wu, int64_t ldwu, const float* bu,
+                          int64_t H2, float* wm_ext, float* r, bgStream stream) {
+    if (H2 <= 0 || ldwm < 2 * H2 + 3 || ldwu < 2 * H2) return BG_ERR_ARG;
+    if (!Wm || !bm || !Wu || !bu || !wm_ext || !r) return BG_ERR_ARG;
+    const int64_t n = H2 * (2 * H2 + 8);
+    if (n > 0x7fffffff) return BG_ERR_SHAPE;
+    k_d_compose_prep<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(Wm, ldwm, bm, Wu, ldwu, bu, (int)H2,
+                                                                                       wm_ext, r);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_d_compose_bwd_finish_f32(const float* gp, const float* gwm_ext, int64_t H2, float* g_Wm, float* g_bm, float* g_Wu,
+                                float* g_bu, bgStream stream) {
+    if (H2 <= 0 || !gp || !gwm_ext || !g_Wm || !g_bm || !g_Wu || !g_bu) return BG_ERR_ARG;
+    const int64_t n = H2 * (2 * H2 + 8);
+    if (n > 0x7fffffff) return BG_ERR_SHAPE;
+    k_d_compose_bwd_finish<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(gp, gwm_ext, (int)H2, g_Wm, g_bm,
+                                                                                             g_Wu, g_bu);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }
@@ -564,18 +630,27 @@ int bg_cheb_shift_slabs_f32(const float* x, float* out, int64_t n_blocks, int64_
     return BG_OK;
 }
 
-int bg_d_coef_init_bwd_f32(const float* G, int64_t slab, int64_t L, int64_t H, int64_t nf, int64_t nl, int64_t ML,
-                           int64_t ds, int64_t dl, float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b,
-                           float* gw_tail, int64_t ldw, float* g_bc, bgStream stream) {
-    if (H <= 0 || L < 0 || nf < 0 || nl < 0 || ML < 0 || ds < nf + ML + 5 || dl < nl || ldw < 4) return BG_ERR_ARG;
+int bg_d_coef_init_bwd_strided_f32(const float* G, int64_t slab, int64_t L, int64_t H, int64_t nf, int64_t nl, int64_t ML,
+                                   int64_t ds, int64_t dl, float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b,
+                                   float* gw_tail, int64_t ldw, float* g_bc, int64_t ld_gbc, int32_t zero_pad,
+                                   bgStream stream) {
+    if (H <= 0 || L < 0 || nf < 0 || nl < 0 || ML < 0 || ds < nf + ML + 5 || dl < nl || ldw < (zero_pad ? 8 : 4) || ld_gbc < 1)
+        return BG_ERR_ARG;
     if (!G || !g_fe_w || !g_fe_b || !g_le_w || !g_le_b || !gw_tail || !g_bc) return BG_ERR_ARG;
     const int64_t n = (ds + dl) * 2 * H;
     if (n > 0x7fffffff || slab < n) return BG_ERR_SHAPE;
     k_d_coef_init_bwd<<<bg_grid_for(n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
         G, slab, (int)L, (int)H, (int)nf, (int)nl, (int)ML, (int)ds, (int)(ds + dl), g_fe_w, g_fe_b, g_le_w, g_le_b,
-        gw_tail, ldw, g_bc);
+        gw_tail, ldw, g_bc, ld_gbc, zero_pad ? 1 : 0);
     BG_LAUNCH_CHECK();
     return BG_OK;
+}
+
+int bg_d_coef_init_bwd_f32(const float* G, int64_t slab, int64_t L, int64_t H, int64_t nf, int64_t nl, int64_t ML,
+                           int64_t ds, int64_t dl, float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b,
+                           float* gw_tail, int64_t ldw, float* g_bc, bgStream stream) {
+    return bg_d_coef_init_bwd_strided_f32(G, slab, L, H, nf, nl, ML, ds, dl, g_fe_w, g_fe_b, g_le_w, g_le_b, gw_tail, ldw,
+                                          g_bc, 1, 0, stream);
 }
 
 }  // extern "C"

@@ -176,10 +176,12 @@ int64_t coef_splits(int64_t M, int64_t R) {          // as ops.gemm_tn_raw: M x 
 }
 }  // namespace
 
-extern "C" int bg_d_coef_forward_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b,
-                                     const float* pe, const float* Wc, int64_t ldw, const float* bc, int64_t H,
-                                     int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L, int32_t basis,
-                                     float* xall, float* efull, bgStream s) {
+namespace {
+// bc / g_bc may be a strided column (ld_bc, ld_gbc) and gW may have any pitch: the composed weights of
+// bg_d_table_* live in [2H, 4H+8] rows [Wc | bc | pad]
+int d_coef_forward_impl(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b, const float* pe,
+                        const float* Wc, int64_t ldw, const float* bc, int64_t ld_bc, int64_t H, int64_t nf, int64_t nl,
+                        int64_t ML, int64_t ds, int64_t dl, int64_t L, int32_t basis, float* xall, float* efull, bgStream s) {
     if (!fe_w || !fe_b || !le_w || !le_b || !pe || !Wc || !bc || !xall || !efull) return BG_ERR_ARG;
     if (H <= 0 || L < 0 || ds < nf + ML + 5 || dl < nl || ldw < 4 * H + 4) return BG_ERR_ARG;
     if (basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB) return BG_ERR_ARG;
@@ -187,7 +189,8 @@ extern "C" int bg_d_coef_forward_f32(const float* fe_w, const float* fe_b, const
     hipStream_t st = (hipStream_t)s;
     BG_HIP(hipMemsetAsync(xall, 0, sizeof(float) * (size_t)((L + 1) * S * H2), st));
     BG_HIP(hipMemsetAsync(efull, 0, sizeof(float) * (size_t)(N * H2), st));
-    BG_TRY(bg_d_coef_init_f32(fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, H, nf, nl, ML, ds, dl, xall + du * H2, efull, s));
+    BG_TRY(bg_d_coef_init_strided_f32(fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, ld_bc, H, nf, nl, ML, ds, dl, xall + du * H2,
+                                      efull, s));
     for (int64_t m = 0; m < L; ++m) {
         const int64_t rows = N < (m + 2) * du ? N : (m + 2) * du;       // blocks above m+1 are still zero
         float* cur = xall + m * S * H2;
@@ -206,19 +209,13 @@ extern "C" int bg_d_coef_forward_f32(const float* fe_w, const float* fe_b, const
     return BG_OK;
 }
 
-extern "C" int64_t bg_d_coef_backward_workspace(int64_t H, int64_t ds, int64_t dl, int64_t L) {
-    if (H <= 0 || ds < 0 || dl < 0 || L < 0) return -1;
-    const int64_t H2 = 2 * H, du = ds + dl, S = (L + 2) * du;
-    return coef_splits(H2, L * S) * H2 * 2 * H2;
-}
-
-extern "C" int bg_d_coef_backward_f32(const float* g, const float* xall, const float* Wc, int64_t ldw,
-                                      int64_t H, int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L,
-                                      int32_t basis, float* shall, float* gall, float* wab, float* partial, float* gW,
-                                      float* g_bc, float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b, bgStream s) {
+int d_coef_backward_impl(const float* g, const float* xall, const float* Wc, int64_t ldw, int64_t H, int64_t nf, int64_t nl,
+                         int64_t ML, int64_t ds, int64_t dl, int64_t L, int32_t basis, float* shall, float* gall, float* wab,
+                         float* partial, float* gW, int64_t ldgw, float* g_bc, int64_t ld_gbc, int32_t zero_pad,
+                         float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b, bgStream s) {
     if (!g || !xall || !Wc || !gall || !wab || !partial || !gW || !g_bc || !g_fe_w || !g_fe_b || !g_le_w || !g_le_b)
         return BG_ERR_ARG;
-    if (H <= 0 || L < 1 || ldw < 4 * H + 4) return BG_ERR_ARG;
+    if (H <= 0 || L < 1 || ldw < 4 * H + 4 || ldgw < 4 * H + 4) return BG_ERR_ARG;
     if ((basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB) || (basis == BG_CHAIN_CHEB && !shall)) return BG_ERR_ARG;
     const int64_t H2 = 2 * H, du = ds + dl, N = (L + 1) * du, S = N + du;
     hipStream_t st = (hipStream_t)s;
@@ -246,10 +243,78 @@ extern "C" int bg_d_coef_backward_f32(const float* g, const float* xall, const f
         BG_TRY(bg_cheb_shift_slabs_f32(xall, shall, L * (L + 2) + 1, L + 2, 1, L + 1, du * H2, 0, s));
     const float* B[4] = {xall + du * H2, basis == BG_CHAIN_CHEB ? shall + du * H2 : xall, nullptr, nullptr};
     const int64_t ldb[4] = {H2, H2, 0, 0}, Ns[4] = {H2, H2, 0, 0};
-    BG_TRY(bg_gemm_tn_splitk_f32(H2, L * S, gall + S * H2, H2, 2, B, ldb, Ns, gW, 2 * H2 + 4, partial,
+    BG_TRY(bg_gemm_tn_splitk_f32(H2, L * S, gall + S * H2, H2, 2, B, ldb, Ns, gW, ldgw, partial,
                                  (int32_t)coef_splits(H2, L * S), 0, s));
-    return bg_d_coef_init_bwd_f32(gall, S * H2, L, H, nf, nl, ML, ds, dl, g_fe_w, g_fe_b, g_le_w, g_le_b, gW + 2 * H2,
-                                  2 * H2 + 4, g_bc, s);
+    return bg_d_coef_init_bwd_strided_f32(gall, S * H2, L, H, nf, nl, ML, ds, dl, g_fe_w, g_fe_b, g_le_w, g_le_b,
+                                          gW + 2 * H2, ldgw, g_bc, ld_gbc, zero_pad, s);
+}
+}  // namespace
+
+extern "C" int bg_d_coef_forward_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b,
+                                     const float* pe, const float* Wc, int64_t ldw, const float* bc, int64_t H,
+                                     int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L, int32_t basis,
+                                     float* xall, float* efull, bgStream s) {
+    return d_coef_forward_impl(fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, 1, H, nf, nl, ML, ds, dl, L, basis, xall, efull, s);
+}
+
+extern "C" int64_t bg_d_coef_backward_workspace(int64_t H, int64_t ds, int64_t dl, int64_t L) {
+    if (H <= 0 || ds < 0 || dl < 0 || L < 0) return -1;
+    const int64_t H2 = 2 * H, du = ds + dl, S = (L + 2) * du;
+    return coef_splits(H2, L * S) * H2 * 2 * H2;
+}
+
+extern "C" int bg_d_coef_backward_f32(const float* g, const float* xall, const float* Wc, int64_t ldw,
+                                      int64_t H, int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L,
+                                      int32_t basis, float* shall, float* gall, float* wab, float* partial, float* gW,
+                                      float* g_bc, float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b, bgStream s) {
+    return d_coef_backward_impl(g, xall, Wc, ldw, H, nf, nl, ML, ds, dl, L, basis, shall, gall, wab, partial, gW,
+                                4 * H + 4, g_bc, 1, 0, g_fe_w, g_fe_b, g_le_w, g_le_b, s);
+}
+
+// The same with the block's composition (models.VoxelBlock.compose) inside: from messageMLP / updateMLP to the table.
+// P = 4H + 8; wm_ext, r, wcb are [2H, P] buffers of the caller (wcb = [Wc | bc | pad] stays for the backward, wm_ext too).
+extern "C" int bg_d_table_forward_f32(const float* Wm, int64_t ldwm, const float* bm, const float* Wu, int64_t ldwu,
+                                      const float* bu, const float* fe_w, const float* fe_b, const float* le_w,
+                                      const float* le_b, const float* pe, int64_t H, int64_t nf, int64_t nl, int64_t ML,
+                                      int64_t ds, int64_t dl, int64_t L, int32_t basis, float* wm_ext, float* r, float* wcb,
+                                      float* xall, float* efull, bgStream s) {
+    if (!Wm || !bm || !Wu || !bu || !wm_ext || !r || !wcb || H <= 0) return BG_ERR_ARG;
+    const int64_t H2 = 2 * H, P = 2 * H2 + 8;
+    BG_TRY(bg_d_compose_prep_f32(Wm, ldwm, bm, Wu, ldwu, bu, H2, wm_ext, r, s));
+    {
+        const float* A[4] = {Wu + H2, nullptr, nullptr, nullptr};       // Wu2
+        const int64_t ld[4] = {ldwu, 0, 0, 0}, Ks[4] = {H2, 0, 0, 0};
+        BG_TRY(bg_gemm_f32(0, 0, H2, P, 1, A, ld, Ks, wm_ext, P, wcb, P, nullptr, nullptr, BG_ACT_NONE, 0.01f, r, P, nullptr, 0,
+                           nullptr, nullptr, 0, nullptr, 0, s));
+    }
+    return d_coef_forward_impl(fe_w, fe_b, le_w, le_b, pe, wcb, P, wcb + 2 * H2 + 4, P, H, nf, nl, ML, ds, dl, L, basis, xall,
+                               efull, s);
+}
+
+// gp, gwm_ext: [2H, P] workspaces.  Writes g_Wm [2H, 4H+3], g_bm, g_Wu [2H, 4H], g_bu and the encoders' gradients.
+extern "C" int bg_d_table_backward_f32(const float* g, const float* xall, const float* wcb, const float* wm_ext,
+                                       const float* Wu, int64_t ldwu, int64_t H, int64_t nf, int64_t nl, int64_t ML,
+                                       int64_t ds, int64_t dl, int64_t L, int32_t basis, float* shall, float* gall,
+                                       float* wab, float* partial, float* gp, float* gwm_ext, float* g_Wm, float* g_bm,
+                                       float* g_Wu, float* g_bu, float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b,
+                                       bgStream s) {
+    if (!wcb || !wm_ext || !Wu || !gp || !gwm_ext || !g_Wm || !g_bm || !g_Wu || !g_bu || H <= 0 || ldwu < 4 * H) return BG_ERR_ARG;
+    const int64_t H2 = 2 * H, P = 2 * H2 + 8;
+    BG_TRY(d_coef_backward_impl(g, xall, wcb, P, H, nf, nl, ML, ds, dl, L, basis, shall, gall, wab, partial, gp, P,
+                                gp + 2 * H2 + 4, P, 1, g_fe_w, g_fe_b, g_le_w, g_le_b, s));
+    {   // d Wu2 = gp wm_ext^T, straight into the second half of g_Wu's rows
+        const float* A[4] = {gp, nullptr, nullptr, nullptr};
+        const int64_t ld[4] = {P, 0, 0, 0}, Ks[4] = {P, 0, 0, 0};
+        BG_TRY(bg_gemm_f32(0, 1, H2, H2, 1, A, ld, Ks, wm_ext, P, g_Wu + H2, 2 * H2, nullptr, nullptr, BG_ACT_NONE, 0.01f,
+                           nullptr, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
+    }
+    {   // d wm_ext = Wu2^T gp
+        const float* A[4] = {Wu + H2, nullptr, nullptr, nullptr};
+        const int64_t ld[4] = {ldwu, 0, 0, 0}, Ks[4] = {H2, 0, 0, 0};
+        BG_TRY(bg_gemm_f32(1, 0, H2, P, 1, A, ld, Ks, gp, P, gwm_ext, P, nullptr, nullptr, BG_ACT_NONE, 0.01f, nullptr, 0,
+                           nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
+    }
+    return bg_d_compose_bwd_finish_f32(gp, gwm_ext, H2, g_Wm, g_bm, g_Wu, g_bu, s);
 }
 
 // ---------------------------------------------------------------- the critic update below the coefficient table

@@ -41,6 +41,7 @@ FUSE_COEF_INPUTS = True   # collapsed discriminator: the recurrence's parameter 
 FUSE_GENERATOR_FORWARD = True   # graph-free Generator.forward as ONE host call (bg_generator_forward_f32)
 FUSE_PSTACK = True        # generator update: ProgramGNN as ONE autograd node, one host call each way (ops.ProgramStack)
 FUSE_GSTACK = True        # generator update: VoxelGNN_G below the program GNN as ONE autograd node, one host call each way (ops.VoxelStackG)
+FUSE_COMPOSE_D = True     # collapsed discriminator: the block's composition inside the coefficient node (ops.PolyCoefDW)
 FUSE_CRITIC_HEAD = True   # WGAN-GP critic update below the coefficient table as ONE host call each way (ops.CriticHead)
 COLLAPSE_D = True      # evaluate the discriminator's (linear) voxel GNN as a polynomial in the aggregation operator
 
@@ -516,10 +517,26 @@ class VoxelGNN_D(nn.Module):
         key = (ds, dl, torch.is_grad_enabled(), ops.D_BASIS)
         if self._share_coef and self._coef_cache is not None and self._coef_cache[0] == key:
             return self._coef_cache[1]
-        W = self._collapsed_weight(self.block.compose(), n_feat, ds, dl)
+        W = self._table_from_parameters(n_feat, ds, dl)
+        if W is None:
+            W = self._collapsed_weight(self.block.compose(), n_feat, ds, dl)
         if self._share_coef:
             self._coef_cache = (key, W)
         return W
+
+    def _table_from_parameters(self, n_feat, ds, dl):
+        """compose() + PolyCoefD as one node (ops.PolyCoefDW), or None where that form does not apply."""
+        blk, fe, le = self.block, self.feature_enc[0], self.label_enc[0]
+        Wm, Wu = blk.messageMLP[0].weight, blk.updateMLP[0].weight
+        H2, L = Wm.shape[0], self.layer_num
+        H = H2 // 2
+        if not (FUSE_COMPOSE_D and FUSE_COEF_INPUTS and ops.FUSE_COEF_RECURRENCE and Wm.is_cuda and L >= 1
+                and not blk.if_agg_story_in_update and Wm.shape[1] == 2 * H2 + 3 and tuple(Wu.shape) == (H2, 2 * H2)
+                and fe.weight.shape == (H, n_feat) and le.weight.shape[0] == H and H2 % 4 == 0):
+            return None
+        XL = ops.PolyCoefDW.apply(Wm, blk.messageMLP[0].bias, Wu, blk.updateMLP[0].bias, fe.weight, fe.bias, le.weight,
+                                  le.bias, self.pe, L, ds, dl)
+        return SpMM.apply(XL, self._coef_row_order(L, ds, dl, XL.device))
 
     def _coef_row_order(self, L, ds, dl, device) -> LinOp:
         key = (L, ds, dl, str(device))

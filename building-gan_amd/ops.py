@@ -1894,3 +1894,73 @@ class PolyCoefD(torch.autograd.Function):
                                          ptr(g_le_w), ptr(g_le_b), gW.data_ptr() + 4 * 2 * H2, 2 * H2 + 4, ptr(g_bc),
                                          stream()), "bg_d_coef_init_bwd_f32")
         return (gW, g_bc, g_fe_w, g_fe_b, g_le_w, g_le_b) + none
+
+
+class PolyCoefDW(torch.autograd.Function):
+    """PolyCoefD with the block's composition (models.VoxelBlock.compose) inside the node: from messageMLP (Wm [2H, 4H+3],
+    bm) and updateMLP (Wu [2H, 4H], bu) to the coefficient table in ONE host call (bg_d_table_forward_f32: prep, one
+    product with a residual = [Wc | bc], the recurrence) and back (bg_d_table_backward_f32) -- instead of five stock
+    launches and autograd nodes forward and seven backward around PolyCoefD.  Same arithmetic as compose() + PolyCoefD."""
+
+    @staticmethod
+    def forward(ctx, Wm, bm, Wu, bu, fe_w, fe_b, le_w, le_b, pe, L: int, ds: int, dl: int, basis=None):
+        lib = _lib.load()
+        _lib.require_device(Wm, "PolyCoefDW")
+        H2 = Wm.shape[0]
+        H, nf, nl, ML = H2 // 2, fe_w.shape[1], le_w.shape[1], pe.shape[0]
+        if (H2 != 2 * H or Wm.shape[1] != 2 * H2 + 3 or tuple(Wu.shape) != (H2, 2 * H2) or fe_w.shape[0] != H
+                or le_w.shape[0] != H or pe.shape[1] != H or ds < nf + ML + 5 or dl < nl or L < 1):
+            raise _lib.BganError("PolyCoefDW: parameter shapes do not fit the collapsed discriminator")
+        basis = D_BASIS if basis is None else basis
+        du, P = ds + dl, 2 * H2 + 8
+        N = (L + 1) * du
+        S = N + du
+        dev = Wm.device
+        Wm2, Wu2 = _f32c(Wm), _f32c(Wu)
+        args = [_f32c(t).contiguous() for t in (bm, bu, fe_w, fe_b, le_w, le_b, pe)]
+        n_x, n_e, n_p = (L + 1) * S * H2, N * H2, H2 * P
+        buf = torch.empty(n_x + n_e + 3 * n_p, dtype=torch.float32, device=dev)
+        Xall = buf[:n_x].view(L + 1, S, H2)
+        Efull = buf[n_x:n_x + n_e]
+        wm_ext, r, wcb = (buf[n_x + n_e + i * n_p:n_x + n_e + (i + 1) * n_p].view(H2, P) for i in range(3))
+        check(lib.bg_d_table_forward_f32(ptr(Wm2), _ld(Wm2), ptr(args[0]), ptr(Wu2), _ld(Wu2), ptr(args[1]), ptr(args[2]),
+                                         ptr(args[3]), ptr(args[4]), ptr(args[5]), ptr(args[6]), H, nf, nl, ML, ds, dl, L,
+                                         basis, ptr(wm_ext), ptr(r), ptr(wcb), ptr(Xall), ptr(Efull), stream()),
+              "bg_d_table_forward_f32")
+        ctx.dims = (L, du, ds, dl, H, nf, nl, ML, basis)
+        ctx.save_for_backward(Xall, wcb, wm_ext, Wu2)
+        return Xall[L, du:]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        Xall, wcb, wm_ext, Wu = ctx.saved_tensors
+        L, du, ds, dl, H, nf, nl, ML, basis = ctx.dims
+        cheb = basis == CHAIN_CHEB
+        H2, P = 2 * H, 4 * H + 8
+        N = (L + 1) * du
+        S = N + du
+        dev = g.device
+        g_Wm = torch.empty(H2, 2 * H2 + 3, dtype=torch.float32, device=dev)
+        g_Wu = torch.empty(H2, 2 * H2, dtype=torch.float32, device=dev)
+        small = torch.empty(4 * H2 + H * (nf + nl), dtype=torch.float32, device=dev)
+        g_bm, g_bu, g_fe_b, g_le_b = small[:H2], small[H2:2 * H2], small[2 * H2:2 * H2 + H], small[2 * H2 + H:3 * H2]
+        g_fe_w = small[3 * H2:3 * H2 + H * nf].view(H, nf)
+        g_le_w = small[3 * H2 + H * nf:3 * H2 + H * (nf + nl)].view(H, nl)
+        g2 = _f32c(g).contiguous()
+        nws = int(lib.bg_d_coef_backward_workspace(H, ds, dl, L))
+        n_g, n_w, n_t, n_p = (L + 1) * S * H2, 2 * H2 * H2, ((L * S + du) * H2 if cheb else 0), H2 * P
+        work = torch.empty(n_g + n_w + n_t + 2 * n_p + nws, dtype=torch.float32, device=dev)
+        o = 0
+        Gall = work[o:o + n_g]; o += n_g
+        Wab = work[o:o + n_w]; o += n_w
+        shall = work[o:o + n_t] if cheb else None; o += n_t
+        gp = work[o:o + n_p]; o += n_p
+        gwm = work[o:o + n_p]; o += n_p
+        partial = work[o:]
+        check(lib.bg_d_table_backward_f32(ptr(g2), ptr(Xall), ptr(wcb), ptr(wm_ext), ptr(Wu), _ld(Wu), H, nf, nl, ML, ds, dl,
+                                          L, basis, ptr(shall), ptr(Gall), ptr(Wab), ptr(partial), ptr(gp), ptr(gwm),
+                                          ptr(g_Wm), ptr(g_bm), ptr(g_Wu), ptr(g_bu), ptr(g_fe_w), ptr(g_fe_b), ptr(g_le_w),
+                                          ptr(g_le_b), stream()), "bg_d_table_backward_f32")
+        return (g_Wm, g_bm, g_Wu, g_bu, g_fe_w, g_fe_b, g_le_w, g_le_b) + (None,) * 5

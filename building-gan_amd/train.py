@@ -57,11 +57,18 @@ class FlatAdam:
         self.t = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
         self.t_host = 0
 
+    def _grad_views(self):
+        """The flat gradient buffer seen through each parameter's shape (made once: three tensor ops per parameter)."""
+        v = self.__dict__.get("_views")
+        if v is None:
+            v = self._views = [self.grad[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
+        return v
+
     def zero_grad(self):
         self.grad.zero_()
-        for p, off in zip(self.params, self.offsets):   # autograd may have replaced .grad; re-attach the views
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
-                p.grad = self.grad[off:off + p.numel()].view_as(p)
+        for p, view in zip(self.params, self._grad_views()):   # autograd may have replaced .grad; re-attach the views
+            if p.grad is not view:
+                p.grad = view
 
     def detach_grads(self):
         """Before a backward pass whose gradients ``collect`` will gather: with ``.grad`` unset autograd hands
@@ -74,20 +81,27 @@ class FlatAdam:
         """All parameter gradients into the flat buffer by ONE concatenation (pads and parameters without a
         gradient read a cached zero block); ``.grad`` is a view of the flat buffer again afterwards."""
         dev = self.grad.device
+        pads = self.__dict__.get("_pads")
+        if pads is None:          # zero blocks between / after the parameters, and one per parameter without a gradient
+            pads, end = [], 0
+            for p, off in zip(self.params, self.offsets):
+                pads.append((ops.zeros_view(off - end, device=dev) if off > end else None,
+                             ops.zeros_view(p.numel(), device=dev)))
+                end = off + p.numel()
+            self._pads = pads
+            self._tail = ops.zeros_view(self.grad.numel() - end, device=dev) if self.grad.numel() > end else None
         pieces = []
-        end = 0
-        for p, off in zip(self.params, self.offsets):
-            if off > end:
-                pieces.append(ops.zeros_view(off - end, device=dev))
+        for p, (gap, zero) in zip(self.params, pads):
+            if gap is not None:
+                pieces.append(gap)
             g = p.grad
-            pieces.append(g.detach().reshape(-1) if g is not None else ops.zeros_view(p.numel(), device=dev))
-            end = off + p.numel()
-        if self.grad.numel() > end:
-            pieces.append(ops.zeros_view(self.grad.numel() - end, device=dev))
+            pieces.append(zero if g is None else (g.detach() if g.requires_grad else g).reshape(-1))
+        if self._tail is not None:
+            pieces.append(self._tail)
         with torch.no_grad():
             torch.cat(pieces, out=self.grad)
-        for p, off in zip(self.params, self.offsets):
-            p.grad = self.grad[off:off + p.numel()].view_as(p)
+        for p, view in zip(self.params, self._grad_views()):
+            p.grad = view
 
     def all_reduce(self, group=None):
         if _world(group) > 1:

@@ -409,9 +409,30 @@ int bg_gemm_cheb_f32(int transB, int64_t M, int64_t N, const float* X, int64_t l
                      int64_t n_blocks, int transpose, const float* B, int64_t ldb, float* C, int64_t ldc,
                      const float* residual, int64_t ldr, const float* pre_add, int64_t ldp, bgStream stream);
 
+/* bg_d_coef_init_f32 with bc read at a stride (bc[c * ld_bc]): the bias as a column of a wider matrix.            */
+int bg_d_coef_init_strided_f32(const float* fe_w, const float* fe_b, const float* le_w, const float* le_b,
+                               const float* pe, const float* Wc, int64_t ldw, const float* bc, int64_t ld_bc, int64_t H,
+                               int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, float* x0, float* e,
+                               bgStream stream);
+
+/* The two elementwise ends of models.VoxelBlock.compose for the discriminator's block (H2 = 2H, P = 2 H2 + 8):
+ * prep:   wm_ext [H2, P] = [Wm | 0 | bm | 0 0 0],  r [H2, P] = [Wu1 | 0 .. | bu at column 2 H2 + 4 | 0 0 0], so that
+ *         Wu2 wm_ext + r = [Wc | bc | 0 0 0] is ONE product with a residual;
+ * finish: from gp = d / d [Wc | bc | pad] and gwm_ext = Wu2^T gp: g_Wm [H2, 2 H2 + 3], g_bm, the first half of g_Wu's
+ *         rows ([H2, 2 H2]), g_bu.
+ * replaces: the cat / split / add launches of the composition (Model/models.py:149-150 hold the two Linears).     */
+int bg_d_compose_prep_f32(const float* Wm, int64_t ldwm, const float* bm, const float* Wu, int64_t ldwu, const float* bu,
+                          int64_t H2, float* wm_ext, float* r, bgStream stream);
+int bg_d_compose_bwd_finish_f32(const float* gp, const float* gwm_ext, int64_t H2, float* g_Wm, float* g_bm, float* g_Wu,
+                                float* g_bu, bgStream stream);
+
 /* Backward of bg_d_coef_init_f32: G = L+1 slabs (pitch `slab` floats) of gradient states [.., 2H]; rows [0, du)
  * of slab 0 are d/d x0, the sum over slabs 1..L of rows [0, du) is d/d e.  Writes the gradients of fe_w, fe_b,
  * le_w, le_b (contiguous), of Wc's position block (gw_tail = &gWc[0, 4H], pitch ldw) and of bc.           */
+int bg_d_coef_init_bwd_strided_f32(const float* G, int64_t slab, int64_t L, int64_t H, int64_t nf, int64_t nl, int64_t ML,
+                                   int64_t ds, int64_t dl, float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b,
+                                   float* gw_tail, int64_t ldw, float* g_bc, int64_t ld_gbc, int32_t zero_pad,
+                                   bgStream stream);   /* g_bc at a stride; zero_pad: also clear gw_tail[c, 5..7] */
 int bg_d_coef_init_bwd_f32(const float* G, int64_t slab, int64_t L, int64_t H, int64_t nf, int64_t nl, int64_t ML,
                            int64_t ds, int64_t dl, float* g_fe_w, float* g_fe_b, float* g_le_w, float* g_le_b,
                            float* gw_tail, int64_t ldw, float* g_bc, bgStream stream);
@@ -572,6 +593,22 @@ int bg_d_coef_backward_f32(const float* g, const float* xall, const float* Wc, i
                            float* shall, float* gall, float* wab,
                            float* partial, float* gW, float* g_bc, float* g_fe_w, float* g_fe_b, float* g_le_w,
                            float* g_le_b, bgStream stream);
+
+/* bg_d_coef_* with the block's composition (models.VoxelBlock.compose: Wc = [Wu1 + Wu2 Wm1 | Wu2 Wm2 | Wu2 Wm3],
+ * bc = Wu2 bm + bu) inside: from messageMLP (Wm [2H, 4H+3], bm) and updateMLP (Wu [2H, 4H], bu) to the coefficient table and
+ * back to their gradients.  P = 4H + 8; wm_ext, r, wcb (forward; wm_ext and wcb = [Wc | bc | pad] are read again by the
+ * backward), gp, gwm_ext (backward) are [2H, P] buffers of the caller.  Forward: 2 launches + bg_d_coef_forward_f32's;
+ * backward: bg_d_coef_backward_f32's + 3.  g_Wm [2H, 4H+3], g_bm [2H], g_Wu [2H, 4H], g_bu [2H] are written completely.
+ * replaces: the eleven small stock launches (cat / add / split and their backward) around the recurrence.        */
+int bg_d_table_forward_f32(const float* Wm, int64_t ldwm, const float* bm, const float* Wu, int64_t ldwu, const float* bu,
+                           const float* fe_w, const float* fe_b, const float* le_w, const float* le_b, const float* pe,
+                           int64_t H, int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L, int32_t basis,
+                           float* wm_ext, float* r, float* wcb, float* xall, float* efull, bgStream stream);
+int bg_d_table_backward_f32(const float* g, const float* xall, const float* wcb, const float* wm_ext, const float* Wu,
+                            int64_t ldwu, int64_t H, int64_t nf, int64_t nl, int64_t ML, int64_t ds, int64_t dl, int64_t L,
+                            int32_t basis, float* shall, float* gall, float* wab, float* partial, float* gp, float* gwm_ext,
+                            float* g_Wm, float* g_bm, float* g_Wu, float* g_bu, float* g_fe_w, float* g_fe_b, float* g_le_w,
+                            float* g_le_b, bgStream stream);
 
 /* ---- the generator's voxel GNN with a backward: forward that keeps what the backward reads, and the backward ----
  * Plan pieces only the backward reads (besides bgGeneratorPlan).                                                  */

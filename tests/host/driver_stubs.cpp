@@ -71,16 +71,30 @@ int bg_attention_fwd_f32(const float* a_, int64_t lda, const float* logits, int6
     rec(5, a, sizeof(a) / 8);
     return 0;
 }
-int bg_d_coef_init_f32(const float*, const float*, const float*, const float*, const float*, const float*, int64_t,
-                       const float*, int64_t H, int64_t, int64_t, int64_t, int64_t ds, int64_t dl, float* x0, float* e, bgStream) {
-    int64_t a[] = {P(x0), P(e), (ds + dl) * 2 * H};
+int bg_d_coef_init_strided_f32(const float*, const float*, const float*, const float*, const float*, const float* Wc,
+                               int64_t ldw, const float* bc, int64_t ld_bc, int64_t H, int64_t, int64_t, int64_t, int64_t ds,
+                               int64_t dl, float* x0, float* e, bgStream) {
+    int64_t a[] = {P(x0), P(e), (ds + dl) * 2 * H, P(Wc), ldw, P(bc), ld_bc};
     rec(30, a, sizeof(a) / 8);
     return 0;
 }
-int bg_d_coef_init_bwd_f32(const float* G, int64_t slab, int64_t L, int64_t H, int64_t, int64_t, int64_t, int64_t ds,
-                           int64_t dl, float*, float*, float*, float*, float* gw_tail, int64_t ldw, float*, bgStream) {
-    int64_t a[] = {P(G), slab, L, (ds + dl) * 2 * H, P(gw_tail), ldw};
+int bg_d_coef_init_bwd_strided_f32(const float* G, int64_t slab, int64_t L, int64_t H, int64_t, int64_t, int64_t, int64_t ds,
+                                   int64_t dl, float*, float*, float*, float*, float* gw_tail, int64_t ldw, float* g_bc,
+                                   int64_t ld_gbc, int32_t zero_pad, bgStream) {
+    int64_t a[] = {P(G), slab, L, (ds + dl) * 2 * H, P(gw_tail), ldw, P(g_bc), ld_gbc, zero_pad};
     rec(31, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_d_compose_prep_f32(const float* Wm, int64_t ldwm, const float* bm, const float* Wu, int64_t ldwu, const float* bu,
+                          int64_t H2, float* wm_ext, float* r, bgStream) {
+    int64_t a[] = {P(Wm), ldwm, P(bm), P(Wu), ldwu, P(bu), H2, P(wm_ext), P(r)};
+    rec(35, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_d_compose_bwd_finish_f32(const float* gp, const float* gwm_ext, int64_t H2, float* g_Wm, float* g_bm, float* g_Wu,
+                                float* g_bu, bgStream) {
+    int64_t a[] = {P(gp), P(gwm_ext), H2, P(g_Wm), P(g_bm), P(g_Wu), P(g_bu)};
+    rec(36, a, sizeof(a) / 8);
     return 0;
 }
 // device-to-device copies of the coefficient composites

@@ -993,3 +993,71 @@ def test_d_coef_host_sequence_and_extents(drv, basis, L):
     if basis:        # the Chebyshev form without its workspace is refused, not run
         assert drv.bg_d_coef_backward_f32(g, xall, Wc, ldw, H, nf, nl, ML, ds, dl, L, 1, None, gall, wab, partial, gW,
                                           *outs, None) != 0
+
+
+@pytest.mark.parametrize("basis", [0, 1])
+def test_d_table_host_sequence_and_extents(drv, basis):
+    """bg_d_table_forward_f32 / _backward_f32: the composition's two launches before and three after the recurrence's own
+    sequence; the composed weights reach the recurrence as [Wc | bc | pad] rows of 4H+8 floats (bc as a strided column),
+    the backward's gradient of them is assembled in the same layout (pad cleared) and every operand stays in its buffer."""
+    f, H, nf, nl, ML, ds, dl, L = 4, 128, 4, 6, 20, 32, 8, 12
+    H2, du = 2 * H, ds + dl
+    P = 2 * H2 + 8
+    N = (L + 1) * du
+    S = N + du
+    R = Ranges()
+    Wm, bm, Wu, bu = R.new("Wm", H2 * (2 * H2 + 3) * f), R.new("bm", H2 * f), R.new("Wu", H2 * 2 * H2 * f), R.new("bu", H2 * f)
+    par = [R.new(n, b * f) for n, b in (("fe_w", H * nf), ("fe_b", H), ("le_w", H * nl), ("le_b", H), ("pe", ML * H))]
+    wm_ext, r, wcb = R.new("wm_ext", H2 * P * f), R.new("r", H2 * P * f), R.new("wcb", H2 * P * f)
+    xall, efull = R.new("xall", (L + 1) * S * H2 * f), R.new("efull", N * H2 * f)
+    drv.bg_d_table_forward_f32.argtypes = ([C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 6
+                                           + [C.c_int64] * 7 + [C.c_int32] + [C.c_void_p] * 6)
+
+    def calls_of(fn, *args):
+        drv.stub_reset()
+        rc = fn(*args)
+        return rc, [(drv.stub_call(i)[0], [drv.stub_call(i)[2 + k] for k in range(drv.stub_call(i)[1])])
+                    for i in range(drv.stub_count())]
+    rc, fwd = calls_of(drv.bg_d_table_forward_f32, Wm, 2 * H2 + 3, bm, Wu, 2 * H2, bu, *par, H, nf, nl, ML, ds, dl, L, basis,
+                       wm_ext, r, wcb, xall, efull, None)
+    assert rc == 0
+    assert [k for k, _ in fwd] == [35, 1, 25, 25, 30] + [32 if basis else 1] * L
+    prep = fwd[0][1]
+    assert prep == [Wm, 2 * H2 + 3, bm, Wu, 2 * H2, bu, H2, wm_ext, r]
+    g0 = fwd[1][1]
+    (tA, tB, M, Nn, n_seg), A, lda, Ks = g0[0:5], g0[5:9], g0[9:13], g0[13:17]
+    assert (tA, tB, M, Nn, n_seg, Ks[0], lda[0]) == (0, 0, H2, P, 1, H2, 2 * H2) and A[0] == Wu + H2 * f       # Wu2
+    assert g0[17] == wm_ext and g0[18] == P and g0[19] == wcb and g0[20] == P and g0[24] == r and g0[25] == P
+    R.check(A[0], ((M - 1) * lda[0] + Ks[0]) * f, "Wu2")
+    init = [a for k, a in fwd if k == 30][0]
+    assert init[3] == wcb and init[4] == P and init[5] == wcb + (2 * H2 + 4) * f and init[6] == P
+    for k, a in fwd:
+        if k == 32:
+            assert a[9] == wcb and a[10] == P                                    # the recurrence multiplies by [Wc | ..] rows
+        elif k == 1 and a is not g0:
+            assert a[17] == wcb and a[18] == P
+    # ---- backward
+    drv.bg_d_coef_backward_workspace.restype = C.c_int64
+    drv.bg_d_coef_backward_workspace.argtypes = [C.c_int64] * 4
+    nws = drv.bg_d_coef_backward_workspace(H, ds, dl, L)
+    g, gall, wab = R.new("g", N * H2 * f), R.new("gall", (L + 1) * S * H2 * f), R.new("wab", 2 * H2 * H2 * f)
+    shall = R.new("shall", (L * S + du) * H2 * f) if basis else None
+    partial, gp, gwm = R.new("partial", nws * f), R.new("gp", H2 * P * f), R.new("gwm", H2 * P * f)
+    outs = [R.new(n, b * f) for n, b in (("g_Wm", H2 * (2 * H2 + 3)), ("g_bm", H2), ("g_Wu", H2 * 2 * H2), ("g_bu", H2),
+                                         ("g_fe_w", H * nf), ("g_fe_b", H), ("g_le_w", H * nl), ("g_le_b", H))]
+    drv.bg_d_table_backward_f32.argtypes = [C.c_void_p] * 5 + [C.c_int64] * 8 + [C.c_int32] + [C.c_void_p] * 15
+    rc, bwd = calls_of(drv.bg_d_table_backward_f32, g, xall, wcb, wm_ext, Wu, 2 * H2, H, nf, nl, ML, ds, dl, L, basis, shall,
+                       gall, wab, partial, gp, gwm, *outs, None)
+    assert rc == 0
+    assert [k for k, _ in bwd] == [25, 20, 20, 20] + [32 if basis else 1] * L + ([33] if basis else []) + [19, 31, 1, 1, 36]
+    tn = [a for k, a in bwd if k == 19][0]
+    assert tn[8] == gp and tn[9] == P                                            # d [Wa | Wb] at the composed rows' pitch
+    ib = [a for k, a in bwd if k == 31][0]
+    assert ib[4] == gp + 2 * H2 * f and ib[5] == P and ib[6] == gp + (2 * H2 + 4) * f and ib[7] == P and ib[8] == 1
+    copies = [a for k, a in bwd if k == 20]
+    assert copies[1][2] == wcb and copies[1][3] == P * f and copies[2][2] == wcb + H2 * f      # Wab from the composed rows
+    m1, m2 = [a for k, a in bwd if k == 1][-2:]
+    assert (m1[0], m1[1], m1[2], m1[3]) == (0, 1, H2, H2) and m1[5] == gp and m1[13] == P and m1[17] == wm_ext
+    assert m1[19] == outs[2] + H2 * f and m1[20] == 2 * H2                        # second half of g_Wu's rows
+    assert (m2[0], m2[1], m2[2], m2[3]) == (1, 0, H2, P) and m2[5] == Wu + H2 * f and m2[17] == gp and m2[19] == gwm
+    assert bwd[-1][1] == [gp, gwm, H2, outs[0], outs[1], outs[2], outs[3]]

@@ -939,13 +939,14 @@ def test_shared_weight_gradient_buffers_fail_loudly_on_partial_backward(cuda):
         loss.backward()                                        # the first call is cut off from the loss
 
 
-def test_coefficient_inputs_by_one_launch_equal_cat_construction(cuda, d_basis):
+def test_coefficient_inputs_by_one_launch_equal_cat_construction(cuda, d_basis, monkeypatch):
     """ops.PolyCoefD (X0 / E written into the recurrence's buffers by bg_d_coef_init_f32, parameter gradients
     read out by bg_d_coef_init_bwd_f32) against the cat / transpose construction feeding ops.PolyCoef: the
     collapsed weight bit for bit, every discriminator gradient to fp32 rounding (the sum over the layers'
     slabs runs in a different order)."""
     from building_gan_amd import models as hm
     cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 54, True, cuda)
+    monkeypatch.setattr(hm, "FUSE_COMPOSE_D", False)
     res = {}
     for fused in (True, False):
         hm.FUSE_COEF_INPUTS = fused
@@ -968,12 +969,13 @@ def test_coefficient_inputs_by_one_launch_equal_cat_construction(cuda, d_basis):
         assert float((a - r).abs().max()) <= 2e-5 * scale, n
 
 
-def test_coefficient_recurrence_in_one_host_call_equals_separate_launches(cuda, d_basis):
+def test_coefficient_recurrence_in_one_host_call_equals_separate_launches(cuda, d_basis, monkeypatch):
     """ops.FUSE_COEF_RECURRENCE (bg_d_coef_forward_f32 / bg_d_coef_backward_f32: the recurrence's launches issued by
     one C call each way) against the same launches issued one by one from the host: the collapsed weight, the
     critic's outputs and every discriminator gradient bit for bit."""
-    from building_gan_amd import ops
+    from building_gan_amd import models as hm, ops
     cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 58, True, cuda)
+    monkeypatch.setattr(hm, "FUSE_COMPOSE_D", False)      # (its own test: test_block_composition_inside_the_coefficient_node)
     res = {}
     for fused in (True, False):
         ops.FUSE_COEF_RECURRENCE = fused
@@ -990,6 +992,36 @@ def test_coefficient_recurrence_in_one_host_call_equals_separate_launches(cuda, 
     names = ["W", "b", "s", "dlabel"] + [n for n, _ in Dh.named_parameters()]
     for n, a, r in zip(names, res[True], res[False]):
         assert torch.equal(a, r), n
+
+
+def test_block_composition_inside_the_coefficient_node(cuda, d_basis):
+    """models.FUSE_COMPOSE_D (ops.PolyCoefDW: compose() and the recurrence as one node, bg_d_table_forward_f32 /
+    _backward_f32) against compose() under autograd feeding ops.PolyCoefD: the table and the critic's outputs bit for bit,
+    every discriminator gradient to fp32 rounding."""
+    from building_gan_amd import models as hm
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup("small", 59, True, cuda)
+    res = {}
+    for fused in (True, False):
+        hm.FUSE_COMPOSE_D = fused
+        try:
+            for p in Dh.parameters():
+                p.grad = None
+            W = Dh.voxelGNN_D.coefficients(gpu.voxel_feature.shape[1] - 3, 32, 8)
+            lab = gpu.voxel_label.clone().requires_grad_(True)
+            b, s = Dh(gpu, lab)
+            (b.sum() + 2 * s.sum()).backward()
+            res[fused] = [W.detach().clone(), b.detach(), s.detach(), lab.grad] + [p.grad.clone() for p in Dh.parameters()]
+        finally:
+            hm.FUSE_COMPOSE_D = True
+    names = ["W", "b", "s", "dlabel"] + [n for n, _ in Dh.named_parameters()]
+    for n, a, r in zip(names[:4], res[True], res[False]):
+        assert torch.equal(a, r), n
+    worst = 0.0
+    for n, a, r in zip(names[4:], res[True][4:], res[False][4:]):
+        e = float((a - r).abs().max()) / (float(r.abs().max()) + 1e-12)
+        worst = max(worst, e)
+        assert e <= 2e-6, (n, e)
+    print("composition inside the node vs compose() under autograd: worst gradient difference %.1e" % worst)
 
 
 def test_attention_backward_head_one_launch_equals_separate_launches(cuda):
