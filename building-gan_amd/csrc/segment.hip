@@ -516,7 +516,10 @@ __device__ __forceinline__ void story_project_body(const float* __restrict__ x, 
                                                    const float* __restrict__ W, int64_t ldw, int Hout,
                                                    float* __restrict__ out, int64_t ldo, int H, int64_t row) {
     __shared__ float4 part[1024];
-    __shared__ float mean[256];
+    // the story mean, 4 pad floats after every 16: the projection's P lane groups read segments H / P apart, which without
+    // the skew start on one bank (P-way conflict on every read: SQ_LDS_BANK_CONFLICT was 67 % of this kernel's LDS cycles)
+    __shared__ __attribute__((aligned(16))) float mean[256 + 64];
+    auto mi = [](int h) { return h + 4 * (h >> 4); };
     const int nt = blockDim.x;                  // 256 or 1024 threads (a power of two)
     const int H4 = H / 4;                       // <= 64 lanes per slot row
     int lpr = 1;
@@ -548,8 +551,7 @@ __device__ __forceinline__ void story_project_body(const float* __restrict__ x, 
     }
     if (grp == 0 && sub < H4) {
         const float c = count[row];
-        mean[4 * sub + 0] = acc.x / c; mean[4 * sub + 1] = acc.y / c;
-        mean[4 * sub + 2] = acc.z / c; mean[4 * sub + 3] = acc.w / c;
+        *reinterpret_cast<float4*>(mean + mi(4 * sub)) = make_float4(acc.x / c, acc.y / c, acc.z / c, acc.w / c);
     }
     __syncthreads();
     // projection: P = nt / (2 Hout) adjacent lanes share one output, each over a contiguous quarter (..) of H
@@ -557,12 +559,12 @@ __device__ __forceinline__ void story_project_body(const float* __restrict__ x, 
     if (P >= 2 && (P & (P - 1)) == 0 && P <= 8 && P * 2 * Hout == nt && H % (4 * P) == 0) {
         const int o = threadIdx.x / P, pp = threadIdx.x % P, hs = H / P;
         const float* w = W + (int64_t)(o < Hout ? o : o - Hout) * ldw + (o < Hout ? 0 : H) + pp * hs;
-        const float* mv = mean + pp * hs;
         float d = 0.f;
         for (int h = 0; h < hs; h += 4) {
             const float4 wv = bg_ld4(w + h);
-            d = fmaf(wv.x, mv[h], d); d = fmaf(wv.y, mv[h + 1], d);
-            d = fmaf(wv.z, mv[h + 2], d); d = fmaf(wv.w, mv[h + 3], d);
+            const float4 mv = *reinterpret_cast<const float4*>(mean + mi(pp * hs + h));
+            d = fmaf(wv.x, mv.x, d); d = fmaf(wv.y, mv.y, d);
+            d = fmaf(wv.z, mv.z, d); d = fmaf(wv.w, mv.w, d);
         }
         for (int off = 1; off < P; off <<= 1) d += __shfl_xor(d, off, 64);
         if (pp == 0) out[row * ldo + o] = d;
@@ -573,8 +575,9 @@ __device__ __forceinline__ void story_project_body(const float* __restrict__ x, 
         float d = 0.f;
         for (int h = 0; h < H; h += 4) {
             const float4 wv = bg_ld4(w + h);
-            d = fmaf(wv.x, mean[h], d); d = fmaf(wv.y, mean[h + 1], d);
-            d = fmaf(wv.z, mean[h + 2], d); d = fmaf(wv.w, mean[h + 3], d);
+            const float4 mv = *reinterpret_cast<const float4*>(mean + mi(h));
+            d = fmaf(wv.x, mv.x, d); d = fmaf(wv.y, mv.y, d);
+            d = fmaf(wv.z, mv.z, d); d = fmaf(wv.w, mv.w, d);
         }
         out[row * ldo + o] = d;
     }
