@@ -212,7 +212,9 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
         float vv[CPL], av[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) { vv[j] = V[v * ldv + lane + 64 * j]; av[j] = A[v * lda + lane + 64 * j]; }
-        const int32_t b = rowptr[v], e = rowptr[v + 1];
+        // (the same row for the whole wave: keep its bounds in scalar registers -- the loops over the edges become scalar
+        // branches and the lane indices of bg_readlane scalar operands)
+        const int32_t b = __builtin_amdgcn_readfirstlane(rowptr[v]), e = __builtin_amdgcn_readfirstlane(rowptr[v + 1]);
         const float em0 = exp_mask[2 * v], em1 = exp_mask[2 * v + 1];
         float l0 = 0.f, l1 = 0.f;
         if (!Wd) { l0 = logits[v * ldl]; l1 = logits[v * ldl + 1]; }
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
         float bv[4][CPL], xv0[4][CPL];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int32_t c = __shfl(my_col, i < deg ? i : 0, 64);
+            const int32_t c = bg_readlane(my_col, i < deg ? i : 0);
             const float* bp = B + (int64_t)c * ldb;
             const float* xp = X + (int64_t)c * ldx;
 #pragma unroll
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
             if (k0 > 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int32_t c = __shfl(my_col, k0 + i < deg ? k0 + i : k0, 64);
+                    const int32_t c = bg_readlane(my_col, k0 + i < deg ? k0 + i : k0);
                     const float* bp = B + (int64_t)c * ldb;
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) bv[i][j] = bp[lane + 64 * j];
@@ -269,16 +271,14 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
             }
         }
         // ---- segment Gumbel-softmax (k_seg_gumbel_softmax): max, then exp / sum in slot order
-        float m = y;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        const float m = bg_wave_max(y);
         const float ex = lane < deg ? expf(y - m) : 0.f;
         float sum = 0.f;
-        for (int j = 0; j < deg; ++j) sum += __shfl(ex, j, 64);
+        for (int j = 0; j < deg; ++j) sum += bg_readlane(ex, j);
         const float o = ex / (sum + 1e-16f);
         float best = -3.402823466e+38f; int ba = 0;
         for (int j = 0; j < deg; ++j) {
-            const float oj = __shfl(o, j, 64);
+            const float oj = bg_readlane(o, j);
             if (oj > best) { best = oj; ba = j; }
         }
         if (lane < deg) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) xv[i][j] = xv0[i][j];
                 } else {
-                    const int32_t c = __shfl(my_col, k0 + i < deg ? k0 + i : k0, 64);
+                    const int32_t c = bg_readlane(my_col, k0 + i < deg ? k0 + i : k0);
                     const float* xp = X + (int64_t)c * ldx;
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) xv[i][j] = xp[lane + 64 * j];
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (k0 + i < deg) {
-                    const float w = __shfl(o, k0 + i, 64);
+                    const float w = bg_readlane(o, k0 + i);
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) g[j] += w * xv[i][j];
                 }
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_attention_bwd_head(const float* __restr
         gg[v * ldgg + lane + 64 * j] = gs[j];
         gath[j] = 0.f;
     }
-    const int32_t b = rowptr[v], e = rowptr[v + 1];
+    const int32_t b = __builtin_amdgcn_readfirstlane(rowptr[v]), e = __builtin_amdgcn_readfirstlane(rowptr[v + 1]);
     const int deg = e - b;
     const int32_t my_col = lane < deg ? col[b + lane] : 0;
     const float my_soft = lane < deg ? soft[b + lane] : 0.f;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void k_attention_bwd_head(const float* __restr
         float xv[4][CPL];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int32_t c = __shfl(my_col, k0 + i < deg ? k0 + i : k0, 64);
+            const int32_t c = bg_readlane(my_col, k0 + i < deg ? k0 + i : k0);
             const float* xp = X + (int64_t)c * ldx;
 #pragma unroll
             for (int j = 0; j < CPL; ++j) xv[i][j] = xp[lane + 64 * j];
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void k_attention_bwd_head(const float* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (k0 + i < deg) {                                   // wave-uniform
-                const float w = __shfl(my_soft, k0 + i, 64);
+                const float w = bg_readlane(my_soft, k0 + i);
                 float acc = 0.f;
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_attention_bwd_head(const float* __restr
     }
     // segment softmax backward over the voxel's edges, in slot order
     float dot = 0.f;
-    for (int k = 0; k < deg; ++k) dot = fmaf(__shfl(my_soft, k, 64), __shfl(my_g, k, 64), dot);
+    for (int k = 0; k < deg; ++k) dot = fmaf(bg_readlane(my_soft, k), bg_readlane(my_g, k), dot);
     if (lane < deg) d_att[b + lane] = my_soft * (my_g - dot) / tau;
     // mask
     float gm = 0.f;

@@ -26,11 +26,57 @@ static inline int bg_grid_for(int64_t work, int per_block, int cap = 1 << 20) {
     return static_cast<int>(g);
 }
 
+// Cross-lane helpers that stay off the LDS crossbar (`__shfl*` compiles to ds_bpermute_b32, an LDS instruction with LDS
+// latency): DPP row operations inside a row of 16 lanes, gfx950's v_permlane16_swap / v_permlane32_swap across rows.
+//   bg_lane_xor<OFF>(v)[l] = v[l ^ OFF]   for OFF = 1, 2, 4, 8 (DPP: quad_perm, two masked row shifts, row_ror:8)
+template <int OFF>
+__device__ __forceinline__ float bg_lane_xor(float v) {
+    const int x = __float_as_int(v);
+    int t;
+    if (OFF == 1) t = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);            // quad_perm [1,0,3,2]
+    else if (OFF == 2) t = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);       // quad_perm [2,3,0,1]
+    else if (OFF == 4) {
+        t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);                     // lanes 0-3, 8-11 of a row: from l + 4
+        t = __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);                     // lanes 4-7, 12-15: from l - 4
+    } else t = __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false);                  // row_ror:8
+    return __int_as_float(t);
+}
+// the two halves of v[l] (op) v[l ^ 16] / v[l ^ 32]: after the swap a holds one partner in every lane, b the other
+__device__ __forceinline__ void bg_swap16(float v, float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void bg_swap32(float v, float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+// Sum over the 64 lanes, every lane gets it: the xor butterfly 32, 16, 8, 4, 2, 1 -- the same pairs in the same order as
+// `for (off = 32; off; off >>= 1) v += __shfl_xor(v, off)`, hence the same bits (tools/micro/dpp_sum.hip checks that).
 __device__ __forceinline__ float bg_wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    float a, b;
+    bg_swap32(v, a, b); v = a + b;
+    bg_swap16(v, a, b); v = a + b;
+    v += bg_lane_xor<8>(v);
+    v += bg_lane_xor<4>(v);
+    v += bg_lane_xor<2>(v);
+    v += bg_lane_xor<1>(v);
     return v;
 }
+__device__ __forceinline__ float bg_wave_max(float v) {
+    float a, b;
+    bg_swap32(v, a, b); v = fmaxf(a, b);
+    bg_swap16(v, a, b); v = fmaxf(a, b);
+    v = fmaxf(v, bg_lane_xor<8>(v));
+    v = fmaxf(v, bg_lane_xor<4>(v));
+    v = fmaxf(v, bg_lane_xor<2>(v));
+    v = fmaxf(v, bg_lane_xor<1>(v));
+    return v;
+}
+// v of lane `lane` (the same, wave-uniform `lane` in every thread) through the scalar unit instead of the LDS crossbar
+__device__ __forceinline__ float bg_readlane(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ int32_t bg_readlane(int32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
 __device__ __forceinline__ float4 bg_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void bg_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
