@@ -566,7 +566,9 @@ __device__ __forceinline__ void story_project_body(const float* __restrict__ x, 
             d = fmaf(wv.x, mv.x, d); d = fmaf(wv.y, mv.y, d);
             d = fmaf(wv.z, mv.z, d); d = fmaf(wv.w, mv.w, d);
         }
-        for (int off = 1; off < P; off <<= 1) d += __shfl_xor(d, off, 64);
+        d += bg_lane_xor<1>(d);                                   // P in {2, 4, 8}: the same pairs as the shuffle butterfly
+        if (P >= 4) d += bg_lane_xor<2>(d);
+        if (P >= 8) d += bg_lane_xor<4>(d);
         if (pp == 0) out[row * ldo + o] = d;
         return;
     }
