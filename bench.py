@@ -358,6 +358,9 @@ class HipWorkload:
             ts.append((time.perf_counter() - t) * 1e3)
         return round(statistics.median(ts), 3)
 
+    def settle_host(self):
+        self.trainer.settle_host()
+
     def replay_best_case(self, steps, warmup):
         """hipGraph replay of the captured iteration on ONE fixed batch, plan build outside (all ranks)."""
         tr = self.trainer
@@ -448,6 +451,8 @@ def main(argv=None):
     for _ in range(args.warmup):
         wl.step(i)
         i += 1
+    if hasattr(wl, "settle_host"):
+        wl.settle_host()              # what Trainer.fit does before its loop: collect once, gc.freeze() (collector stays on)
     wl.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):

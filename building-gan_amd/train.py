@@ -471,6 +471,16 @@ class Trainer:
         inference.py:74-76."""
         torch.save({k: v.detach().clone().cpu() for k, v in self.generator.state_dict().items()}, path)
 
+    @staticmethod
+    def settle_host():
+        """Before a long run of iterations: one full collection, then ``gc.freeze()`` -- the networks, plans' code, the
+        library bindings leave the cyclic collector's generations, so the collections the per-iteration autograd graphs
+        trigger no longer walk them (the collector stays ON; measured 3-4 % of an eager step, tools/gc_probe.py).
+        Process-wide, as gc.freeze() is; ``gc.unfreeze()`` undoes it."""
+        import gc
+        gc.collect()
+        gc.freeze()
+
     def fit(self, loader, n_epochs: int, model_dir: Optional[str] = None, eval_period: int = 20, on_epoch=None):
         """The reference's epoch loop (train.py:73-75,133-141): every batch of ``loader`` (any iterable of batches,
         re-iterated per epoch) goes to the device and through one iteration whose index restarts with the epoch;
@@ -480,6 +490,7 @@ class Trainer:
         stats = {}
         from .plan import prefetch_plan
         dev = torch.device(self.device)
+        self.settle_host()
 
         def fetch(it):
             b = next(it, None)

@@ -26,3 +26,12 @@ for rep in range(4):
         dt = (time.perf_counter() - t0) / 60
         print("gc %-3s %.3f ms/step   slowest host-side step call %.2f ms   gc counts %s" % ("on" if on else "off", dt * 1e3, worst * 1e3, gc.get_count()), flush=True)
 gc.enable()
+gc.collect()
+gc.freeze()          # everything alive now (modules, plans' code objects, the trainer) leaves the collector's generations
+for rep in range(3):
+    w.sync()
+    t0 = time.perf_counter()
+    for _ in range(60):
+        w.step(i); i += 1
+    w.sync()
+    print("gc on after gc.freeze(): %.3f ms/step" % ((time.perf_counter() - t0) / 60 * 1e3), flush=True)
