@@ -308,21 +308,23 @@ class HipWorkload:
 
     def step(self, i):
         """One iteration on batch i of the stream plus ONE plan build: the plan of the NEXT batch, rebuilt from its
-        index vectors as for a batch fresh from the loader, issued right after this iteration's launches on a side
-        stream (plan.prefetch_plan -- the loader-side prefetch of a training loop; train.Trainer.fit does the same).
-        Only the very first step finds no plan waiting and builds its own first."""
+        index vectors as for a batch fresh from the loader.  Its launches go to a side stream BEFORE this iteration is
+        issued (plan.prefetch_plan -- the loader-side prefetch of a training loop; train.Trainer.fit does the same), so
+        its flags have reached the host long before the next step reads them.  Only the very first step finds no plan
+        waiting and builds its own first."""
         n = len(self.batches)
         b = self.batches[i % n]
         if "_bg_plan" not in b.__dict__:
-            self.build_plan(b)
-        self.trainer.train_iteration(b, i)
+            self.build_plan(b)                    # finishes the plan the previous step started (or builds the first one)
         nxt = self.batches[(i + 1) % n]
         nxt.__dict__.pop("_bg_plan", None)        # a fresh batch: its index plan is part of the step
+        nxt.__dict__.pop("_bg_plan_pending", None)
         getattr(nxt.voxel_feature, "__dict__", {}).pop("_bg_split", None)      # (and nothing else derived from it is kept)
+        if self.prefetch_plan is not self.build_plan:
+            self.trainer.prefetch(nxt)            # plan (+ with several ranks the global counts) on a side stream
+        self.trainer.train_iteration(b, i)
         if self.prefetch_plan is self.build_plan:
             self.build_plan(nxt)
-        else:
-            self.trainer.prefetch(nxt)            # plan (+ with several ranks the global counts) on a side stream
 
     def sync(self):
         import torch

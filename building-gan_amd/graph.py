@@ -84,6 +84,7 @@ class VolumeDesignGraph:
             if torch.is_tensor(v):
                 setattr(self, k, v.to(device, non_blocking=non_blocking))
         self.__dict__.pop("_bg_plan", None)  # device-side plans do not survive a move
+        self.__dict__.pop("_bg_plan_pending", None)
         return self
 
 

@@ -207,11 +207,12 @@ def _check_and_publish(graph, p, flags, min_cross):
     return p
 
 
-def _build_plan_one_call(graph, S) -> Optional[GraphPlan]:
+def _build_plan_one_call(graph, S, defer: bool = False):
     """The whole plan by bg_plan_build (include/bgan.h): two arenas, one host call, one read-back.  Returns None for
     batches it is not laid out for (empty pieces, operators with long rows where the piece-by-piece path would add
     chunk tables, derived operators above 2^22 slots): those take the piece-by-piece path below, which builds the
-    same plan."""
+    same plan.  ``defer``: launch only -- the flags / statistics travel to pinned host memory asynchronously and a
+    _PendingPlan is returned; its finish() reads them (prefetch_plan: the host never waits for the side stream)."""
     vf = graph.voxel_feature
     dev = vf.device
     pe, ve = graph.program_edge, graph.voxel_edge
@@ -244,18 +245,42 @@ def _build_plan_one_call(graph, S) -> Optional[GraphPlan]:
     ai = torch.empty(tot[0], dtype=torch.int32, device=dev)
     af = torch.empty(tot[1], dtype=torch.float32, device=dev)
     check(lib.bg_plan_build(C.byref(pin), ai.data_ptr(), af.data_ptr(), stream()), "bg_plan_build")
-    host = ai[oi[_I32["FLAGS"]]: oi[_I32["STATS"]] + len(_STAT)].tolist()         # the one synchronisation
+    tail = ai[oi[_I32["FLAGS"]]: oi[_I32["STATS"]] + len(_STAT)]
+    sizes = (Np, Nv, Ep, Ev, Ec, B, S, n_slot, cp_R, R)
+    if defer:
+        host_buf = torch.empty(tail.numel(), dtype=torch.int32, pin_memory=True)
+        host_buf.copy_(tail, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        return _PendingPlan(graph, dev, ai, af, list(oi), list(of), sizes, host_buf, done)
+    return _finish_plan_one_call(graph, dev, ai, af, oi, of, sizes, tail.tolist())         # the one synchronisation
+
+
+class _PendingPlan:
+    """A plan whose kernels and read-back are in flight (plan.prefetch_plan)."""
+
+    def __init__(self, graph, dev, ai, af, oi, of, sizes, host_buf, done):
+        self.graph, self.device, self.ai, self.af, self.oi, self.of = graph, dev, ai, af, oi, of
+        self.sizes, self.host_buf, self.done = sizes, host_buf, done
+
+    def finish(self) -> "GraphPlan":
+        if not self.done.query():         # long over when the next iteration asks (the copy was queued a step ago);
+            self.done.synchronize()       # a query is much cheaper than a synchronize that has nothing to wait for
+        return _finish_plan_one_call(self.graph, self.device, self.ai, self.af, self.oi, self.of, self.sizes,
+                                     self.host_buf.tolist())
+
+
+def _finish_plan_one_call(graph, dev, ai, af, oi, of, sizes, host) -> "GraphPlan":
+    Np, Nv, Ep, Ev, Ec, B, S, n_slot, cp_R, R = sizes
     flags = {nm: tuple(host[4 * i: 4 * i + 4]) for i, nm in enumerate(_CSR_NAMES)}
     st_off = oi[_I32["STATS"]] - oi[_I32["FLAGS"]]
     stat = {n: host[st_off + i] for n, i in _STAT.items()}
 
     def I(name, n):
-        o = oi[_I32[name]]
-        return ai[o: o + n]
+        return ai.narrow(0, oi[_I32[name]], n)
 
     def F(name, n):
-        o = of[_F32[name]]
-        return af[o: o + n]
+        return af.narrow(0, of[_F32[name]], n)
 
     def csr(pre, n_rows, n_cols, nnz, count=None):
         return Csr(I(pre + "_ROWPTR", n_rows + 1), I(pre + "_COL", nnz), I(pre + "_PERM", nnz), n_rows, n_cols, nnz,
@@ -334,15 +359,18 @@ def _build_plan_one_call(graph, S) -> Optional[GraphPlan]:
 _PREFETCH_STREAMS = {}
 
 
-def prefetch_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
-    """Build the plan of a batch that a LATER iteration will use, beside the work already queued on the current
-    stream: the launches go to a side stream and the one host read-back waits for that stream only, so an iteration
-    whose kernels are still running is not drained first (what a loader's prefetch does for the reference's collate).
-    The first build_plan() on the batch makes the then-current stream wait for the side stream's event.  A plan
-    depends on the batch's index vectors alone, never on parameters."""
+def prefetch_plan(graph, num_stories: Optional[int] = None) -> Optional[GraphPlan]:
+    """Start the plan of a batch that a LATER iteration will use, beside the work already queued on the current
+    stream: the launches go to a side stream, the flags / statistics go to pinned host memory by an asynchronous copy,
+    and the host does NOT wait (what a loader's prefetch does for the reference's collate).  The first build_plan() on
+    the batch reads the read-back (finished long before), builds the plan's views and makes the then-current stream
+    wait for the side stream's event.  A plan depends on the batch's index vectors alone, never on parameters.
+    Returns the plan when it already exists or had to be built synchronously, else None."""
     cached = graph.__dict__.get("_bg_plan") if hasattr(graph, "__dict__") else None
     if cached is not None:
         return cached
+    if hasattr(graph, "__dict__") and "_bg_plan_pending" in graph.__dict__:
+        return None
     dev = graph.voxel_feature.device
     if dev.type != "cuda":
         return build_plan(graph, num_stories)
@@ -350,10 +378,22 @@ def prefetch_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     if side is None:
         side = _PREFETCH_STREAMS[dev] = torch.cuda.Stream(device=dev)
     main = torch.cuda.current_stream(dev)
+    pending = None
     with torch.cuda.stream(side):
-        p = build_plan(graph, num_stories)
-        ev = torch.cuda.Event()
-        ev.record(side)
+        if ONE_CALL_BUILD:
+            S1 = num_stories if num_stories is not None else getattr(graph, "num_stories", None)
+            if S1 is not None:           # (without the story count the build starts with a read-back of its own)
+                _lib.require_device(graph.voxel_feature, "prefetch_plan")
+                pending = _build_plan_one_call(graph, int(S1), defer=True)
+        if pending is None:
+            p = build_plan(graph, num_stories)
+            ev = torch.cuda.Event()
+            ev.record(side)
+    if pending is not None:
+        for t in (pending.ai, pending.af):
+            t.record_stream(main)         # allocated under the side stream, read by kernels of the main stream
+        graph.__dict__["_bg_plan_pending"] = pending
+        return None
     p.ops["_ready_event"] = ev
     for t in p.ops.get("_arenas", ()):
         t.record_stream(main)             # allocated under the side stream, read by kernels of the main stream
@@ -368,6 +408,10 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
         if ev is not None:                # prefetched on a side stream: order this stream behind its launches
             torch.cuda.current_stream(cached.device).wait_event(ev)
         return cached
+    pending = graph.__dict__.pop("_bg_plan_pending", None) if hasattr(graph, "__dict__") else None
+    if pending is not None:               # launched by prefetch_plan: read the (long finished) flags, build the views
+        torch.cuda.current_stream(pending.device).wait_event(pending.done)
+        return pending.finish()
     if ONE_CALL_BUILD:
         _lib.require_device(graph.voxel_feature, "build_plan")
         S1 = num_stories if num_stories is not None else getattr(graph, "num_stories", None)

@@ -444,6 +444,9 @@ class Trainer:
     def train_iteration(self, batch, i: int, program_z=None, voxel_z=None, noise: Optional[Sequence] = None,
                         u: Optional[torch.Tensor] = None):
         """Iteration ``i`` of an epoch (reference train.py:74-114).  Returns a dict of detached losses."""
+        if hasattr(batch, "__dict__") and "_bg_plan_pending" in batch.__dict__:
+            from .plan import build_plan
+            build_plan(batch)               # started by prefetch(): read its (finished) flags, build the views
         counts = global_counts(batch, self.group)
         do_d = i % self.n_critic_d == 0
         if (self.collapse_check_every and i % self.collapse_check_every == 0 and hasattr(self.discriminator, "guard_collapse")
@@ -501,10 +504,11 @@ class Trainer:
             it = iter(loader)
             batch, i = fetch(it), 0
             while batch is not None:
-                stats = self.train_iteration(batch, i)
-                batch, i = fetch(it), i + 1
-                if batch is not None and dev.type == "cuda":
-                    self.prefetch(batch)          # the next batch's index plan (and global counts) beside this iteration
+                nxt = fetch(it)
+                if nxt is not None and dev.type == "cuda":
+                    self.prefetch(nxt)            # the next batch's index plan (and global counts): started before this
+                stats = self.train_iteration(batch, i)      # iteration is issued, read when the next one begins
+                batch, i = nxt, i + 1
             if epoch % eval_period == 0:
                 if model_dir is not None:
                     os.makedirs(model_dir, exist_ok=True)

@@ -130,8 +130,9 @@ def test_plan_in_one_host_call_reports_bad_indices(cuda, monkeypatch):
 
 
 def test_prefetched_plan_equals_direct_build_and_orders_the_consumer(cuda):
-    """plan.prefetch_plan builds on a side stream; the plan must equal the directly built one bit for bit, and the
-    first build_plan() on the batch must order the current stream behind the side stream (the event is consumed)."""
+    """plan.prefetch_plan launches on a side stream and does NOT wait for the read-back; the first build_plan() on the
+    batch finishes it: that plan must equal the directly built one bit for bit, and the current stream must be ordered
+    behind the side stream.  A batch without a story count takes the synchronous prefetch (event on the plan)."""
     from building_gan_amd import ops, plan as P
     g = _batch("dataset", 9, "jitter").to(cuda)
     direct = P.build_plan(g)
@@ -141,15 +142,39 @@ def test_prefetched_plan_equals_direct_build_and_orders_the_consumer(cuda):
     # keep the main stream busy so that the side stream really runs beside it
     for _ in range(20):
         ops.spmm_raw(direct.vox_mean, x)
-    pre = P.prefetch_plan(g)
-    assert "_ready_event" in pre.ops
+    assert getattr(g, "num_stories", None) is not None
+    assert P.prefetch_plan(g) is None and "_bg_plan_pending" in g.__dict__ and "_bg_plan" not in g.__dict__
+    assert P.prefetch_plan(g) is None                              # idempotent while pending
     got_plan = P.build_plan(g)
-    assert got_plan is pre and "_ready_event" not in pre.ops
+    assert "_bg_plan_pending" not in g.__dict__ and g.__dict__["_bg_plan"] is got_plan
     got = ops.spmm_raw(got_plan.vox_mean, x)
     assert torch.equal(got, want)
-    a = {k: v for k, v in pre.ops.items() if k != "_arenas"}
+    a = {k: v for k, v in got_plan.ops.items() if k != "_arenas"}
     b = {k: v for k, v in direct.ops.items() if k != "_arenas"}
     _same(a, b, "plan", set())
+    # moving the batch drops a pending plan like a finished one
+    P.prefetch_plan(_drop(g))
+    g.to(cuda)
+    assert "_bg_plan_pending" not in g.__dict__ and "_bg_plan" not in g.__dict__
+    # no story count on the batch: the synchronous form, with the event the consumer waits for
+    g.__dict__.pop("num_stories", None)
+    pre = P.prefetch_plan(g)
+    assert pre is not None and "_ready_event" in pre.ops
+    assert P.build_plan(g) is pre and "_ready_event" not in pre.ops
+    _same({k: v for k, v in pre.ops.items() if k != "_arenas"}, b, "plan", set())
+    # bad indices surface when the pending plan is finished
+    bad = _batch("small", 3, True).to(cuda)
+    bad.cross_edge_voxel_index_select = bad.cross_edge_voxel_index_select.flip(0).contiguous()
+    if getattr(bad, "num_stories", None) is not None:
+        assert P.prefetch_plan(bad) is None
+        with pytest.raises(Exception, match="non-decreasing"):
+            P.build_plan(bad)
+
+
+def _drop(g):
+    g.__dict__.pop("_bg_plan", None)
+    g.__dict__.pop("_bg_plan_pending", None)
+    return g
 
 
 def test_plan_unsorted_random_keys(cuda):
