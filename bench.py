@@ -418,8 +418,8 @@ class HipWorkload:
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)      # 20 five-iteration cycles: a 20-step window moves by +-5 % from run to run
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--preset", default="dataset")
     ap.add_argument("--batches", type=int, default=8, help="distinct batches the timed steps rotate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -6,9 +6,9 @@ set -e
 T=${1:-prof}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$T; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-STEPS=20
+STEPS=100
 # 1. kernel trace + stats of the bench command itself (no CPU baseline: it is not GPU work) ...
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python3 bench.py --steps $STEPS --warmup 5 --no-cpu-baseline > $O/bench_prof.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python3 bench.py --steps $STEPS --warmup 20 --no-cpu-baseline > $O/bench_prof.log 2>&1
 cp $(find /tmp/pb -name '*kernel_stats.csv' | head -1) $O/bench_kernel_stats.csv
 python tools/prof_summary.py /tmp/pb $STEPS 40 > $O/bench_kernel_stats_summary.txt
 # ... and of its timed region alone (tools/step_only.py brackets the K steps with marker launches): true per-step numbers
