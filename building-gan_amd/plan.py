@@ -252,21 +252,21 @@ def _build_plan_one_call(graph, S, defer: bool = False):
         host_buf.copy_(tail, non_blocking=True)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))
-        return _PendingPlan(graph, dev, ai, af, list(oi), list(of), sizes, host_buf, done)
+        return _PendingPlan(dev, ai, af, list(oi), list(of), sizes, host_buf, done)
     return _finish_plan_one_call(graph, dev, ai, af, oi, of, sizes, tail.tolist())         # the one synchronisation
 
 
 class _PendingPlan:
     """A plan whose kernels and read-back are in flight (plan.prefetch_plan)."""
 
-    def __init__(self, graph, dev, ai, af, oi, of, sizes, host_buf, done):
-        self.graph, self.device, self.ai, self.af, self.oi, self.of = graph, dev, ai, af, oi, of
+    def __init__(self, dev, ai, af, oi, of, sizes, host_buf, done):      # (no reference to the batch: it holds this object)
+        self.device, self.ai, self.af, self.oi, self.of = dev, ai, af, oi, of
         self.sizes, self.host_buf, self.done = sizes, host_buf, done
 
-    def finish(self) -> "GraphPlan":
+    def finish(self, graph) -> "GraphPlan":
         if not self.done.query():         # long over when the next iteration asks (the copy was queued a step ago);
             self.done.synchronize()       # a query is much cheaper than a synchronize that has nothing to wait for
-        return _finish_plan_one_call(self.graph, self.device, self.ai, self.af, self.oi, self.of, self.sizes,
+        return _finish_plan_one_call(graph, self.device, self.ai, self.af, self.oi, self.of, self.sizes,
                                      self.host_buf.tolist())
 
 
@@ -411,7 +411,7 @@ def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:
     pending = graph.__dict__.pop("_bg_plan_pending", None) if hasattr(graph, "__dict__") else None
     if pending is not None:               # launched by prefetch_plan: read the (long finished) flags, build the views
         torch.cuda.current_stream(pending.device).wait_event(pending.done)
-        return pending.finish()
+        return pending.finish(graph)
     if ONE_CALL_BUILD:
         _lib.require_device(graph.voxel_feature, "build_plan")
         S1 = num_stories if num_stories is not None else getattr(graph, "num_stories", None)

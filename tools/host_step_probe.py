@@ -25,8 +25,8 @@ acc["bp"], acc["sync"] = [], []
 orig_bp, orig_fin = w.build_plan, P._PendingPlan.finish
 def timed_bp(b):
     t = time.perf_counter(); r = orig_bp(b); acc["bp"].append(time.perf_counter() - t); return r
-def timed_fin(self):
-    t = time.perf_counter(); self.done.synchronize(); acc["sync"].append(time.perf_counter() - t); return orig_fin(self)
+def timed_fin(self, graph):
+    t = time.perf_counter(); self.done.synchronize(); acc["sync"].append(time.perf_counter() - t); return orig_fin(self, graph)
 w.build_plan = timed_bp
 P._PendingPlan.finish = timed_fin
 t0 = time.perf_counter()
