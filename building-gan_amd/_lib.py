@@ -12,7 +12,21 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("BG_LIB_PATH") or os.path.join(_HERE, "csrc", "libbgan_hip.so")  # env: tuning A/B only
+def _lib_path() -> str:
+    """The in-tree library.  BG_LIB_PATH may name another build of it for A/B timing (``make tuning``, a variant under
+    csrc/variants/), but only inside this package's csrc/ directory: the loader never follows the variable elsewhere."""
+    default = os.path.join(_HERE, "csrc", "libbgan_hip.so")
+    alt = os.environ.get("BG_LIB_PATH")
+    if not alt:
+        return default
+    root = os.path.realpath(os.path.join(_HERE, "csrc")) + os.sep
+    real = os.path.realpath(alt)
+    if not real.startswith(root):
+        raise ImportError("BG_LIB_PATH=%r is outside %s: only builds of this package's own sources are loaded" % (alt, root))
+    return real
+
+
+LIB_PATH = _lib_path()
 
 _p = C.c_void_p
 _i64 = C.c_int64

@@ -17,6 +17,16 @@
         if ((call) != hipSuccess) return BG_ERR_LAUNCH;     \
     } while (0)
 
+// Tuning knobs.  The library is stateless and reads NO environment variable in its default build: every knob below
+// is the constant `dflt`.  A build with -DBG_TUNING_KNOBS (tools/ A/B runs only: `make tuning`) reads the named
+// variable once per process instead; kernel SELECTION may then differ, results never do (every variant is tested).
+#ifdef BG_TUNING_KNOBS
+#include <stdlib.h>
+static inline int bg_tune_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline constexpr int bg_tune_int(const char*, int dflt) { return dflt; }
+#endif
+
 static inline bool bg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static inline int bg_grid_for(int64_t work, int per_block, int cap = 1 << 20) {

@@ -4,7 +4,6 @@
 // extern "C" launcher with the same arguments as the op-by-op host path, so results are bit-identical.
 #include "common.h"
 #include <stdio.h>
-#include <stdlib.h>
 #include <initializer_list>
 
 namespace {
@@ -47,13 +46,12 @@ int linear(int64_t M, int64_t N, int n_seg, const float* a0, int64_t k0, const f
 
 }  // namespace
 
-// BG_DRIVER_SYNC=1 (diagnosis): every step is named on stderr before it is issued and the stream is drained after
+// BG_DRIVER_SYNC=1 (diagnosis, -DBG_TUNING_KNOBS builds only): every step is named on stderr before it is issued and the stream is drained after
 // it, so a faulting launch is the last line printed.
 static int g_step_sync = -1;
 static int step_sync() {
     if (g_step_sync < 0) {
-        const char* e = getenv("BG_DRIVER_SYNC");
-        g_step_sync = (e && e[0] == '1') ? 1 : 0;
+        g_step_sync = bg_tune_int("BG_DRIVER_SYNC", 0) == 1 ? 1 : 0;
     }
     return g_step_sync;
 }

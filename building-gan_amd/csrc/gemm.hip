@@ -11,7 +11,6 @@
 // Both feed the same k order to the MFMA: step j of an 8-deep group multiplies k = 8g+j (lanes
 // 0-31) and k = 8g+4+j (lanes 32-63) -- a permutation of k that both operands share.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -897,8 +896,7 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
 int xcd_mode() {
     static int cached = -1;
     if (cached < 0) {
-        const char* e = getenv("BG_GEMM_XCD");
-        cached = e ? (atoi(e) != 0) : 1;
+        cached = bg_tune_int("BG_GEMM_XCD", 1) != 0;
     }
     return cached;
 }
@@ -947,8 +945,7 @@ int launch_gemm(int transA, int transB, bool vec, GemmArgs g, int splits, hipStr
 int panel_mode() {
     static int cached = -1;
     if (cached < 0) {
-        const char* e = getenv("BG_GEMM_PANEL");
-        cached = e ? (atoi(e) != 0) : 1;
+        cached = bg_tune_int("BG_GEMM_PANEL", 1) != 0;
     }
     return cached;
 }
@@ -976,8 +973,7 @@ int launch_gemm_panel(GemmArgs g, hipStream_t s) {
 int panel_nj() {
     static int cached = -1;
     if (cached < 0) {
-        const char* e = getenv("BG_GEMM_PANEL_NJ");
-        cached = (e && atoi(e) == 2) ? 2 : 1;
+        cached = bg_tune_int("BG_GEMM_PANEL_NJ", 1) == 2 ? 2 : 1;
     }
     return cached;
 }
@@ -986,8 +982,7 @@ int panel_nj() {
 int dma_mode() {
     static int cached = -1;
     if (cached < 0) {
-        const char* e = getenv("BG_GEMM_DMA");
-        cached = e ? atoi(e) : 1;                     // 1 = by shape (see bg_gemm_f32)
+        cached = bg_tune_int("BG_GEMM_DMA", 1);       // 1 = by shape (see bg_gemm_f32)
         if (cached < 0 || cached > 4) cached = 1;
     }
     return cached;
@@ -1012,8 +1007,7 @@ int launch_gemm_dma(int transB, GemmArgs g, hipStream_t s) {
 int skinny_mode() {
     static int cached = -1;
     if (cached < 0) {
-        const char* e = getenv("BG_GEMM_SKINNY");
-        cached = e ? (atoi(e) != 0) : 1;
+        cached = bg_tune_int("BG_GEMM_SKINNY", 1) != 0;
     }
     return cached;
 }
@@ -1022,8 +1016,7 @@ int skinny_mode() {
 int skinny_max_tiles() {
     static int cached = -1;
     if (cached < 0) {
-        const char* e = getenv("BG_GEMM_SKINNY_TILES");
-        cached = e ? atoi(e) : 256;
+        cached = bg_tune_int("BG_GEMM_SKINNY_TILES", 256);
     }
     return cached;
 }
@@ -1035,7 +1028,7 @@ int launch_gemm_skinny(int transB, GemmArgs g, hipStream_t s) {
     int groups = 0;
     for (int i = 0; i < g.n_seg; ++i) groups += (int)((g.Ks[i] + 7) >> 3);
     static int force = -1;
-    if (force < 0) { const char* e = getenv("BG_GEMM_SKINNY_WAVES"); force = e ? atoi(e) : 0; }
+    if (force < 0) force = bg_tune_int("BG_GEMM_SKINNY_WAVES", 0);
     const bool wide = force ? force == 8 : groups > 32;      // K > 256: eight waves share it, one load round each
     if (wide) {
         if (transB) k_gemm_skinny<true, 8><<<blocks, 512, 0, s>>>(g);
@@ -1057,8 +1050,7 @@ bool operand_vec_ok(const float* p, int64_t ld, bool kc, int64_t K, int64_t rows
 int tile_override() {
     static int cached = -1;
     if (cached < 0) {
-        const char* e = getenv("BG_GEMM_TILE");
-        cached = e ? atoi(e) : 0;
+        cached = bg_tune_int("BG_GEMM_TILE", 0);
         if (cached < 0 || cached > 4) cached = 0;
     }
     return cached;
@@ -1068,8 +1060,7 @@ int tile_override() {
 int bk_override() {
     static int cached = -1;
     if (cached < 0) {
-        const char* e = getenv("BG_GEMM_BK");
-        cached = e ? atoi(e) : 0;
+        cached = bg_tune_int("BG_GEMM_BK", 0);
         if (cached != 32 && cached != 64) cached = 0;
     }
     return cached;
@@ -1153,7 +1144,7 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
         if (whole) {
             g.total_steps = (int)psteps; g.steps_per_split = (int)psteps;
             int64_t t = (M + 16 * 256 - 1) / (16 * 256);                 // 16-row tiles per panel so that panels <= 256
-            { static int force = -1; if (force < 0) { const char* e = getenv("BG_GEMM_PANEL_T"); force = e ? atoi(e) : 0; }
+            { static int force = -1; if (force < 0) force = bg_tune_int("BG_GEMM_PANEL_T", 0);
               if (force >= 2 && force <= 4) t = force; }
             if (panel_nj() == 2) {
                 if (t <= 2) return launch_gemm_panel<2, 2>(g, st);

@@ -550,7 +550,10 @@ inline void build_rows(const bgPlanIn& p, int64_t* N) {
 int plan_layout(const bgPlanIn& p, PlanLayout& L) {
     if (p.Np <= 0 || p.Nv <= 0 || p.Ep < 0 || p.Ev <= 0 || p.Ec <= 0 || p.B <= 0 || p.S <= 0 || p.n_slot <= 0) return BG_ERR_SHAPE;
     if (p.S * p.S > (1 << 22) || p.Np * p.Np > (1 << 22)) return BG_ERR_SHAPE;
-    if (p.Ev >= ((int64_t)1 << 30) || p.Ec >= ((int64_t)1 << 30) || p.Nv >= ((int64_t)1 << 30)) return BG_ERR_SHAPE;
+    // k_plan_misc, k_rowsort_short_b, k_story_graph and k_floor_* give every element a thread of its own and
+    // bg_grid_for caps a grid at 2^20 workgroups of 256 threads: 2^28 elements per job is the most they cover
+    constexpr int64_t kMaxJob = ((int64_t)1 << 28) - 1;
+    if (p.Ev > kMaxJob || p.Ec > kMaxJob || p.Nv > kMaxJob || p.Ep > kMaxJob || p.Np > kMaxJob) return BG_ERR_SHAPE;
     int64_t len[BGP_N_I32];
     const int64_t Np = p.Np, Nv = p.Nv, Ep = p.Ep, Ev = p.Ev, Ec = p.Ec, B = p.B, S = p.S, ns = p.n_slot;
     int64_t mx = Np > ns ? Np : ns; mx = mx > Nv ? mx : Nv; mx = mx > S ? mx : S; mx = mx > Ec ? mx : Ec; mx = mx > B ? mx : B;
@@ -654,14 +657,20 @@ int bg_plan_build(const bgPlanIn* in, int32_t* ai, float* af, bgStream stream) {
     }
     const dim3 ge(bg_grid_for(e_max, 256, 2048), kMaxBuilds), gn(g1(n_max), kMaxBuilds);
     k_hist_b<<<ge, 256, 0, s>>>(J, stats);
+    BG_LAUNCH_CHECK();
     k_scan_b<<<kMaxBuilds, 1024, 0, s>>>(J);
+    BG_LAUNCH_CHECK();
     k_place_b<<<ge, 256, 0, s>>>(J);
+    BG_LAUNCH_CHECK();
     k_rowsort_short_b<<<gn, 256, 0, s>>>(J);
+    BG_LAUNCH_CHECK();
     k_rowsort_long_b<<<dim3(128, kMaxBuilds), 256, 0, s>>>(J);
+    BG_LAUNCH_CHECK();
     k_fill_col_b<<<ge, 256, 0, s>>>(J);
     BG_LAUNCH_CHECK();
     // 4. floor level of every voxel inside its own building
     k_floor_min<<<g1(Nv), 256, 0, s>>>(p.vfc, p.vbi, Nv, B, I(BGP_FIRST));
+    BG_LAUNCH_CHECK();
     k_floor_level<<<g1(Nv), 256, 0, s>>>(p.vfc, p.vbi, Nv, B, I(BGP_FIRST), I(BGP_LEVEL));
     BG_LAUNCH_CHECK();
     // 5. int32 copies, counts, chunk counts, statistics: one launch
@@ -714,6 +723,7 @@ int bg_plan_build(const bgPlanIn* in, int32_t* ai, float* af, bgStream stream) {
     if (p.chunk_rows[3] > 0) { SJ.a[nsj] = I(BGP_CP_CHUNK); SJ.n[nsj++] = Np + 1; }
     for (int i = nsj; i < 4; ++i) { SJ.a[i] = nullptr; SJ.n[i] = 0; }
     k_scan_jobs<<<nsj, 1024, 0, s>>>(SJ);
+    BG_LAUNCH_CHECK();
     // 7. the two derived operators
     DerivedArgs D{I(BGP_SGR_ROWPTR), I(BGP_SGR_COL), I(BGP_STORYGRAPH32), (int)S, (int)B, I(BGP_SS_ROWPTR), I(BGP_SS_COL),
                   F(BGP_SS_COUNT), stats + BGS_NNZ_SS,

@@ -3,7 +3,6 @@
 // one float4 per lane, rows owned by lane groups (no atomics), slot order = COO order.
 #include "common.h"
 #include <mutex>
-#include <stdlib.h>
 
 namespace {
 
@@ -102,9 +101,15 @@ __global__ __launch_bounds__(256) void k_spmm_vec(SpmmArgs a) {
 // the gathers of every slot -- three dependent round trips per R rows where the loop above pays one per slot group
 // (index, then row, then the next slot ..).  Sums run in slot order (bit-identical to the loop); slots past D
 // (rows longer than D) continue in the loop form.
-template <int LPR, int R>
+// Round 3 (tools/micro/spmm_lab.hip, profiles/r03_gather_*): R = 2 rows with D = 6 register slots (voxel grids have
+// at most six neighbours; 60 VGPRs, 8 waves per SIMD) against R = 1, D = 8 (40 VGPRs): 10^6 edges streaming from
+// HBM 61.9 -> 57.2 us (H = 128), 125.9 -> 114.2 us (H = 256); operand in the Infinity Cache 39.8 -> 34.0 us.  The
+// kernel is bound by the CU's queue of outstanding L1 -> L2 read requests (64 lines of 128 bytes per CU: PMC
+// TCP_TCC_READ_REQ_LATENCY / kernel cycles / 256 = 45 with R = 1, 51 with R = 2, 62-66 for a persistent pipelined
+// form that loses the gain to L2 misses); R = 4 (116 VGPRs, 4 waves per SIMD) is slower than R = 1.
+template <int LPR, int R, int D>
 __global__ __launch_bounds__(256) void k_spmm_batched(SpmmArgs a) {
-    constexpr int RPW = 64 / LPR, D = 8;
+    constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % LPR;
     const int64_t blk = xcd_remap(blockIdx.x, gridDim.x);
@@ -151,16 +156,16 @@ __global__ __launch_bounds__(256) void k_spmm_batched(SpmmArgs a) {
     }
 }
 
-template <int R>
+template <int R, int D>
 int launch_spmm_batched(const SpmmArgs& a, hipStream_t s) {
     int lpr = 1;
     while (lpr < a.H4) lpr <<= 1;
     const int gpb = 4 * (64 / lpr);                                   // lane groups per 256-thread workgroup
     const int grid = bg_grid_for((a.n_rows + R - 1) / R, gpb, 0x7fffffff);
     switch (lpr) {
-        case 16: k_spmm_batched<16, R><<<grid, 256, 0, s>>>(a); break;
-        case 32: k_spmm_batched<32, R><<<grid, 256, 0, s>>>(a); break;
-        case 64: k_spmm_batched<64, R><<<grid, 256, 0, s>>>(a); break;
+        case 16: k_spmm_batched<16, R, D><<<grid, 256, 0, s>>>(a); break;
+        case 32: k_spmm_batched<32, R, D><<<grid, 256, 0, s>>>(a); break;
+        case 64: k_spmm_batched<64, R, D><<<grid, 256, 0, s>>>(a); break;
         default: return BG_ERR_SHAPE;
     }
     BG_LAUNCH_CHECK();
@@ -223,7 +228,7 @@ int spmm_dispatch(SpmmArgs a, int64_t H, hipStream_t s) {
     }
     const bool general = !a.col || a.edge_w || a.col_mode;
     {
-        static const int64_t nt_bytes = [] { const char* e = getenv("BG_SPMM_NT_MB"); return (int64_t)(e ? atoi(e) : 64) << 20; }();
+        static const int64_t nt_bytes = (int64_t)bg_tune_int("BG_SPMM_NT_MB", 64) << 20;
         a.nt_store = nt_bytes > 0 && a.n_rows * H * 4 >= nt_bytes;
     }
     for (int64_t h0 = 0; h0 < H; h0 += 256) {   // panels of 64 float4 columns
@@ -234,12 +239,13 @@ int spmm_dispatch(SpmmArgs a, int64_t H, hipStream_t s) {
         if (a.gadd) p.gadd = a.gadd + h0;
         p.H4 = (int)((H - h0 < 256 ? H - h0 : 256) / 4);
         int rc;
-        // large plain gather-sums: the batched form (all of a row's indices, then all of its gathers, in flight at
-        // once): 70.9 -> 64.7 us at 10^6 edges streaming from HBM, unchanged when the operand sits in the Infinity
-        // Cache; BG_SPMM_BATCH=0 keeps the loop form for A/B runs
-        static const int batch_rows = [] { const char* e = getenv("BG_SPMM_BATCH"); return e ? atoi(e) : 1; }();
+        // large plain gather-sums: the batched form (the indices of two rows, then all their gathers, in flight at
+        // once): 70.9 us (loop form) -> 57.2 us at 10^6 edges streaming from HBM.  Tuning builds: BG_SPMM_BATCH = 0
+        // keeps the loop form, 1 / 4 select other row counts
+        static const int batch_rows = bg_tune_int("BG_SPMM_BATCH", 2);
         if (!general && !p.gadd && p.H4 >= 16 && batch_rows > 0 && p.n_rows >= 4096)
-            rc = batch_rows == 1 ? launch_spmm_batched<1>(p, s) : (batch_rows == 2 ? launch_spmm_batched<2>(p, s) : launch_spmm_batched<4>(p, s));
+            rc = batch_rows == 1 ? launch_spmm_batched<1, 8>(p, s)
+                                 : (batch_rows == 2 ? launch_spmm_batched<2, 6>(p, s) : launch_spmm_batched<4, 6>(p, s));
         else
             rc = general ? launch_spmm_vec<true>(p, s) : launch_spmm_vec<false>(p, s);
         if (rc != BG_OK) return rc;
@@ -1105,9 +1111,17 @@ static __device__ __align__(256) unsigned char bg_segmax_scratch[8u * BG_SEGMAX_
 static void* g_segmax_scratch_ptr[BG_MAX_DEVICES];      // per device, filled on that device's first call
 static std::mutex g_segmax_scratch_mutex;
 
-static int segmax_scratch_for_current_device(void** out) {
+// The buffer belongs to the device the kernels will run on, i.e. the stream's.  Like every launch of this library
+// the call needs that device to be the current one (a launch on another device's stream fails in the runtime); here
+// a mismatch would also pick another GPU's address, so it is refused before anything is launched.
+static int segmax_scratch_for_stream(hipStream_t s, void** out) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BG_MAX_DEVICES) return BG_ERR_LAUNCH;
+    if (s) {
+        hipDevice_t sd;
+        if (hipStreamGetDevice(s, &sd) != hipSuccess) return BG_ERR_LAUNCH;
+        if ((int)sd != dev) return BG_ERR_ARG;
+    }
     std::lock_guard<std::mutex> lock(g_segmax_scratch_mutex);
     if (!g_segmax_scratch_ptr[dev]) {
         void* p = nullptr;
@@ -1126,7 +1140,7 @@ int bg_segmax_static_f32(const float* x, int64_t ldx, const int32_t* rowptr, con
     if (!chunk_ptr) return BG_ERR_ARG;
     if (n_chunks_ub > BG_SEGMAX_STATIC_ELEMS || n_chunks_ub * H > (int64_t)BG_SEGMAX_STATIC_ELEMS) return BG_ERR_SCRATCH;
     void* base = nullptr;
-    int rc = segmax_scratch_for_current_device(&base);
+    int rc = segmax_scratch_for_stream((hipStream_t)stream, &base);
     if (rc != BG_OK) return rc;
     // nothing has to start at zero: phase 1 writes every partial that phase 2 reads
     float* pval = reinterpret_cast<float*>(base);

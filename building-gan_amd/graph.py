@@ -79,12 +79,29 @@ class VolumeDesignGraph:
         return -1 if key in _LAST_DIM else 0
 
     def to(self, device, non_blocking: bool = False):
+        """As ``batch.to(device)`` of reference train.py:75.  With ``non_blocking=True`` (copies from pinned memory
+        that the host does not wait for) an event is recorded behind the last copy (``_bg_h2d_event``): streams other
+        than the current one -- the plan's prefetch stream -- order themselves behind it before they read the batch."""
         for k in self.keys:
             v = getattr(self, k)
             if torch.is_tensor(v):
                 setattr(self, k, v.to(device, non_blocking=non_blocking))
         self.__dict__.pop("_bg_plan", None)  # device-side plans do not survive a move
         self.__dict__.pop("_bg_plan_pending", None)
+        self.__dict__.pop("_bg_h2d_event", None)
+        dev = torch.device(device) if not isinstance(device, torch.device) else device
+        if non_blocking and dev.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self.__dict__["_bg_h2d_event"] = ev
+        return self
+
+    def pin_memory(self):
+        """Page-locked host copies of every tensor (what a DataLoader with ``pin_memory=True`` hands over)."""
+        for k in self.keys:
+            v = getattr(self, k)
+            if torch.is_tensor(v) and not v.is_cuda:
+                setattr(self, k, v.pin_memory())
         return self
 
 

@@ -939,19 +939,30 @@ class DiscriminatorVoxel(nn.Module):
     # takes over until a later check finds the parameters back inside
     COLLAPSE_AMPLIFICATION_LIMIT = 1e-4 / 2.0 ** -24 / 8.0
 
-    def guard_collapse(self, graph, label=None) -> float:
+    def guard_collapse(self, graph, label=None, reduce_max=None) -> float:
         """Runtime guard of the collapsed (polynomial) evaluation: measure its rounding amplification on this batch
         with the current parameters (one small product on <= 2,048 sampled voxels; ONE host read, so call it every
         few hundred optimizer steps -- train.Trainer does, `collapse_check_every`) and switch the discriminator
-        between the collapsed form and the layer-by-layer stack accordingly.  Returns the amplification."""
+        between the collapsed form and the layer-by-layer stack accordingly.  Returns the amplification.
+        ``reduce_max`` (a one-element-tensor -> tensor function, e.g. an all-reduce MAX over the data-parallel group)
+        makes the decision the same on every rank: each rank measures its own batch, all of them act on the largest
+        value (NaN counts as +inf), so no rank evaluates the discriminator in another order than its peers."""
         plan = build_plan(graph)
         gnn = self.voxelGNN_D
-        if not (COLLAPSE_D and COMPOSE_BLOCKS and plan.vox_all_has and gnn.layer_num > 0):
+        applies = bool(COLLAPSE_D and COMPOSE_BLOCKS and plan.vox_all_has and gnn.layer_num > 0)
+        if not applies and reduce_max is None:
             return 0.0
-        pos, feat = extract_pos(graph.voxel_feature)
-        label = graph.voxel_label if label is None else label
-        amp = float(gnn.collapse_amplification(feat, label, plan, _pos_terms(plan, pos)))
-        gnn.collapse_ok = amp == amp and amp <= self.COLLAPSE_AMPLIFICATION_LIMIT        # NaN -> stack
+        if applies:
+            pos, feat = extract_pos(graph.voxel_feature)
+            label = graph.voxel_label if label is None else label
+            amp_t = gnn.collapse_amplification(feat, label, plan, _pos_terms(plan, pos)).detach().reshape(1).float()
+            amp_t = torch.where(torch.isnan(amp_t), torch.full_like(amp_t, float("inf")), amp_t)
+        else:                                     # this rank's batch takes the stack anyway: it still joins the collective
+            amp_t = torch.zeros(1, dtype=torch.float32, device=graph.voxel_feature.device)
+        if reduce_max is not None:
+            amp_t = reduce_max(amp_t)
+        amp = float(amp_t)
+        gnn.collapse_ok = amp <= self.COLLAPSE_AMPLIFICATION_LIMIT                       # +inf (a NaN somewhere) -> stack
         return amp
 
     def prepare(self, graph, n_label: int = NUMBER_OF_CLASS):

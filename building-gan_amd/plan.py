@@ -374,30 +374,53 @@ def prefetch_plan(graph, num_stories: Optional[int] = None) -> Optional[GraphPla
     dev = graph.voxel_feature.device
     if dev.type != "cuda":
         return build_plan(graph, num_stories)
+    S1 = num_stories if num_stories is not None else getattr(graph, "num_stories", None)
+    if not ONE_CALL_BUILD or S1 is None:
+        # the piece-by-piece build starts with a read-back of its own (nothing would overlap) and allocates every plan
+        # tensor one by one: it runs on the CURRENT stream, which owns those tensors for the iteration's kernels
+        return build_plan(graph, num_stories)
+    side = prefetch_stream(dev)
+    main = torch.cuda.current_stream(dev)
+    order_behind_producer(graph, side, main)
+    with torch.cuda.stream(side):
+        _lib.require_device(graph.voxel_feature, "prefetch_plan")
+        pending = _build_plan_one_call(graph, int(S1), defer=True)
+    if pending is None:
+        # the one-call build declined the batch (long rows, an empty piece): as above, on the current stream
+        return build_plan(graph, num_stories)
+    for t in (pending.ai, pending.af):
+        t.record_stream(main)             # allocated under the side stream, read by kernels of the main stream
+    graph.__dict__["_bg_plan_pending"] = pending
+    return None
+
+
+def prefetch_stream(dev) -> "torch.cuda.Stream":
     side = _PREFETCH_STREAMS.get(dev)
     if side is None:
         side = _PREFETCH_STREAMS[dev] = torch.cuda.Stream(device=dev)
-    main = torch.cuda.current_stream(dev)
-    pending = None
-    with torch.cuda.stream(side):
-        if ONE_CALL_BUILD:
-            S1 = num_stories if num_stories is not None else getattr(graph, "num_stories", None)
-            if S1 is not None:           # (without the story count the build starts with a read-back of its own)
-                _lib.require_device(graph.voxel_feature, "prefetch_plan")
-                pending = _build_plan_one_call(graph, int(S1), defer=True)
-        if pending is None:
-            p = build_plan(graph, num_stories)
-            ev = torch.cuda.Event()
-            ev.record(side)
-    if pending is not None:
-        for t in (pending.ai, pending.af):
-            t.record_stream(main)         # allocated under the side stream, read by kernels of the main stream
-        graph.__dict__["_bg_plan_pending"] = pending
-        return None
-    p.ops["_ready_event"] = ev
-    for t in p.ops.get("_arenas", ()):
-        t.record_stream(main)             # allocated under the side stream, read by kernels of the main stream
-    return p
+    return side
+
+
+_PLAN_INPUT_KEYS = ("program_edge", "voxel_edge", "cross_edge_program_index_select", "cross_edge_voxel_index_select",
+                    "voxel_floor_cluster", "voxel_feature_batch", "program_class_cluster", "program_target_ratio_batch",
+                    "program_target_ratio", "program_class_feature", "voxel_feature", "FAR")
+
+
+def order_behind_producer(graph, side, main) -> None:
+    """Order the side stream behind whatever produced the batch's tensors and tell the allocator that the side
+    stream reads them.  A loader that copies from pinned memory with ``non_blocking=True`` (``VolumeDesignGraph.to``)
+    leaves an event behind its last copy (``_bg_h2d_event``): the side stream waits for that event only, so the
+    plan still runs beside the iteration queued before it.  Without the event the side stream waits for everything
+    queued on the current stream so far (a batch built by device ops there is then complete as well)."""
+    ev = graph.__dict__.get("_bg_h2d_event") if hasattr(graph, "__dict__") else None
+    if ev is not None:
+        side.wait_event(ev)
+    else:
+        side.wait_stream(main)
+    for k in _PLAN_INPUT_KEYS:
+        t = getattr(graph, k, None)
+        if torch.is_tensor(t) and t.is_cuda:
+            t.record_stream(side)         # allocated under the main stream, read by the side stream's kernels
 
 
 def build_plan(graph, num_stories: Optional[int] = None) -> GraphPlan:

@@ -32,6 +32,19 @@ def _world(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+# With one rank every collective is the identity and is skipped.  FORCE_COLLECTIVES = True issues them anyway when a
+# process group exists (bench.py --force-dist, tests/test_rccl_one_rank.py): the RCCL call path -- all-reduce of the
+# flat gradient buffers, broadcast of the parameters, the counts' collective on the side stream, the cuts of the
+# captured iteration at the collectives -- then runs on a single GPU exactly as it does with eight.
+FORCE_COLLECTIVES = False
+
+
+def _collective(group=None) -> bool:
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return FORCE_COLLECTIVES or dist.get_world_size(group) > 1
+
+
 class FlatAdam:
     """Parameters and gradients of a module as views into two flat buffers + HIP Adam."""
 
@@ -104,7 +117,7 @@ class FlatAdam:
             p.grad = view
 
     def all_reduce(self, group=None):
-        if _world(group) > 1:
+        if _collective(group):
             if self.grad.is_cuda and dist.get_backend(group) == "gloo":
                 torch.cuda.current_stream().synchronize()      # gloo reads the buffer from the host side
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
@@ -149,7 +162,7 @@ def global_counts(batch, group=None):
     if cached is not None and cached[0] == _world(group):
         return cached[1]
     B, S, Nv = _local_counts(batch)
-    if _world(group) > 1:
+    if _collective(group):
         t = torch.tensor([B, S, Nv], dtype=torch.float64, device=batch.voxel_feature.device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         B, S, Nv = (int(x) for x in t.tolist())
@@ -160,19 +173,17 @@ def prefetch_counts(batch, group=None):
     """The global counts of a batch that a LATER iteration will use, fetched now on the plan's side stream: reading the
     all-reduced counts back at the start of an iteration would first drain everything the previous iteration queued
     (with one rank there is nothing to fetch).  Every rank must call this for the same batches in the same order."""
-    if _world(group) <= 1 or not hasattr(batch, "__dict__"):
+    if not _collective(group) or not hasattr(batch, "__dict__"):
         return
-    from .plan import _PREFETCH_STREAMS
+    from .plan import prefetch_stream
     dev = batch.voxel_feature.device
     B, S, Nv = _local_counts(batch)
     if dev.type != "cuda":
         t = torch.tensor([B, S, Nv], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     else:
-        side = _PREFETCH_STREAMS.get(dev)
-        if side is None:
-            side = _PREFETCH_STREAMS[dev] = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(side):
+        side = prefetch_stream(dev)
+        with torch.cuda.stream(side):             # (the counts come from host-side shapes: nothing of the batch is read)
             t = torch.tensor([B, S, Nv], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             t = t.cpu()                   # waits for the side stream (and the collective it ordered behind) only
@@ -209,6 +220,7 @@ class Trainer:
         self.collapse_check_every = collapse_check_every
         self.group = group
         self._graphs = None
+        self._captured_batch = None
         self._cw_cache = None
         # composed generator weights (functions of the parameters alone) kept between generator updates for the
         # graph-free forwards of critic-only iterations; refreshed IN PLACE (captured graphs hold the buffers)
@@ -219,7 +231,7 @@ class Trainer:
         self._overlap_stream = None    # set while capture() records the iteration
 
     def broadcast_parameters(self, src: int = 0):
-        if _world(self.group) > 1:
+        if _collective(self.group):
             dist.broadcast(self.opt_g.flat, src, group=self.group)
             dist.broadcast(self.opt_d.flat, src, group=self.group)
             self.refresh_derived()
@@ -433,6 +445,18 @@ class Trainer:
         stats["g_loss"] = g_loss.detach()
         return stats
 
+    def _reduce_max(self):
+        """The collective that makes a per-rank measurement a group-wide decision (None with one rank)."""
+        if not _collective(self.group):
+            return None
+
+        def reduce_max(t):
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                torch.cuda.current_stream().synchronize()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            return t
+        return reduce_max
+
     def prefetch(self, batch):
         """What the NEXT iteration needs from its batch alone -- the index plan and, with several ranks, the global
         counts -- issued now beside the running iteration (side stream; see plan.prefetch_plan)."""
@@ -451,7 +475,7 @@ class Trainer:
         do_d = i % self.n_critic_d == 0
         if (self.collapse_check_every and i % self.collapse_check_every == 0 and hasattr(self.discriminator, "guard_collapse")
                 and batch.voxel_feature.is_cuda and not torch.cuda.is_current_stream_capturing()):
-            self.discriminator.guard_collapse(batch)
+            self.discriminator.guard_collapse(batch, reduce_max=self._reduce_max())
         gen, stats = self._phase_d(batch, counts, do_d, program_z, voxel_z, noise, u, g_update=i % self.n_critic_g == 0)
         if do_d:
             self.opt_d.all_reduce(self.group)
@@ -573,6 +597,7 @@ class Trainer:
         gB2, _ = cap(lambda: self.opt_d.step())
         graphs["no_g"] = (gA2, gB2, statsA2)
         self._graphs = graphs
+        self._captured_batch = batch
         self._keep = (gen, gen2)
         self._overlap_stream = None    # eager iterations stay on one stream
         self.opt_g.restore(saved[0])
@@ -581,8 +606,18 @@ class Trainer:
         torch.cuda.synchronize()
 
     def train_iteration_graphed(self, i: int):
+        """Replay the captured iteration.  A replay runs the discriminator in the form it had when it was captured
+        (collapsed polynomial or layer stack); every ``collapse_check_every`` replays the guard is measured again on
+        the captured batch (group-wide, one host read) and a changed decision re-captures the graphs."""
         if self._graphs is None:
             raise RuntimeError("call capture(batch) first")
+        if (self.collapse_check_every and i > 0 and i % self.collapse_check_every == 0
+                and hasattr(self.discriminator, "guard_collapse") and self._captured_batch is not None):
+            gnn = getattr(self.discriminator, "voxelGNN_D", None)
+            before = getattr(gnn, "collapse_ok", None)
+            self.discriminator.guard_collapse(self._captured_batch, reduce_max=self._reduce_max())
+            if getattr(gnn, "collapse_ok", None) != before:
+                self.capture(self._captured_batch, warmup=1)
         if i % self.n_critic_g == 0:
             gA, gB, gC, stats = self._graphs["with_g"]
             gA.replay()

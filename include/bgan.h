@@ -9,6 +9,13 @@
  *
  * Conventions: matrices are row-major float32 with an explicit row pitch `ld*` (in floats);
  * CSR plans are int32 (rowptr[n_rows+1], col[nnz]); "first index wins" on arg-max ties.
+ *
+ * State and environment: the shipped library keeps no state between calls (the one exception is
+ * declared beside bg_segmax_static_f32) and reads NO environment variable: which kernel serves a
+ * shape is a function of the arguments alone.  The BG_GEMM_*, BG_SPMM_* and BG_DRIVER_SYNC variables that
+ * tools/ mention exist only in a build made with -DBG_TUNING_KNOBS (`make -C building-gan_amd/csrc
+ * tuning`, csrc/common.h): they select among kernel variants for A/B timing, never change a result,
+ * and are not part of this interface.
  */
 #ifndef BGAN_H
 #define BGAN_H
@@ -106,7 +113,7 @@ int bg_plan_layout(const bgPlanIn* in, int64_t* offs_i32, int64_t* offs_f32, int
 
 /* Every CSR, segment table, chunk table, floor level, derived operator and statistic of a batch's plan (what
  * building-gan_amd/plan.py otherwise assembles from ~25 bg_plan_* calls and ~100 host-issued tensor operations) by
- * ONE host call: ~90 launches issued back to back, no synchronisation; the caller reads BGP_FLAGS / BGP_STATS back
+ * ONE host call: 13 launches (+ one memset) issued back to back, no synchronisation; the caller reads BGP_FLAGS / BGP_STATS back
  * once.  arena_i32 must be 16-byte aligned.
  * replaces: the COO bookkeeping of every torch_scatter / torch_geometric call of a pass (see bg_plan_csr).          */
 int bg_plan_build(const bgPlanIn* in, int32_t* arena_i32, float* arena_f32, bgStream stream);
@@ -244,7 +251,9 @@ int bg_segmax_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int3
  * torch_scatter on every call).  n_chunks_ub * H > BG_SEGMAX_STATIC_ELEMS returns BG_ERR_SCRATCH; chunk_ptr is
  * required (the one-launch form of bg_segmax_f32 needs no workspace to begin with).  Every call on a GPU shares
  * that GPU's buffer: calls that overlap on one GPU (two streams, two threads) race; calls on one stream do not.
- * The first call on a device looks the buffer's address up (hipGetSymbolAddress): make it outside stream capture. */
+ * ONE CALL IN FLIGHT PER GPU.  The buffer is the one of the stream's device, which must be the current device
+ * (BG_ERR_ARG otherwise, before anything is launched).  The first call on a device looks the buffer's address up
+ * (hipGetSymbolAddress): make it outside stream capture. */
 #define BG_SEGMAX_STATIC_ELEMS (1 << 20)
 int bg_segmax_static_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
                          const int32_t* chunk_ptr, int32_t rows_per_chunk, int64_t n_chunks_ub,

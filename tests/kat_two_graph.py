@@ -203,3 +203,173 @@ def attention(att, x, v, exp_mask, exp_att):
     for e, (j, i) in enumerate(zip(cep, cev)):
         new_v[i] += mask_soft[i] * soft[e] * x[j]
     return mask_soft, mask_win, soft, arg, new_v
+
+
+# ---------------------------------------------------------------- round 3: the rest of the path, by the same loops
+# Whole networks on the literal batch: the generator's call schedule (/root/reference/Model/models.py:185-203,
+# 241-250), its output stage (:128-141 with /root/reference/util_graph.py:44-48), the discriminator with both max
+# pools (:215-229, 260-264), the area pipeline (/root/reference/util_graph.py:21-41) and the gradient penalty's VALUE
+# by central differences (/root/reference/Model/losses.py:73-89).  float64 throughout, one node / edge / segment at a
+# time, no oracle code, no plan.
+def position_table(d_model, max_len=20):
+    """models.py:13-19."""
+    pe = np.zeros((max_len, d_model))
+    for p in range(max_len):
+        for k in range(0, d_model, 2):
+            f = np.exp(k * (-np.log(10000.0) / d_model))
+            pe[p, k] = np.sin(p * f)
+            pe[p, k + 1] = np.cos(p * f)
+    return pe
+
+
+def _split_feature():
+    f = batched_voxel_feature().astype(np.float64)
+    return f[:, 3:6], np.concatenate([f[:, 0:3], f[:, 6:]], 1)          # models.py:45-49: (pos, the rest)
+
+
+def program_gnn(gnn, z):
+    """models.py:83-92: enc([class one-hot | story level | z]) then layer_num residual applications of ONE block."""
+    W, b = _lin(gnn.enc[0])
+    onehot = np.eye(6)[[c % 6 for c in EXPECT["program_class_cluster"]]]
+    x = np.stack([W @ np.concatenate([onehot[i], [EXPECT["story_level_feature"][i]], z[i]]) + b for i in range(NP)])
+    for _ in range(gnn.layer_num):
+        x = x + program_block(gnn.block, x)
+    return x
+
+
+def generator_forward(G, program_z, noises):
+    """models.py:241-250 with VoxelGNN_G.forward (:185-203): attention once before the layers, then after layer i for
+    even i > 0; the mask / att of the LAST call go to the output stage.  ``noises`` = [(Exp(1) [Nv, 2], Exp(1) [Ec])]
+    in call order.  Returns (out, soft_out, mask_soft, mask_win, att_soft, arg edge per voxel, program index per
+    voxel, calls made)."""
+    x = program_gnn(G.programGNN, program_z)
+    gnn = G.voxelGNN
+    pos, rest = _split_feature()
+    W, b = _lin(gnn.enc[0])
+    pe = position_table(W.shape[0])
+    v = np.stack([W @ rest[i] + b + pe[FLOOR_LEVEL[i]] for i in range(NV)])
+    call = 0
+    _, _, _, _, v = attention(gnn.attention, x, v, noises[call][0], noises[call][1])
+    call += 1
+    last = None
+    for i in range(gnn.layer_num):
+        v = v + voxel_block(gnn.block, v, pos)
+        if i % 2 == 0 and i != 0:
+            ms, mw, soft, arg, v = attention(gnn.attention, x, v, noises[call][0], noises[call][1])
+            call += 1
+            last = (ms, mw, soft, arg)
+    ms, mw, soft, arg = last
+    out, soft_out, idx = construct_output(ms, mw, soft, arg)
+    return out, soft_out, ms, mw, soft, arg, idx, call
+
+
+def straight_through(hard, soft):
+    """util.py:10 / :26: (hard - soft) + soft, in this order."""
+    return (hard - soft) + soft
+
+
+def construct_output(mask_soft, mask_win, att_soft, arg):
+    """models.py:128-141: per voxel, the program node of the cross edge with the largest att_hard * mask_hard (first
+    edge on ties: a masked voxel's logits are all zero), and the class one-hots of the voxel's edges summed with the
+    hard / soft attention, times the hard mask."""
+    cep, cev = EXPECT["cross_edge_program_index_select"], EXPECT["cross_edge_voxel_index_select"]
+    onehot = np.eye(6)[[c % 6 for c in EXPECT["program_class_cluster"]]]
+    mask_hard = np.array([straight_through(1.0 if mask_win[i] == 0 else 0.0, mask_soft[i]) for i in range(NV)])
+    att_hard = np.array([straight_through(1.0 if arg[cev[e]] == e else 0.0, att_soft[e]) for e in range(EC)])
+    out, soft_out, idx = np.zeros((NV, 6)), np.zeros((NV, 6)), np.zeros(NV, dtype=np.int64)
+    for i in range(NV):
+        es = [e for e in range(EC) if cev[e] == i]
+        best = es[0]
+        for e in es[1:]:
+            if att_hard[e] * mask_hard[i] > att_hard[best] * mask_hard[i]:
+                best = e
+        idx[i] = cep[best]
+        for e in es:
+            out[i] += att_hard[e] * onehot[cep[e]]
+            soft_out[i] += att_soft[e] * onehot[cep[e]]
+        out[i] *= mask_hard[i]
+        soft_out[i] *= mask_hard[i]
+    return out, soft_out, idx
+
+
+def segment_max(v, seg_of, n_seg):
+    """torch_scatter.scatter_max as global_max_pool uses it (models.py:262-263): per segment and column the largest
+    value and the FIRST row that holds it; a segment without rows gives 0 and no row."""
+    val, arg = np.zeros((n_seg, v.shape[1])), -np.ones((n_seg, v.shape[1]), dtype=np.int64)
+    for s in range(n_seg):
+        rows = [i for i in range(v.shape[0]) if seg_of[i] == s]
+        for h in range(v.shape[1]):
+            for i in rows:
+                if arg[s, h] < 0 or v[i, h] > val[s, h]:
+                    val[s, h], arg[s, h] = v[i, h], i
+    return val, arg
+
+
+def _mlp2(seq, x):
+    (W1, b1), (W2, b2) = _lin(seq[0]), _lin(seq[1])
+    return W2 @ (W1 @ x + b1) + b2                       # act = "": no activation (train.py:65 for WGAN-GP)
+
+
+def discriminator_forward(D, label):
+    """models.py:215-229 + 260-264: [feature_enc(rest) + pe[level] | label_enc(label)], layer_num residual D-flavour
+    blocks, max over each story / each graph, the two decoders.  Returns (building [B], story [S])."""
+    gnn = D.voxelGNN_D
+    pos, rest = _split_feature()
+    Wf, bf = _lin(gnn.feature_enc[0])
+    Wl, bl = _lin(gnn.label_enc[0])
+    pe = position_table(Wf.shape[0])
+    v = np.stack([np.concatenate([Wf @ rest[i] + bf + pe[FLOOR_LEVEL[i]], Wl @ label[i] + bl]) for i in range(NV)])
+    for _ in range(gnn.layer_num):
+        v = v + voxel_block(gnn.block, v, pos)
+    story, _ = segment_max(v, EXPECT["voxel_floor_cluster"], S)
+    graph, _ = segment_max(v, EXPECT["voxel_feature_batch"], NB)
+    return (np.array([_mlp2(D.building_dec, graph[g])[0] for g in range(NB)]),
+            np.array([_mlp2(D.story_dec, story[s])[0] for s in range(S)]))
+
+
+def program_ratio(att, mask, area_col=6):
+    """util_graph.py:21-41: masked voxel area -> cross edge -> program node -> (graph, class) slot -> graph."""
+    cep, cev = EXPECT["cross_edge_program_index_select"], EXPECT["cross_edge_voxel_index_select"]
+    area = batched_voxel_feature().astype(np.float64)[:, area_col]
+    slots, slot_graph = EXPECT["program_class_cluster"], EXPECT["program_target_ratio_batch"]
+    program_weight = np.zeros(NP)
+    for e in range(EC):
+        program_weight[cep[e]] += att[e] * (mask[cev[e]] * area[cev[e]])
+    class_weight = np.zeros(len(slot_graph))
+    for p in range(NP):
+        class_weight[slots[p]] += program_weight[p]
+    far = np.zeros(NB)
+    for s, g in enumerate(slot_graph):
+        far[g] += class_weight[s]
+    ratio = np.array([class_weight[s] / (far[slot_graph[s]] + 1e-16) for s in range(len(slot_graph))])
+    return ratio, program_weight, far
+
+
+def gp_sample(label, out, u):
+    """losses.py:76-79: hard one-hot of the interpolate (straight-through VALUES), zero where the interpolate is."""
+    sample = np.zeros_like(label)
+    for i in range(NV):
+        mixed = label[i] * u[i] + out[i] * (1.0 - u[i])
+        hard = np.zeros(6)
+        hard[int(np.argmax(mixed))] = 1.0                 # torch.max: first index on ties
+        sample[i] = straight_through(hard, mixed) * (1.0 if mixed.max() != 0 else 0.0)
+    return sample
+
+
+def gradient_penalty(D, label, out, u, h=1e-6):
+    """losses.py:81-87 with the two gradients taken by central differences of the summed outputs (the discriminator
+    is piecewise linear in its label input, so the differences are exact up to float64 rounding away from a switch of
+    a max): mean over voxels of (|d sum(D_b) / d sample_i|_2 - 1)^2, the same for the story output, and their sum."""
+    sample = gp_sample(label, out, u)
+    gb, gs = np.zeros_like(sample), np.zeros_like(sample)
+    for i in range(NV):
+        for c in range(6):
+            up, dn = sample.copy(), sample.copy()
+            up[i, c] += h
+            dn[i, c] -= h
+            (bu, su), (bd, sd) = discriminator_forward(D, up), discriminator_forward(D, dn)
+            gb[i, c] = (bu.sum() - bd.sum()) / (2 * h)
+            gs[i, c] = (su.sum() - sd.sum()) / (2 * h)
+    gp_b = np.mean((np.sqrt((gb ** 2).sum(1)) - 1.0) ** 2)
+    gp_s = np.mean((np.sqrt((gs ** 2).sum(1)) - 1.0) ** 2)
+    return gp_b + gp_s, gp_b, gp_s, sample

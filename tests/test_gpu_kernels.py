@@ -156,11 +156,12 @@ def test_prefetched_plan_equals_direct_build_and_orders_the_consumer(cuda):
     P.prefetch_plan(_drop(g))
     g.to(cuda)
     assert "_bg_plan_pending" not in g.__dict__ and "_bg_plan" not in g.__dict__
-    # no story count on the batch: the synchronous form, with the event the consumer waits for
+    # no story count on the batch: the synchronous form, built on the CURRENT stream (it starts with a read-back, so
+    # nothing would overlap, and its tensors must belong to the stream whose kernels read them)
     g.__dict__.pop("num_stories", None)
     pre = P.prefetch_plan(g)
-    assert pre is not None and "_ready_event" in pre.ops
-    assert P.build_plan(g) is pre and "_ready_event" not in pre.ops
+    assert pre is not None and "_ready_event" not in pre.ops
+    assert P.build_plan(g) is pre
     _same({k: v for k, v in pre.ops.items() if k != "_arenas"}, b, "plan", set())
     # bad indices surface when the pending plan is finished
     bad = _batch("small", 3, True).to(cuda)
@@ -169,6 +170,68 @@ def test_prefetched_plan_equals_direct_build_and_orders_the_consumer(cuda):
         assert P.prefetch_plan(bad) is None
         with pytest.raises(Exception, match="non-decreasing"):
             P.build_plan(bad)
+
+
+def test_prefetched_plan_waits_for_a_non_blocking_copy_from_pinned_memory(cuda):
+    """A loader hands over pinned host tensors and copies them with non_blocking=True: the host runs ahead of the copy
+    engine.  prefetch_plan's side stream must order itself behind the batch's copies (the event VolumeDesignGraph.to
+    leaves behind them) -- otherwise k_hist_b reads index vectors that have not arrived."""
+    import copy
+    from building_gan_amd import ops, plan as P
+    cpu = _batch("dataset", 11, "jitter")
+    direct = P.build_plan(copy.deepcopy(cpu).to(cuda))
+    want = {k: v for k, v in direct.ops.items() if k != "_arenas"}
+    x = torch.rand(direct.Nv, 128, device=cuda)
+    filler = torch.empty(1 << 26, dtype=torch.uint8).pin_memory()
+    sink = torch.empty(1 << 26, dtype=torch.uint8, device=cuda)
+    for rep in range(4):
+        b = copy.deepcopy(cpu).pin_memory()
+        assert b.voxel_edge.is_pinned()
+        # work queued in front: a 64 MiB upload on the same stream (the batch's copies wait behind it) and kernels
+        sink.copy_(filler, non_blocking=True)
+        for _ in range(8):
+            ops.spmm_raw(direct.vox_mean, x)
+        b.to(cuda, non_blocking=True)
+        assert "_bg_h2d_event" in b.__dict__
+        assert P.prefetch_plan(b) is None and "_bg_plan_pending" in b.__dict__
+        got = P.build_plan(b)
+        _same({k: v for k, v in got.ops.items() if k != "_arenas"}, want, "plan[%d]" % rep, set())
+    # a blocking move leaves no event and the side stream waits for the whole current stream instead
+    b = copy.deepcopy(cpu).to(cuda)
+    assert "_bg_h2d_event" not in b.__dict__
+    assert P.prefetch_plan(b) is None
+    _same({k: v for k, v in P.build_plan(b).ops.items() if k != "_arenas"}, want, "plan[blocking]", set())
+    torch.cuda.synchronize()
+
+
+def test_prefetch_of_the_piece_by_piece_plan_stays_on_the_current_stream(cuda, monkeypatch):
+    """With the one-call build switched off (or declined) prefetch_plan builds synchronously on the current stream:
+    every plan tensor then belongs to the stream whose kernels read it, so dropping the plan while those kernels are
+    still queued cannot hand its blocks to a later prefetch on another stream."""
+    from building_gan_amd import ops, plan as P
+    monkeypatch.setattr(P, "ONE_CALL_BUILD", False)
+    g = _batch("small", 6, "jitter").to(cuda)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # "the current stream" need not be the default one
+        p = P.prefetch_plan(g)
+        assert p is not None and "_arenas" not in p.ops and "_ready_event" not in p.ops
+        assert "_bg_plan_pending" not in g.__dict__ and g.__dict__["_bg_plan"] is p
+        x = torch.rand(p.Nv, 128, device=cuda)
+        first = ops.spmm_raw(p.vox_mean, x)
+        # drop the plan with kernels that read it still queued, build another batch's plan, run the first result again
+        rowptr, col = p.vox_mean.csr.rowptr.clone(), p.vox_mean.csr.col.clone()
+        for _ in range(50):
+            ops.spmm_raw(p.vox_mean, x)
+        last = ops.spmm_raw(p.vox_mean, x)
+        g.__dict__.pop("_bg_plan")
+        del p
+        other = _batch("small", 7, "jitter").to(cuda)
+        P.prefetch_plan(other)
+        assert torch.equal(first, last)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert int(rowptr[-1]) == col.numel()
 
 
 def _drop(g):
