@@ -27,6 +27,24 @@ static inline int bg_tune_int(const char* name, int dflt) { const char* e = gete
 static inline constexpr int bg_tune_int(const char*, int dflt) { return dflt; }
 #endif
 
+// Zero fills and device-to-device copies go through bg_zero_bytes / bg_copy2d_bytes (optim.hip, include/bgan.h):
+// KERNELS of this library, never hipMemsetAsync / hipMemcpy(2D)Async.  Those become memset / memcpy NODES under stream
+// capture, and on this stack (ROCm 7.2, gfx950) a replayed graph was seen to run such a node out of order with the
+// kernel nodes around it when other work had been queued on the stream between two graph launches: the coefficient
+// table of bg_d_coef_forward_f32 came out zeroed AFTER its first rows were written (tools/lab/nan_probe3.py;
+// DESIGN.md section 6, round 3).  Kernel nodes keep their order.
+static inline hipError_t bg_zero_async(void* p, size_t bytes, hipStream_t s) {
+    return bg_zero_bytes(p, (int64_t)bytes, (bgStream)s) == BG_OK ? hipSuccess : hipErrorLaunchFailure;
+}
+static inline hipError_t bg_copy2d_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows,
+                                         hipStream_t s) {
+    return bg_copy2d_bytes(dst, (int64_t)dpitch, src, (int64_t)spitch, (int64_t)width, (int64_t)rows, (bgStream)s) == BG_OK
+               ? hipSuccess : hipErrorLaunchFailure;
+}
+static inline hipError_t bg_copy_async(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    return bg_copy2d_async(dst, bytes, src, bytes, bytes, 1, s);
+}
+
 static inline bool bg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static inline int bg_grid_for(int64_t work, int per_block, int cap = 1 << 20) {

@@ -185,8 +185,8 @@ int d_coef_forward_impl(const float* fe_w, const float* fe_b, const float* le_w,
     if (basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB) return BG_ERR_ARG;
     const int64_t H2 = 2 * H, du = ds + dl, N = (L + 1) * du, S = N + du;
     hipStream_t st = (hipStream_t)s;
-    BG_HIP(hipMemsetAsync(xall, 0, sizeof(float) * (size_t)((L + 1) * S * H2), st));
-    BG_HIP(hipMemsetAsync(efull, 0, sizeof(float) * (size_t)(N * H2), st));
+    BG_HIP(bg_zero_async(xall, sizeof(float) * (size_t)((L + 1) * S * H2), st));
+    BG_HIP(bg_zero_async(efull, sizeof(float) * (size_t)(N * H2), st));
     BG_TRY(bg_d_coef_init_strided_f32(fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, ld_bc, H, nf, nl, ML, ds, dl, xall + du * H2,
                                       efull, s));
     for (int64_t m = 0; m < L; ++m) {
@@ -218,12 +218,11 @@ int d_coef_backward_impl(const float* g, const float* xall, const float* Wc, int
     const int64_t H2 = 2 * H, du = ds + dl, N = (L + 1) * du, S = N + du;
     hipStream_t st = (hipStream_t)s;
     // G^m at rows [0, N) of slab m, du zero rows below it (the shift-up view reads them)
-    BG_HIP(hipMemsetAsync(gall, 0, sizeof(float) * (size_t)((L + 1) * S * H2), st));
-    BG_HIP(hipMemcpyAsync(gall + L * S * H2, g, sizeof(float) * (size_t)(N * H2), hipMemcpyDeviceToDevice, st));
+    BG_HIP(bg_zero_async(gall, sizeof(float) * (size_t)((L + 1) * S * H2), st));
+    BG_HIP(bg_copy_async(gall + L * S * H2, g, sizeof(float) * (size_t)(N * H2), st));
     // Wab = [Wc[:, :2H]; Wc[:, 2H:4H]]  ([4H, 2H]): G Wa + shiftup(G) Wb
-    BG_HIP(hipMemcpy2DAsync(wab, sizeof(float) * H2, Wc, sizeof(float) * ldw, sizeof(float) * H2, H2, hipMemcpyDeviceToDevice, st));
-    BG_HIP(hipMemcpy2DAsync(wab + H2 * H2, sizeof(float) * H2, Wc + H2, sizeof(float) * ldw, sizeof(float) * H2, H2,
-                            hipMemcpyDeviceToDevice, st));
+    BG_HIP(bg_copy2d_async(wab, sizeof(float) * H2, Wc, sizeof(float) * ldw, sizeof(float) * H2, H2, st));
+    BG_HIP(bg_copy2d_async(wab + H2 * H2, sizeof(float) * H2, Wc + H2, sizeof(float) * ldw, sizeof(float) * H2, H2, st));
     for (int64_t m = L - 1; m >= 0; --m) {
         const float* nxt = gall + (m + 1) * S * H2;
         if (basis == BG_CHAIN_CHEB) {                                   // second operand = the adjoint shift of G^{m+1}

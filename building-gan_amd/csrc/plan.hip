@@ -466,7 +466,7 @@ int bg_plan_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N,
     if (E > 0 && (!key || !col || !perm)) return BG_ERR_ARG;        /* other == NULL: slot k points at row perm[k] */
     if (E >= (int64_t)1 << 31 || N >= ((int64_t)1 << 31) - 1) return BG_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    BG_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (N + 1), s));
+    BG_HIP(bg_zero_async(rowptr, sizeof(int32_t) * (N + 1), s));
     if (E > 0) {
         k_hist<<<bg_grid_for(E, 256, 2048), 256, 0, s>>>(key, E, N, rowptr, flags);
         BG_LAUNCH_CHECK();
@@ -474,7 +474,7 @@ int bg_plan_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N,
     k_scan_inplace<<<1, 1024, 0, s>>>(rowptr, N + 1);
     BG_LAUNCH_CHECK();
     if (E > 0) {
-        BG_HIP(hipMemcpyAsync(cursor, rowptr, sizeof(int32_t) * (N + 1), hipMemcpyDeviceToDevice, s));
+        BG_HIP(bg_copy_async(cursor, rowptr, sizeof(int32_t) * (N + 1), s));
         k_place<<<bg_grid_for(E, 256, 2048), 256, 0, s>>>(key, E, N, cursor, perm, flags);
         BG_LAUNCH_CHECK();
         // cursor is free again after placement: it becomes the work list of long rows
@@ -494,7 +494,7 @@ int bg_plan_segptr(const int64_t* seg_id, int64_t n, int64_t nseg, int32_t* ptr,
     if (n >= (int64_t)1 << 31) return BG_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
-        BG_HIP(hipMemsetAsync(ptr, 0, sizeof(int32_t) * (nseg + 1), s));
+        BG_HIP(bg_zero_async(ptr, sizeof(int32_t) * (nseg + 1), s));
         return BG_OK;
     }
     k_segptr<<<bg_grid_for(n, 256), 256, 0, s>>>(seg_id, n, nseg, ptr, flags);
@@ -633,7 +633,7 @@ int bg_plan_build(const bgPlanIn* in, int32_t* ai, float* af, bgStream stream) {
     auto g1 = [](int64_t n) { return bg_grid_for(n, 256); };
 
     // 1. everything that starts at zero (row pointers, story -> graph tables, flags)
-    BG_HIP(hipMemsetAsync(ai, 0, sizeof(int32_t) * L.zero_end, s));
+    BG_HIP(bg_zero_async(ai, sizeof(int32_t) * L.zero_end, s));
     // 2. story -> graph (the key of build 8) and the first-floor table
     k_story_graph<<<g1(Nv > B ? Nv : B), 256, 0, s>>>(p.vfc, p.vbi, Nv, S, sg64, I(BGP_STORYGRAPH32), I(BGP_FIRST), B);
     BG_LAUNCH_CHECK();

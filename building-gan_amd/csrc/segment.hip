@@ -1171,9 +1171,9 @@ int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, const in
         return BG_OK;
     }
     if (ldo == H) {
-        BG_HIP(hipMemsetAsync(out, 0, sizeof(float) * n_rows * H, s));
+        BG_HIP(bg_zero_async(out, sizeof(float) * n_rows * H, s));
     } else {
-        BG_HIP(hipMemset2DAsync(out, sizeof(float) * ldo, 0, sizeof(float) * H, n_rows, s));
+        for (int64_t r = 0; r < n_rows; ++r) BG_HIP(bg_zero_async(out + r * ldo, sizeof(float) * H, s));   // (pitched output: never on the step's path)
     }
     if (n_seg == 0) return BG_OK;
     k_scatter_arg<<<bg_grid_for(n_seg * H, 256, 0x7fffffff), 256, 0, s>>>(g, ldg, arg, out, ldo, n_seg, (int)H);

@@ -254,7 +254,10 @@ class Trainer:
         with torch.no_grad():
             for buf, t in zip(self._g_derived, self.generator.voxelGNN.derived_weights()):
                 if buf is not None:
-                    buf.copy_(t)
+                    # an elementwise KERNEL, not copy_(): a contiguous device-to-device copy_ is a memcpy node under
+                    # stream capture, and memset / memcpy nodes were seen to run out of order in replayed graphs on
+                    # this stack (csrc/common.h, bg_zero_async); x * 1 keeps every bit pattern of finite values
+                    torch.mul(t, 1.0, out=buf)
 
     # ------------------------------------------------------------------ objectives
     # reference losses.py:14-35 / 52-61 with every mean written as (local sum) / (global count), so that the

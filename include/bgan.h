@@ -758,6 +758,15 @@ int bg_gloss_head_backward_f32(const bgCriticHead* h, int64_t n_lab, const float
 
 /* ------------------------------------------------------------------ optimiser ----------- */
 
+/* Zero fill and strided device-to-device copy as KERNELS (sizes and pitches in bytes, multiples of 4; 4-byte aligned
+ * pointers; `width` bytes of each of `rows` rows).  NO COUNTERPART IN THE REFERENCE: they stand where the composite
+ * entry points would otherwise call hipMemsetAsync / hipMemcpy2DAsync, which turn into memset / memcpy graph nodes
+ * under stream capture -- on ROCm 7.2 / gfx950 a replayed graph was seen to run such a node out of order with its
+ * neighbouring kernel nodes (csrc/common.h).  Callers that capture this library's calls should use them likewise. */
+int bg_zero_bytes(void* p, int64_t bytes, bgStream stream);
+int bg_copy2d_bytes(void* dst, int64_t dpitch, const void* src, int64_t spitch, int64_t width, int64_t rows,
+                    bgStream stream);
+
 /* One Adam step on a flat fp32 buffer (torch.optim.Adam semantics, no weight decay/amsgrad):
  * m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * t = step, or *step_dev (a device int32) when step_dev is not NULL, so that a captured hipGraph

@@ -97,12 +97,8 @@ int bg_d_compose_bwd_finish_f32(const float* gp, const float* gwm_ext, int64_t H
     rec(36, a, sizeof(a) / 8);
     return 0;
 }
-// device-to-device copies of the coefficient composites
-int hipMemcpyAsync(void* dst, const void* src, size_t bytes, int, void*) {
-    int64_t a[] = {P(dst), (int64_t)bytes, P(src), (int64_t)bytes, (int64_t)bytes, 1};
-    rec(20, a, sizeof(a) / 8);
-    return 0;
-}
+// device-to-device copies and zero fills of the coefficient composites (the library's own kernels: bg_copy2d_bytes
+// / bg_zero_bytes, never hipMemcpy*Async / hipMemsetAsync -- see csrc/common.h)
 int bg_cheb_shift_f32(const float* x, float* out, int64_t K, int64_t K_out, int64_t block_floats, int32_t transpose, bgStream) {
     int64_t a[] = {P(x), P(out), K, K_out, block_floats, transpose};
     rec(29, a, sizeof(a) / 8);
@@ -252,14 +248,13 @@ int bg_pack_columns_f32(const float* const* src, const int64_t* ld, int n_src, i
     rec(20, a, sizeof(a) / 8);
     return (n_src == 1 && group >= C) ? 0 : -1;
 }
-int hipMemsetAsync(void* dst, int value, size_t bytes, void*) {
-    int64_t a[] = {P(dst), value, (int64_t)bytes};
+int bg_zero_bytes(void* dst, int64_t bytes, bgStream) {
+    int64_t a[] = {P(dst), 0, bytes};
     rec(25, a, sizeof(a) / 8);
     return 0;
 }
-// the one HIP runtime call the critic composites make themselves (a strided device-to-device copy)
-int hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int, void*) {
-    int64_t a[] = {P(dst), (int64_t)dpitch, P(src), (int64_t)spitch, (int64_t)width, (int64_t)height};
+int bg_copy2d_bytes(void* dst, int64_t dpitch, const void* src, int64_t spitch, int64_t width, int64_t rows, bgStream) {
+    int64_t a[] = {P(dst), dpitch, P(src), spitch, width, rows};
     rec(20, a, sizeof(a) / 8);
     return 0;
 }

@@ -245,6 +245,47 @@ def test_graph_capture_replays_and_restores_state(cuda):
         assert torch.equal(kept, now)
 
 
+def test_graph_replays_stay_finite_and_do_not_depend_on_work_queued_between_segments(cuda):
+    """Regression (round 3).  The captured iteration used to contain hipMemsetAsync / hipMemcpy2DAsync nodes (the
+    coefficient recurrence's zero fills); replayed after a synchronisation and ANY eager kernel on the stream, the
+    table came out zeroed -- g_adv 0.068 instead of -20.99 -- and the second replay of the generator-update graph
+    went NaN.  Fills and copies are kernels of the library now (bg_zero_bytes / bg_copy2d_bytes)."""
+    from building_gan_amd.synthetic import make_batch
+    from building_gan_amd.train import Trainer
+
+    def run(disturb, n_iter):
+        batch = make_batch("small", seed=3, ragged=True).to(cuda)
+        torch.manual_seed(0)
+        tr = Trainer(cuda)
+        tr.capture(batch)
+        seen = []
+        for i in range(n_iter):
+            if i % tr.n_critic_g == 0:
+                gA, gB, gC, stats = tr._graphs["with_g"]
+                segs = (gA, gB, gC)
+            else:
+                gA, gB, stats = tr._graphs["no_g"]
+                segs = (gA, gB)
+            for g in segs:
+                g.replay()
+                if disturb:
+                    torch.cuda.synchronize()
+                    junk = [torch.full((1 + 37 * k,), float("nan"), device=cuda) for k in range(8)]
+                    del junk
+            torch.cuda.synchronize()
+            seen.append({k: v.clone() for k, v in stats.items()})
+        return seen, tr.opt_d.flat.clone(), tr.opt_g.flat.clone()
+
+    plain, d0, g0 = run(False, 11)
+    mixed, d1, g1 = run(True, 11)
+    for i, (a, b) in enumerate(zip(plain, mixed)):
+        for k in a:
+            assert torch.isfinite(a[k]).all(), (i, k, a[k])
+            assert torch.equal(a[k], b[k]), (i, k, a[k], b[k])
+    assert torch.isfinite(d0).all() and torch.isfinite(g0).all()
+    assert torch.equal(d0, d1) and torch.equal(g0, g1)
+
+
 def test_isolated_voxel_falls_back_to_two_linear_path(cuda):
     """A 1x1x1 building has a voxel without in-edges: mean aggregation gives 0 there (not W x_i + b),
     so the composed-weight shortcut is illegal and the literal two-Linear path must be taken."""
