@@ -128,3 +128,187 @@ def test_hip_layers_match_float64_loops_over_the_literal_batch(cuda):
                                rtol=1e-4, atol=2e-5)
     mask, att, nv = at(xd, vd.clone().requires_grad_(True), plan, (em.to(cuda), ea.to(cuda)))
     _check_attention(mask, att, nv, want, 1e-4)
+
+
+# ---------------------------------------------------------------- round 3: whole networks against the loops
+# (VERDICT round 2, item 4): Generator.forward with 12 voxel layers (attention before the layers and after layers
+# 2, 4, 6, 8, 10; the LAST call's mask / att go to construct_output), DiscriminatorVoxel.forward with both max pools,
+# get_program_ratio, and the gradient penalty's value against central differences in float64.
+N_ATT_CALLS = 6
+
+
+def _generator_inputs(noise_dim, seed=13):      # (seed 13: one voxel of the last attention call is masked, at H = 8 and H = 128)
+    g = torch.Generator().manual_seed(seed)
+    pz = torch.rand(K.NP, noise_dim, generator=g)
+    vz = torch.rand(K.NV, noise_dim, generator=g)
+    noise = [(torch.empty(K.NV, 2).exponential_(generator=g), torch.empty(K.EC).exponential_(generator=g))
+             for _ in range(N_ATT_CALLS)]
+    return pz, vz, noise
+
+
+def _np64(t):
+    return t.detach().cpu().double().numpy()
+
+
+def _check_generator(got, want, tol):
+    out, soft_out, mask, att, idx = got
+    w_out, w_soft, ms, mw, soft, arg, w_idx, calls = want
+    assert calls == N_ATT_CALLS
+    hard = mask["hard"].detach().cpu().numpy().reshape(-1).round()
+    assert hard.tolist() == [1.0 if w == 0 else 0.0 for w in mw]
+    hot = att["hard"].detach().cpu().numpy().reshape(-1).round()
+    assert sorted(np.nonzero(hot)[0].tolist()) == sorted(arg.tolist())                 # the pointer, bit-exact
+    assert idx.detach().cpu().tolist() == w_idx.tolist()                               # program node per voxel
+    np.testing.assert_allclose(_np64(mask["soft"]).reshape(-1), ms, rtol=tol, atol=tol)
+    np.testing.assert_allclose(_np64(att["soft"]).reshape(-1), soft, rtol=tol, atol=tol)
+    np.testing.assert_allclose(_np64(out), w_out, rtol=tol, atol=tol)
+    np.testing.assert_allclose(_np64(soft_out), w_soft, rtol=tol, atol=tol)
+    # a masked voxel has an all-zero label row and points at the FIRST program node of its story
+    cep, cev = K.EXPECT["cross_edge_program_index_select"], K.EXPECT["cross_edge_voxel_index_select"]
+    for i, w in enumerate(mw):
+        if w != 0:
+            assert not w_out[i].any() and w_idx[i] == cep[cev.index(i)]
+
+
+def test_oracle_generator_matches_float64_loops_over_the_literal_batch():
+    from oracle import networks as om
+    b = _batch()
+    torch.manual_seed(5)
+    G = om.Generator(7, 7, 8, 4, 4, 12)
+    pz, vz, noise = _generator_inputs(4)
+    want = K.generator_forward(G, _np64(pz), [(_np64(a), _np64(c)) for a, c in noise])
+    _check_generator(G(b, pz, vz, noise), want, 2e-5)
+    # the mask really is exercised both ways on this batch and seed
+    assert 0 < sum(1 for w in want[3] if w != 0) < K.NV
+
+
+def _labels(seed=2):
+    g = torch.Generator().manual_seed(seed)
+    lab = torch.zeros(K.NV, 6)
+    lab[torch.arange(K.NV), torch.randint(0, 6, (K.NV,), generator=g)] = 1.0
+    lab[3] = 0.0                                                           # void voxels: all-zero rows
+    lab[1] = 0.0
+    soft = torch.rand(K.NV, 6, generator=g)
+    soft = soft / soft.sum(1, keepdim=True)
+    soft[3] = 0.0                                                          # void AND masked: the interpolate is zero
+    soft[5] = 0.0                                                          # masked, labelled
+    u = torch.rand(K.NV, 1, generator=g)
+    return lab, soft, u
+
+
+def test_oracle_discriminator_program_ratio_and_penalty_match_float64_loops():
+    from oracle import networks as om
+    from oracle.objectives import compute_gradient_penalty
+    from oracle.pointer import get_program_ratio
+    b = _batch()
+    torch.manual_seed(6)
+    D = om.DiscriminatorVoxel(7, 6, 8, 12)
+    lab, soft, u = _labels()
+    vb, vs = D(b, lab)
+    wb, ws = K.discriminator_forward(D, _np64(lab))
+    np.testing.assert_allclose(_np64(vb).reshape(-1), wb, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(_np64(vs).reshape(-1), ws, rtol=2e-5, atol=2e-6)
+    # area pipeline on a hard attention / mask (values 0 / 1 as the generator's straight-through outputs round to)
+    g = torch.Generator().manual_seed(9)
+    att = torch.zeros(K.EC, 1)
+    cev = K.EXPECT["cross_edge_voxel_index_select"]
+    for i in range(K.NV):
+        es = [e for e in range(K.EC) if cev[e] == i]
+        att[es[int(torch.randint(0, len(es), (1,), generator=g))]] = 1.0
+    mask = (torch.rand(K.NV, 1, generator=g) > 0.3).float()
+    ratio, pw, far = get_program_ratio(b, att, mask, 6)
+    w_ratio, w_pw, w_far = K.program_ratio(_np64(att).reshape(-1), _np64(mask).reshape(-1))
+    np.testing.assert_allclose(_np64(ratio).reshape(-1), w_ratio, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(_np64(pw).reshape(-1), w_pw, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(_np64(far).reshape(-1), w_far, rtol=1e-6, atol=1e-7)
+    # gradient penalty: autograd's double-backward value against central differences of the float64 loops
+    gp, gp_b, gp_s = compute_gradient_penalty(D, b, lab, soft, u)
+    w_gp, w_b, w_s, sample = K.gradient_penalty(D, _np64(lab), _np64(soft), _np64(u).reshape(-1))
+    # zero interpolate -> zero row (losses.py:78); a void label with a soft output, or a label with a masked output -> one-hot
+    assert not sample[3].any() and sample[1].max() > 0.999 and sample[5].max() > 0.999
+    np.testing.assert_allclose([float(gp), float(gp_b), float(gp_s)], [w_gp, w_b, w_s], rtol=2e-4)
+
+
+def test_max_pool_tie_and_negative_story_literal():
+    """models.py:262-263 through torch_scatter's rules: first row wins a tie, a story whose values are all negative
+    keeps its (negative) maximum -- zero belongs to EMPTY segments only."""
+    from oracle.scatter import scatter_max
+    b = _batch()
+    v = torch.tensor([[1.0, -2.0], [1.0, -3.0], [0.5, 0.25], [-4.0, -1.0], [-5.0, -1.0], [-4.5, -7.0], [2.0, 2.0]])
+    val, arg = scatter_max(v, b.voxel_floor_cluster, dim_size=K.S)
+    w_val, w_arg = K.segment_max(v.double().numpy(), K.EXPECT["voxel_floor_cluster"], K.S)
+    assert np.array_equal(val.double().numpy(), w_val) and np.array_equal(arg.numpy(), w_arg)
+    assert w_arg[0].tolist() == [0, 0] and w_val[3].tolist() == [-4.5, -1.0] and w_arg[3].tolist() == [5, 4]
+    gval, garg = scatter_max(v, b.voxel_feature_batch, dim_size=K.NB)
+    w_val, w_arg = K.segment_max(v.double().numpy(), K.EXPECT["voxel_feature_batch"], K.NB)
+    assert np.array_equal(gval.double().numpy(), w_val) and np.array_equal(garg.numpy(), w_arg)
+
+
+@pytest.mark.gpu
+def test_hip_generator_matches_float64_loops_over_the_literal_batch(cuda):
+    from building_gan_amd import models as hm
+    b = copy.deepcopy(_batch()).to(cuda)
+    torch.manual_seed(5)
+    G = hm.Generator(7, 7, 128, 32, 4, 12, cuda).to(cuda)
+    pz, vz, noise = _generator_inputs(32)
+    want = K.generator_forward(G, _np64(pz), [(_np64(a), _np64(c)) for a, c in noise])
+    dn = [(a.to(cuda), c.to(cuda)) for a, c in noise]
+    with torch.no_grad():                                                  # the graph-free forward (one host call)
+        _check_generator(G(b, pz.to(cuda), vz.to(cuda), dn), want, 1e-4)
+    _check_generator(G(b, pz.to(cuda), vz.to(cuda), dn), want, 1e-4)       # under autograd (the generator update's nodes)
+    assert 0 < sum(1 for w in want[3] if w != 0) < K.NV
+
+
+@pytest.mark.gpu
+def test_hip_discriminator_program_ratio_and_penalty_match_float64_loops(cuda):
+    from building_gan_amd import models as hm
+    from building_gan_amd.losses import compute_gradient_penalty
+    from building_gan_amd.plan import build_plan
+    from building_gan_amd.util_graph import get_program_ratio
+    b = copy.deepcopy(_batch()).to(cuda)
+    torch.manual_seed(6)
+    D = hm.DiscriminatorVoxel(7, 6, 128, 12).to(cuda)
+    lab, soft, u = _labels()
+    wb, ws = K.discriminator_forward(D, _np64(lab))
+    with torch.no_grad():
+        vb, vs = D(b, lab.to(cuda))                                        # collapsed (polynomial) evaluation
+        np.testing.assert_allclose(_np64(vb).reshape(-1), wb, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(_np64(vs).reshape(-1), ws, rtol=1e-4, atol=1e-5)
+        hm.COLLAPSE_D = False
+        try:
+            vb, vs = D(b, lab.to(cuda))                                    # layer by layer
+        finally:
+            hm.COLLAPSE_D = True
+        np.testing.assert_allclose(_np64(vb).reshape(-1), wb, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(_np64(vs).reshape(-1), ws, rtol=1e-4, atol=1e-5)
+    g = torch.Generator().manual_seed(9)
+    att = torch.zeros(K.EC, 1)
+    cev = K.EXPECT["cross_edge_voxel_index_select"]
+    for i in range(K.NV):
+        es = [e for e in range(K.EC) if cev[e] == i]
+        att[es[int(torch.randint(0, len(es), (1,), generator=g))]] = 1.0
+    mask = (torch.rand(K.NV, 1, generator=g) > 0.3).float()
+    ratio, pw, far = get_program_ratio(b, att.to(cuda), mask.to(cuda), 6)
+    w_ratio, w_pw, w_far = K.program_ratio(_np64(att).reshape(-1), _np64(mask).reshape(-1))
+    np.testing.assert_allclose(_np64(ratio).reshape(-1), w_ratio, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(_np64(pw).reshape(-1), w_pw, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(_np64(far).reshape(-1), w_far, rtol=1e-5, atol=1e-6)
+    w_gp, w_b, w_s, _ = K.gradient_penalty(D, _np64(lab), _np64(soft), _np64(u).reshape(-1))
+    gp, gp_b, gp_s = compute_gradient_penalty(D, b, lab.to(cuda), soft.to(cuda), u.to(cuda))     # reference-shaped API
+    np.testing.assert_allclose([float(gp), float(gp_b), float(gp_s)], [w_gp, w_b, w_s], rtol=1e-3)
+    # pooling: tie -> first row, a story of negative values keeps its negative maximum; gradient goes to the winner
+    plan = build_plan(b)
+    v = torch.zeros(K.NV, 128, device=cuda)
+    v[:, :2] = torch.tensor([[1.0, -2.0], [1.0, -3.0], [0.5, 0.25], [-4.0, -1.0], [-5.0, -1.0], [-4.5, -7.0], [2.0, 2.0]], device=cuda)
+    v.requires_grad_(True)
+    story, building = hm.pool_story_and_graph(v, plan)
+    w_val, w_arg = K.segment_max(_np64(v)[:, :2], K.EXPECT["voxel_floor_cluster"], K.S)
+    assert np.array_equal(_np64(story)[:, :2], w_val)
+    g_val, g_arg = K.segment_max(_np64(v)[:, :2], K.EXPECT["voxel_feature_batch"], K.NB)
+    assert np.array_equal(_np64(building)[:, :2], g_val)
+    story[:, :2].sum().backward()
+    want = np.zeros((K.NV, 2))
+    for s in range(K.S):
+        for h in range(2):
+            want[w_arg[s, h], h] += 1.0
+    assert np.array_equal(_np64(v.grad)[:, :2], want)
