@@ -219,25 +219,50 @@ def test_trainer_flat_gradients_match_oracle(cuda, preset, graphs, aux):
     torch.testing.assert_close(sh["g_loss"].cpu().view(-1), so["g_loss"].view(-1), rtol=1e-3, atol=1e-3)
     worst = {}
     for tag, grads, net in (("D", d_grads, Do), ("G", g_grads, Go)):
-        # a tensor's error is taken relative to its own largest gradient, but not below 1e-3 of the network's
-        # largest: in the linear critic every additive term (biases, position table) shifts D(real) and D(fake)
-        # alike, so its d_loss gradient is exactly zero in exact arithmetic and pure rounding noise on both sides
         top = max(float(p.grad.abs().max()) for p in net.parameters())
-        errs = {}
+        signal, minor, zero = {}, {}, {}
         for n, p in net.named_parameters():
-            scale = max(float(p.grad.abs().max()), 1e-3 * top)
-            errs[n] = float((grads[n].double() - p.grad.double()).abs().max()) / scale
-        worst[tag] = max(errs.items(), key=lambda kv: kv[1])
-        for n, e in errs.items():
-            assert e <= TRAINER_GRAD_BAR[tag], (tag, n, e)
+            own = float(p.grad.abs().max())
+            err = float((grads[n].double() - p.grad.double()).abs().max())
+            if n in STRUCTURALLY_ZERO[tag]:
+                # additive terms of the linear critic shift D(real) and D(fake) alike: the exact d_loss gradient is zero
+                # (the penalty differentiates D's input gradient, which no additive term enters), what both sides hold
+                # is rounding noise -- measured against the network's largest gradient
+                assert own <= 1e-5 * top, (tag, n, own / top)
+                zero[n] = err / top
+            elif own >= SIGNAL_SHARE * top:
+                signal[n] = err / own                 # relative to the tensor's OWN largest gradient: north_star's 1e-4
+            else:
+                minor[n] = (err / own, err / top)     # small but real gradients: a looser relative bar, a tight absolute one
+        assert signal, tag
+        worst[tag] = {"signal": max(signal.items(), key=lambda kv: kv[1]),
+                      "minor": max(minor.items(), key=lambda kv: kv[1][0]) if minor else None,
+                      "zero": max(zero.items(), key=lambda kv: kv[1]) if zero else None}
+        for n, e in signal.items():
+            assert e <= SIGNAL_GRAD_BAR, (tag, n, e)
+        for n, (e_own, e_top) in minor.items():
+            assert e_own <= MINOR_GRAD_BAR and e_top <= ZERO_GRAD_BAR, (tag, n, e_own, e_top)
+        for n, e in zero.items():
+            assert e <= ZERO_GRAD_BAR, (tag, n, e)
     if aux[0]:
         assert float(sh["tr_loss"]) > 0 and float(sh["far_loss"]) > 0
-    print("%s aux=%s: worst flat-gradient error vs the fp32 oracle %s" % (preset, aux, worst))
+    print("%s aux=%s: worst flat-gradient errors vs the fp32 oracle %s" % (preset, aux, worst))
 
 
-# measured on MI355X (pytest -s), error / max(tensor's max gradient, 1e-3 of the network's max), against the FP32
-# oracle: see DESIGN.md section 2 for the numbers; the bars are <= 10x the measured values
-TRAINER_GRAD_BAR = {"D": 1e-3, "G": 1e-3}
+# Measured on MI355X (tools/lab/grad_classes.py prints every tensor): tensors whose largest gradient
+# is >= 1e-2 of their network's largest agree with the oracle to 2.0e-5 (D) / 1.5e-5 (G) of their own maximum at dataset
+# size and 2.9e-6 / 3.2e-6 on the small preset; smaller ones to 9.5e-5 of their own and 8.5e-7 of the network's maximum;
+# the critic's bias tensors hold 1e-7 of the network's maximum on both sides (exactly zero in exact arithmetic).
+SIGNAL_SHARE = 1e-2
+SIGNAL_GRAD_BAR = 1e-4        # north_star's fp32 tolerance, relative to the tensor's own largest gradient
+MINOR_GRAD_BAR = 5e-4         # tensors below SIGNAL_SHARE: relative to their own maximum ..
+ZERO_GRAD_BAR = 1e-5          # .. and, like the structurally zero ones, relative to the network's largest gradient
+STRUCTURALLY_ZERO = {
+    "D": {"voxelGNN_D.feature_enc.0.bias", "voxelGNN_D.label_enc.0.bias", "voxelGNN_D.block.messageMLP.0.bias",
+          "voxelGNN_D.block.updateMLP.0.bias", "building_dec.0.bias", "building_dec.1.bias", "story_dec.0.bias",
+          "story_dec.1.bias"},
+    "G": set(),
+}
 
 
 def test_program_ratio_backward_parity(cuda):
