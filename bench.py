@@ -216,20 +216,22 @@ def _cpu_share():
     return max(n, 1)
 
 
-def cpu_baseline(graphs=1, budget_s=45.0):
-    """CPU oracle (pure-PyTorch restatement, literal per-edge formulation) on ``graphs`` dataset-sized buildings,
-    iterations in the reference's schedule (every 5th carries the generator update), SURVEY.md 8(d): 5 warm-up +
-    20 timed iterations on all the host threads of this job, median per iteration kind; a 5-iteration cycle costs
-    t(D+G) + 4 t(D).  The 1-thread figure runs 1 + 5 iterations (time-bounded)."""
+def cpu_baseline(graphs=8, budget_s=40.0):
+    """CPU oracle (pure-PyTorch restatement, literal per-edge formulation) on the SAME workload shape as the GPU
+    figure: one batch of ``graphs`` (8) dataset-sized buildings, iterations in the reference's schedule (every 5th
+    carries the generator update), SURVEY.md 8(d), on all the host threads of this job.  Bounded sample: one warm-up
+    iteration, then three timed ones (two critic-only, one with the generator update);
+    a 5-iteration cycle costs t(D+G) + 4 t(D), medians per kind.  The 1-thread figure is taken on ONE graph (a
+    batch-8 iteration takes ~40 s on one thread) and says so."""
     import torch
     from building_gan_amd.graph import detach_batch
     from building_gan_amd.synthetic import batch_sizes, make_batch
     from oracle.networks import DiscriminatorVoxel, Generator
     from oracle.objectives import train_iteration
-    batch = make_batch("dataset", seed=0, graphs=graphs)
-    sz = batch_sizes(batch)
 
-    def run(threads, warm, timed, budget):
+    def run(threads, n_graphs, first, count, budget):
+        batch = make_batch("dataset", seed=0, graphs=n_graphs)
+        sz = batch_sizes(batch)
         torch.set_num_threads(threads)
         torch.manual_seed(0)
         G, D = Generator(7, 7, 128, 32, 4, 12), DiscriminatorVoxel(7, 6, 128, 12)
@@ -237,32 +239,100 @@ def cpu_baseline(graphs=1, budget_s=45.0):
         od = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.999))
         t_g, t_d = [], []
         start = time.perf_counter()
-        for i in range(warm + timed):
+        # iteration indices first .. : the warm-up one is critic-only, the timed ones hold one generator update
+        for k, i in enumerate(range(first, first + 1 + count)):
             pz, vz = torch.rand(sz["Np"], 32), torch.rand(sz["Nv"], 32)
             t = time.perf_counter()
             train_iteration(G, D, og, od, batch, detach_batch, i, pz, vz, None, None)
             dt = time.perf_counter() - t
-            if i >= warm:
+            if k >= 1:
                 (t_g if i % 5 == 0 else t_d).append(dt)
             if t_g and t_d and time.perf_counter() - start > budget:
                 break
         cycle = statistics.median(t_g) + 4 * statistics.median(t_d)
-        return 5 * graphs / cycle, statistics.median(t_g), statistics.median(t_d), len(t_g) + len(t_d)
+        return 5 * n_graphs / cycle, statistics.median(t_g), statistics.median(t_d), len(t_g) + len(t_d), sz
 
     prev = torch.get_num_threads()
     cores = _cpu_share()
     try:
-        v_all, tg, td, n_all = run(cores, 5, 20, budget_s)
-        v_one, tg1, td1, n_one = run(1, 1, 6, budget_s / 2)
+        # warm-up = iteration 3, timed = 4, 5 (generator update), 6  (~5 s each on 16 EPYC threads)
+        v_all, tg, td, n_all, sz = run(cores, graphs, 3, 3, budget_s)
+        v_one, tg1, td1, n_one, sz1 = run(1, 1, 3, 2, budget_s / 2)
     finally:
         torch.set_num_threads(prev)
     return {"value": round(v_all, 4), "unit": "voxel-graphs/s", "cores": cores, "kind": "port",
-            "one_thread_value": round(v_one, 4), "cpu_model": _cpu_model(), "torch": torch.__version__,
+            "sample_graphs_per_batch": graphs, "sample_is_batch_1": graphs == 1,
+            "one_thread_value": round(v_one, 4), "one_thread_sample_graphs_per_batch": 1,
+            "cpu_model": _cpu_model(), "torch": torch.__version__,
             "timed_iterations": n_all, "timed_iterations_one_thread": n_one,
-            "sample": "%d dataset-sized graph(s) (Nv=%d, Ev=%d, Ec=%d); reference schedule, median of %d timed "
-                      "iterations after 5 warm-ups on %d threads: iteration with G update %.3fs, critic-only %.3fs; "
-                      "1 thread: %.3fs / %.3fs (%d timed); pure-PyTorch CPU oracle, literal per-edge formulation"
-                      % (graphs, sz["Nv"], sz["Ev"], sz["Ec"], n_all, cores, tg, td, tg1, td1, n_one)}
+            "sample": "one batch of %d dataset-sized graphs (Nv=%d, Ev=%d, Ec=%d: the GPU figure's batch shape); reference "
+                      "schedule, 1 warm-up + %d timed iterations on %d threads: iteration with G update %.3fs, critic-only "
+                      "%.3fs; 1 thread on ONE graph (Nv=%d): %.3fs / %.3fs (%d timed); pure-PyTorch CPU oracle, literal "
+                      "per-edge formulation (the reference itself cannot run: SURVEY.md 8c)"
+                      % (graphs, sz["Nv"], sz["Ev"], sz["Ec"], n_all, cores, tg, td, sz1["Nv"], tg1, td1, n_one)}
+
+
+def inference_figures(dev):
+    """BASELINE.md workload (1), configs[0] / configs[4]: generator inference as /root/reference/inference.py:74-82 ->
+    util_eval.evaluate runs it (forward, check_connectivity, get_program_ratio per batch) on ONE dataset-sized
+    building (batch 1), and the variation batch of a large building (8 copies of 32 stories x 64 x 64 = 1,048,576
+    voxels; reference util_eval.py:139-157).  Random-init weights of the released architecture (the timing does not
+    depend on the values; the released checkpoint's parity is tests/test_golden_gpu.py); synthetic graphs."""
+    import torch
+    from building_gan_amd.graph import Batch
+    from building_gan_amd.models import Generator
+    from building_gan_amd.plan import build_plan
+    from building_gan_amd.synthetic import batch_sizes, make_batch
+    from building_gan_amd.util_eval import check_connectivity, generate_multiple_outputs_from_batch
+    from building_gan_amd.util_graph import get_program_ratio
+    res = {}
+    torch.manual_seed(0)
+    G = Generator(7, 7, 128, 32, 4, 12, dev).to(dev).eval()
+    b = make_batch("dataset", seed=3, graphs=1).to(dev)
+    sz = batch_sizes(b)
+
+    def one(fresh_plan):
+        if fresh_plan:
+            b.__dict__.pop("_bg_plan", None)
+        with torch.no_grad():
+            pz, vz = torch.rand(sz["Np"], 32, device=dev), torch.rand(sz["Nv"], 32, device=dev)
+            out, soft, mask, att, idx = G(b, pz, vz)
+            check_connectivity(b, idx, mask["hard"])
+            get_program_ratio(b, att["hard"], mask["hard"], 6)
+
+    def wall(fn, n, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+    ms_fresh, ms_kept = wall(lambda: one(True), 30), wall(lambda: one(False), 30)
+    res["batch1"] = {"workload": "1 dataset-sized building (Nv=%d, Ev=%d, Ec=%d): generator forward + check_connectivity + "
+                                 "get_program_ratio, as util_eval.evaluate" % (sz["Nv"], sz["Ev"], sz["Ec"]),
+                     "ms_per_design": round(ms_fresh, 3), "designs_per_s": round(1e3 / ms_fresh, 1),
+                     "ms_per_design_plan_kept": round(ms_kept, 3)}
+    del b
+    Gl = Generator(7, 7, 128, 32, 4, 12, dev, max_len=32).to(dev).eval()      # 32 stories: a 32-row position table
+    variations = 8
+    big = Batch.from_data_list([make_batch("large", seed=0)] * variations).to(dev)
+    szl = batch_sizes(big)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    build_plan(big)
+    torch.cuda.synchronize()
+    plan_ms = (time.perf_counter() - t) * 1e3
+    ms = wall(lambda: generate_multiple_outputs_from_batch(big, variations, Gl, None, None, None, [dev]), 3, warm=2)
+    res["variation_batch_1M_voxels"] = {
+        "workload": "%d variations of a 32-story 64x64 building in one batch (Nv=%d, Ev=%d, Ec=%d): generator forward + "
+                    "program ratios, as util_eval.generate_multiple_outputs_from_batch" % (variations, szl["Nv"], szl["Ev"], szl["Ec"]),
+        "ms_per_batch": round(ms, 2), "voxels_per_s": round(szl["Nv"] / (ms * 1e-3), 0), "designs_per_s": round(variations / (ms * 1e-3), 1),
+        "plan_build_ms": round(plan_ms, 1), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    del big
+    torch.cuda.empty_cache()
+    return res
 
 
 # ------------------------------------------------------------------------------------ the workload
@@ -279,6 +349,13 @@ class HipWorkload:
         torch.cuda.set_device(local)
         self.dev = dev = torch.device("cuda", local)
         self.world, self.rank, self.args = world, rank, args
+        self.force_dist = bool(getattr(args, "force_dist", False)) and world == 1
+        if self.force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            from building_gan_amd import train as _train
+            _train.FORCE_COLLECTIVES = True
         if world > 1:
             backend = os.environ.get("BG_DIST_BACKEND", "nccl")  # "gloo" only to rehearse the N > 1 path on one GPU
             if backend == "nccl":
@@ -396,7 +473,9 @@ class HipWorkload:
                 "Nv_min": min(s["Nv"] for s in self.sizes), "Nv_max": max(s["Nv"] for s in self.sizes),
                 "hidden": 128, "voxel_layer": 12, "program_layer": 4, "n_critic_g": 5,
                 "parallelism": "dp%d" % self.world,
-                "launch": "eager kernels + eager RCCL all-reduce of the flat gradient buffers"}
+                "launch": "eager kernels + eager RCCL all-reduce of the flat gradient buffers",
+                "collectives": ("issued on a 1-rank RCCL group (--force-dist)" if self.force_dist else
+                                ("RCCL, %d ranks" % self.world if self.world > 1 else "none (one rank)"))}
 
     def extras(self, line):
         a = self.args
@@ -405,12 +484,14 @@ class HipWorkload:
         line["plan_build_ms"] = self.plan_build_ms()
         if self.world == 1 and not a.no_microbench:
             line["microbench"] = microbench_message_passing(self.dev)
+        if self.world == 1 and not a.no_inference:
+            line["inference"] = inference_figures(self.dev)
         if self.world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
 
     def close(self):
         import torch.distributed as dist
-        if self.world > 1:
+        if self.world > 1 or self.force_dist:
             dist.barrier()
             dist.destroy_process_group()
 
@@ -424,6 +505,10 @@ def main(argv=None):
     ap.add_argument("--batches", type=int, default=8, help="distinct batches the timed steps rotate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
+    ap.add_argument("--no-inference", action="store_true", help="skip the generator-inference figures (configs[0] / configs[4])")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: create a 1-rank process group (RCCL) and issue every collective of the "
+                         "data-parallel path anyway (train.FORCE_COLLECTIVES); the line says so")
     ap.add_argument("--no-replay", action="store_true", help="skip the fixed-batch hipGraph replay figure")
     ap.add_argument("--workload", default=None, metavar="MODULE:CLASS",
                     help="replace the HIP workload by MODULE:CLASS(args, rank, world) with the same methods "
