@@ -160,13 +160,28 @@ def global_counts(batch, group=None):
     fetched for this batch beside the previous iteration."""
     cached = batch.__dict__.pop("_bg_counts", None) if hasattr(batch, "__dict__") else None
     if cached is not None and cached[0] == _world(group):
-        return cached[1]
+        if cached[2] is not None:
+            cached[2].synchronize()       # the copy to pinned memory, queued an iteration ago: finished long since
+        return tuple(int(x) for x in cached[1].tolist())
     B, S, Nv = _local_counts(batch)
     if _collective(group):
         t = torch.tensor([B, S, Nv], dtype=torch.float64, device=batch.voxel_feature.device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         B, S, Nv = (int(x) for x in t.tolist())
     return B, S, Nv
+
+
+_PINNED_RING = []
+
+
+def _pinned_counts():
+    """A 3-element pinned buffer out of a small ring (page-locking memory per call would cost more than the copy;
+    a buffer is read one iteration after it is filled, the ring holds sixteen)."""
+    if not _PINNED_RING:
+        _PINNED_RING.extend([torch.empty(3, dtype=torch.float64, pin_memory=True) for _ in range(16)] + [0])
+    k = _PINNED_RING[-1]
+    _PINNED_RING[-1] = (k + 1) % 16
+    return _PINNED_RING[k]
 
 
 def prefetch_counts(batch, group=None):
@@ -181,13 +196,21 @@ def prefetch_counts(batch, group=None):
     if dev.type != "cuda":
         t = torch.tensor([B, S, Nv], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    else:
-        side = prefetch_stream(dev)
-        with torch.cuda.stream(side):             # (the counts come from host-side shapes: nothing of the batch is read)
-            t = torch.tensor([B, S, Nv], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            t = t.cpu()                   # waits for the side stream (and the collective it ordered behind) only
-    batch.__dict__["_bg_counts"] = (_world(group), tuple(int(x) for x in t.tolist()))
+        batch.__dict__["_bg_counts"] = (_world(group), t, None)
+        return
+    side = prefetch_stream(dev)
+    with torch.cuda.stream(side):             # (the counts come from host-side shapes: nothing of the batch is read)
+        t = torch.tensor([B, S, Nv], dtype=torch.float64, device=dev)
+        if dist.get_backend(group) == "gloo":
+            side.synchronize()                # gloo reads the buffer from the host side
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        # the host does NOT wait here: the sums travel to pinned memory behind the collective, an event marks the
+        # copy, and global_counts() -- one iteration later -- finds it finished (as plan.prefetch_plan's flags)
+        host = _pinned_counts()
+        host.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    batch.__dict__["_bg_counts"] = (_world(group), host, ev)
 
 
 class Trainer:

@@ -82,7 +82,8 @@ def _worker(rank, world, port, ret):
         from building_gan_amd.train import prefetch_counts
         direct = global_counts(mine)
         prefetch_counts(mine)
-        assert mine.__dict__["_bg_counts"] == (world, direct)
+        kept = mine.__dict__["_bg_counts"]          # (world size, the summed counts [host tensor], event or None)
+        assert kept[0] == world and tuple(int(x) for x in kept[1].tolist()) == direct and kept[2] is None
         counts = global_counts(mine)
         assert counts == direct and "_bg_counts" not in mine.__dict__
         gen, stats = tr._phase_d(mine, counts, True, *a)
