@@ -41,7 +41,7 @@ if ROOT not in sys.path:
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 
 
 # ------------------------------------------------------------------------------------ launcher
