@@ -788,6 +788,145 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_skinny(GemmArgs g) {
     }
 }
 
+// The same product for K > 256 with every K_s a multiple of 32 (the coefficient recurrence: [<= 520, 256 | 256] x
+// [512, 256]).  k_gemm_skinny's fragment-shaped loads ask for 32 different 128-byte lines per instruction and use 32
+// bytes of each; with ~20 such loads per lane and 8 waves the CU's address / tag path (not the bytes) is what the
+// kernel waits for: 3.1 of its 6.9 us (ablations in DESIGN.md section 6, round 3).  Here a wave owns whole 32-k
+// CHUNKS (one 128-byte line per operand row): it loads a chunk by full lines (8 lanes per row, 8 rows per
+// instruction), turns it into MFMA fragments through a wave-private LDS tile -- LDS instructions of one wave execute
+// in order, so no workgroup barrier is involved -- and multiplies.  Chunks go to waves round robin (wave, wave + 8, ..),
+// two in flight per wave, so with two equal segments every wave carries one plain and one shifted chunk.
+// Epilogue operands are requested before the K loop.  k order inside a chunk as in k_gemm_skinny's groups.
+template <bool B_KC>
+__global__ __launch_bounds__(512) void k_gemm_skinny_lines(GemmArgs g) {
+    constexpr int NW = 8, P = 36, TILE = 32 * P;             // [row][32 + 4] floats: conflict-free ds_read_b128 fragments
+    constexpr int PER_WAVE = B_KC ? 2 * TILE : TILE;         // >= 32 * 33, the partial tile of the reduction
+    extern __shared__ __align__(16) float sk_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int lr = lane >> 3, lk = 4 * (lane & 7);           // staging: row lr of 8, 16 bytes at k = lk
+    const int bx = blockIdx.x % g.gx, by = blockIdx.x / g.gx;
+    const int64_t m0 = (int64_t)by * 32, n0 = (int64_t)bx * 32;
+    const int64_t bcol = n0 + r < g.N ? n0 + r : g.N - 1;
+    float* As = sk_smem + wave * PER_WAVE;
+    float* Bs = As + TILE;
+
+    int n_chunks = 0;
+    for (int s = 0; s < g.n_seg; ++s) n_chunks += (int)(g.Ks[s] >> 5);
+
+    // epilogue operands of this thread's two outputs, requested now
+    const int col_l = threadIdx.x & 31;
+    const int64_t col = n0 + col_l;
+    float e_pre[16 / NW], e_res[16 / NW];
+#pragma unroll
+    for (int j = 0; j < 16 / NW; ++j) {
+        const int64_t row = m0 + (threadIdx.x >> 5) + 2 * NW * j;
+        e_pre[j] = 0.f; e_res[j] = 0.f;
+        if (row < g.M && col < g.N) {
+            if (g.pre_add) e_pre[j] = g.pre_add[(g.pre_rows ? (int64_t)g.pre_rows[row] : row) * g.ldp + col];
+            if (g.residual) e_res[j] = g.residual[row * g.ldr + col];
+        }
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+
+    for (int c0 = wave; c0 < n_chunks; c0 += 2 * NW) {
+        float4 a[2][4], b[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int c = c0 + NW * u, seg = 0;
+            int64_t koff = 0;
+            if (c >= n_chunks) continue;
+            while (seg < g.n_seg - 1) {                       // wave-uniform walk over <= 4 segments
+                const int nc = (int)(g.Ks[seg] >> 5);
+                if (c < nc) break;
+                c -= nc; koff += g.Ks[seg]; ++seg;
+            }
+            const int64_t k0 = 32 * (int64_t)c;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t rr = 8 * i + lr;
+                const int64_t arow = m0 + rr < g.M ? m0 + rr : g.M - 1;       // edge rows: any valid one, never stored
+                if (g.cheb_R && seg == 1) {
+                    // c_lo * (row one block down) + c_hi * (row one block up), the arithmetic of k_cheb_shift
+                    const int blk = (int)(arow / g.cheb_R);
+                    float c_lo = 0.5f, c_hi = 0.5f;
+                    if (g.cheb_T) { if (blk == 0) c_hi = 1.f; } else { if (blk == 1) c_lo = 1.f; }
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (blk >= 1) {
+                        const float4 x = bg_ld4(g.A[1] + (arow - g.cheb_R) * g.lda[1] + k0 + lk);
+                        v.x = c_lo * x.x; v.y = c_lo * x.y; v.z = c_lo * x.z; v.w = c_lo * x.w;
+                    }
+                    if (blk + 1 < g.cheb_K) {
+                        const float4 y = bg_ld4(g.A[1] + (arow + g.cheb_R) * g.lda[1] + k0 + lk);
+                        v.x = __fmaf_rn(c_hi, y.x, v.x); v.y = __fmaf_rn(c_hi, y.y, v.y);
+                        v.z = __fmaf_rn(c_hi, y.z, v.z); v.w = __fmaf_rn(c_hi, y.w, v.w);
+                    }
+                    a[u][i] = v;
+                } else {
+                    a[u][i] = bg_ld4(g.A[seg] + arow * g.lda[seg] + k0 + lk);
+                }
+                if (B_KC) {
+                    const int64_t brow = n0 + rr < g.N ? n0 + rr : g.N - 1;
+                    b[u][i] = bg_ld4(g.B + brow * g.ldb + koff + k0 + lk);
+                } else {                                      // B [K, N]: a lane's column, 4 consecutive k -- whole lines already
+                    const float* bp = g.B + (koff + k0 + 8 * i + 4 * h) * g.ldb + bcol;
+                    b[u][i] = make_float4(bp[0], bp[g.ldb], bp[2 * g.ldb], bp[3 * g.ldb]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (c0 + NW * u >= n_chunks) continue;
+            // the previous chunk's fragment reads were issued before these writes (same wave: executed in order)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bg_st4(As + (8 * i + lr) * P + lk, a[u][i]);
+                if (B_KC) bg_st4(Bs + (8 * i + lr) * P + lk, b[u][i]);
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 af = bg_ld4(As + r * P + 8 * j + 4 * h);
+                const float4 bf = B_KC ? bg_ld4(Bs + r * P + 8 * j + 4 * h) : b[u][j];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // partial tiles into the waves' own (now idle) staging areas; lane holds column r, rows (q&3) + 8*(q>>2) + 4*h
+#pragma unroll
+    for (int q = 0; q < 16; ++q) As[((q & 3) + 8 * (q >> 2) + 4 * h) * 33 + r] = acc[q];
+    __syncthreads();
+    if (col >= g.N) return;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16 / NW; ++j) {
+        const int row_l = (threadIdx.x >> 5) + 2 * NW * j;
+        const int64_t row = m0 + row_l;
+        if (row >= g.M) continue;
+        const int o = row_l * 33 + col_l;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += sk_smem[w * PER_WAVE + o];
+        v += bv;
+        if (g.row_scale) v *= g.row_scale[row];
+        if (g.pre_add) v += e_pre[j];
+        if (g.act == BG_ACT_LEAKY) v = v > 0.f ? v : v * g.slope;
+        if (g.residual) v += e_res[j];
+        g.C[row * g.ldc + col] = v;
+    }
+}
+
 __global__ void k_splitk_reduce(const float* __restrict__ partial, int splits, int64_t M, int64_t N,
                                 float* __restrict__ C, int64_t ldc, int accumulate) {
     // one float4 of C per thread (M*N % 4 == 0 checked by the launcher), splits added in order
@@ -1030,6 +1169,27 @@ int launch_gemm_skinny(int transB, GemmArgs g, hipStream_t s) {
     static int force = -1;
     if (force < 0) force = bg_tune_int("BG_GEMM_SKINNY_WAVES", 0);
     const bool wide = force ? force == 8 : groups > 32;      // K > 256: eight waves share it, one load round each
+    bool lines = wide && bg_tune_int("BG_GEMM_SKINNY_LINES", 1) != 0;
+    for (int i = 0; i < g.n_seg; ++i) lines = lines && g.Ks[i] % 32 == 0;
+    if (lines) {                                             // whole-line loads through wave-private LDS tiles
+        const size_t lds_bytes = (size_t)8 * (transB ? 2 : 1) * 32 * 36 * sizeof(float);
+        if (transB) {
+            static bool raised[BG_MAX_DEVICES] = {};         // 73,728 bytes: above the 64 KB static limit, opt in per device
+            int dev = 0;
+            BG_HIP(hipGetDevice(&dev));
+            if (dev < 0 || dev >= BG_MAX_DEVICES) return BG_ERR_ARG;
+            if (!raised[dev]) {
+                BG_HIP(hipFuncSetAttribute((const void*)k_gemm_skinny_lines<true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                raised[dev] = true;
+            }
+            k_gemm_skinny_lines<true><<<blocks, 512, lds_bytes, s>>>(g);
+        } else {
+            k_gemm_skinny_lines<false><<<blocks, 512, lds_bytes, s>>>(g);
+        }
+        BG_LAUNCH_CHECK();
+        return BG_OK;
+    }
     if (wide) {
         if (transB) k_gemm_skinny<true, 8><<<blocks, 512, 0, s>>>(g);
         else k_gemm_skinny<false, 8><<<blocks, 512, 0, s>>>(g);

@@ -615,8 +615,13 @@ def test_one_launch_segment_sum_and_max(cuda):
 
 
 @pytest.mark.parametrize("M,N,Ks,transB", [(200, 96, [64, 36], True),        # skinny kernel, 4 waves
-                                            (500, 256, [256, 256], True),     # skinny kernel, 8 waves
-                                            (500, 256, [512], False),         # skinny kernel, B stored [K, N]
+                                            (500, 256, [256, 256], True),     # skinny kernel, whole-line loads (K_s % 32 == 0)
+                                            (500, 256, [512], False),         # same, B stored [K, N]
+                                            (301, 200, [32, 96, 160, 64], True),   # same, four segments, ragged M and N
+                                            (301, 200, [32, 96, 160, 64], False),
+                                            (70, 40, [1024, 512], True),      # same, more than two chunks per wave
+                                            (200, 96, [260, 100], True),      # skinny kernel, 8 waves, fragment loads
+                                            (200, 96, [260, 100], False),
                                             (11520, 128, [128, 128, 4], True),  # 64x64 register-staged kernel
                                             (11520, 128, [128, 128], True),     # row-panel kernel, 48-row panels (one per CU)
                                             (3001, 128, [64, 192], True),       # row-panel kernel, 32-row panels, ragged last panel
