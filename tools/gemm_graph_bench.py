@@ -28,7 +28,7 @@ def nt(name, M, N, Ks, pre=False, leaky=False, bias=False, res=False, gather=Fal
     if acc: kw["acc_init"] = R(M, N)
     if pre: kw["pre_add"] = R(M, N)
     if gather:
-        kw["pre_add"] = R(80, N); kw["pre_rows"] = (torch.arange(M, device=dev) // 144).to(torch.int32)
+        kw["pre_add"] = R(80, N); kw["pre_rows"] = (torch.arange(M, device=dev) * 80 // M).to(torch.int32)    # rows 0..79 only
     if leaky: kw["act"] = 1
     if bias: kw["bias"] = R(N)
     if res: kw["residual"] = xs[0]
