@@ -8,7 +8,6 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
-import os
 import threading
 from typing import List, Optional, Sequence
 
@@ -24,7 +23,11 @@ ACT_NONE, ACT_LEAKY = 0, 1
 # parameters train), 0 = monomials A^k (the first formulation; its rounding amplification grew past
 # DiscriminatorVoxel.COLLAPSE_AMPLIFICATION_LIMIT within ~1000 iterations of training: DESIGN.md section 6).
 CHAIN_POWER, CHAIN_CHEB, CHAIN_CLENSHAW = 0, 1, 2
-D_BASIS = CHAIN_POWER if os.environ.get("BG_D_BASIS", "chebyshev").lower() in ("power", "monomial", "0") else CHAIN_CHEB
+# The collapsed discriminator runs in the Chebyshev basis.  The monomial basis (CHAIN_POWER) stays in the kernels for the
+# tests and tools/basis_conditioning.py, which assign this attribute to compare the two; it is NOT a product option (no
+# environment variable or constructor argument selects it): its amplification passes the guard's limit after ~1,000
+# training iterations.
+D_BASIS = CHAIN_CHEB
 FUSE_COEF_RECURRENCE = True      # PolyCoefD: the coefficient recurrence and its backward as one host call each
 
 _INPUT_GRADS_ONLY = False

@@ -1,6 +1,6 @@
 """Is the collapsed discriminator's rounding amplification a property of the MONOMIAL basis A^k?  Trains the synthetic
 stream until DiscriminatorVoxel.guard_collapse reports a large amplification (or the iteration budget ends), then
-trains in the basis ops.D_BASIS (env BG_D_BASIS), and evaluates, in float64, the same bound  max_o max_i (sum_k |Z_k| |W_k|)_io / max_i |v|_io  for
+trains in the basis ops.D_BASIS (assigned by this tool), and evaluates, in float64, the same bound  max_o max_i (sum_k |Z_k| |W_k|)_io / max_i |v|_io  for
   * the monomial basis   Z_k = A^k U        with the coefficient table the GPU path uses, and
   * the Chebyshev basis  Z_j = T_j(A) U     with the table converted (x^k = sum_j c_kj T_j(x)),
 A = the mean-aggregation operator (spectrum in [-1, 1]).  Analysis aid; nothing here is on the product path."""
