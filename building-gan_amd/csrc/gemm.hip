@@ -788,8 +788,8 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_skinny(GemmArgs g) {
     }
 }
 
-// The same product for K > 256 with every K_s a multiple of 32 (the coefficient recurrence: [<= 520, 256 | 256] x
-// [512, 256]).  k_gemm_skinny's fragment-shaped loads ask for 32 different 128-byte lines per instruction and use 32
+// The same product with whole-line loads (every skinny shape since round 3; the coefficient recurrence's [<= 520, 256 |
+// 256] x [512, 256] is the one it was measured on).  k_gemm_skinny's fragment-shaped loads ask for 32 different 128-byte lines per instruction and use 32
 // bytes of each; with ~20 such loads per lane and 8 waves the CU's address / tag path (not the bytes) is what the
 // kernel waits for: 3.1 of its 6.9 us (ablations in DESIGN.md section 6, round 3).  Here a wave owns whole 32-k
 // CHUNKS (one 128-byte line per operand row): it loads a chunk by full lines (8 lanes per row, 8 rows per
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_lines(GemmArgs g) {
     float* Bs = As + TILE;
 
     int n_chunks = 0;
-    for (int s = 0; s < g.n_seg; ++s) n_chunks += (int)(g.Ks[s] >> 5);
+    for (int s = 0; s < g.n_seg; ++s) n_chunks += (int)((g.Ks[s] + 31) >> 5);
 
     // epilogue operands of this thread's two outputs, requested now
     const int col_l = threadIdx.x & 31;
@@ -841,16 +841,20 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_lines(GemmArgs g) {
             int64_t koff = 0;
             if (c >= n_chunks) continue;
             while (seg < g.n_seg - 1) {                       // wave-uniform walk over <= 4 segments
-                const int nc = (int)(g.Ks[seg] >> 5);
+                const int nc = (int)((g.Ks[seg] + 31) >> 5);
                 if (c < nc) break;
                 c -= nc; koff += g.Ks[seg]; ++seg;
             }
             const int64_t k0 = 32 * (int64_t)c;
+            const bool a_in = k0 + lk < g.Ks[seg];            // a segment's last chunk may be short (K_s % 4 == 0: a 16-byte
+                                                              // piece is all in or all out); the rest multiplies as zeros
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t rr = 8 * i + lr;
                 const int64_t arow = m0 + rr < g.M ? m0 + rr : g.M - 1;       // edge rows: any valid one, never stored
-                if (g.cheb_R && seg == 1) {
+                if (!a_in) {
+                    a[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else if (g.cheb_R && seg == 1) {
                     // c_lo * (row one block down) + c_hi * (row one block up), the arithmetic of k_cheb_shift
                     const int blk = (int)(arow / g.cheb_R);
                     float c_lo = 0.5f, c_hi = 0.5f;
@@ -871,10 +875,13 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_lines(GemmArgs g) {
                 }
                 if (B_KC) {
                     const int64_t brow = n0 + rr < g.N ? n0 + rr : g.N - 1;
-                    b[u][i] = bg_ld4(g.B + brow * g.ldb + koff + k0 + lk);
+                    b[u][i] = a_in ? bg_ld4(g.B + brow * g.ldb + koff + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {                                      // B [K, N]: a lane's column, 4 consecutive k -- whole lines already
-                    const float* bp = g.B + (koff + k0 + 8 * i + 4 * h) * g.ldb + bcol;
-                    b[u][i] = make_float4(bp[0], bp[g.ldb], bp[2 * g.ldb], bp[3 * g.ldb]);
+                    b[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k0 + 8 * i + 4 * h < g.Ks[seg]) {
+                        const float* bp = g.B + (koff + k0 + 8 * i + 4 * h) * g.ldb + bcol;
+                        b[u][i] = make_float4(bp[0], bp[g.ldb], bp[2 * g.ldb], bp[3 * g.ldb]);
+                    }
                 }
             }
         }
@@ -1169,9 +1176,9 @@ int launch_gemm_skinny(int transB, GemmArgs g, hipStream_t s) {
     static int force = -1;
     if (force < 0) force = bg_tune_int("BG_GEMM_SKINNY_WAVES", 0);
     const bool wide = force ? force == 8 : groups > 32;      // K > 256: eight waves share it, one load round each
-    bool lines = wide && bg_tune_int("BG_GEMM_SKINNY_LINES", 1) != 0;
-    for (int i = 0; i < g.n_seg; ++i) lines = lines && g.Ks[i] % 32 == 0;
-    if (lines) {                                             // whole-line loads through wave-private LDS tiles
+    // whole-line loads through wave-private LDS tiles: every shape (the fragment-load kernels below stay for A/B runs in
+    // tuning builds, BG_GEMM_SKINNY_LINES=0)
+    if (bg_tune_int("BG_GEMM_SKINNY_LINES", 1) != 0) {
         const size_t lds_bytes = (size_t)8 * (transB ? 2 : 1) * 32 * 36 * sizeof(float);
         if (transB) {
             static bool raised[BG_MAX_DEVICES] = {};         // 73,728 bytes: above the 64 KB static limit, opt in per device

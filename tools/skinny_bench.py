@@ -41,3 +41,11 @@ def b():
                               X.data_ptr(), H2, None, 0, st())
     assert rc == 0, rc
 print("backward rows 520 (x12 per pass)  : %6.2f us" % timeit(b), flush=True)
+# the K <= 256 shapes of the step (program GNN, per-story terms, decoders): bg_gemm_f32 through ops.gemm_raw
+from building_gan_amd import ops
+for (M, N, Ks, tb) in [(308, 128, [128, 128], True), (308, 128, [128], True), (88, 128, [128], True), (88, 256, [256], True),
+                       (520, 256, [256], True), (308, 128, [128, 128], False), (88, 256, [256], False), (308, 128, [96], True)]:
+    xs = [R(M, k) for k in Ks]; W = R(N, sum(Ks)) if tb else R(sum(Ks), N)
+    out = torch.empty(M, N, device=dev); b = R(N); res = R(M, N)
+    us = timeit(lambda: ops.gemm_raw(xs, W, False, tb, out=out, bias=b, act=1, residual=res))
+    print("M %4d N %3d K %-12s transB %d : %6.2f us" % (M, N, Ks, tb, us), flush=True)
