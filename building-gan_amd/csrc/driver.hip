@@ -149,10 +149,21 @@ extern "C" int bg_generator_forward_f32(const bgGeneratorWeights* w, const bgGen
         if (i > last_att) break;
         BG_TRY(bg_gather_story_f32(v, H, p->vx_rowptr, p->vx_col, p->vx_count, BG_SCALE_DIV, b.gm, H, Nv,
                                    p->st_rowptr, p->st_col, p->st_count, w->Wsb, 2 * H, H, b.pq, 2 * H, S, H, s));
-        BG_TRY(bg_spmm_add_f32(b.pq + H, 2 * H, p->sb_rowptr, p->sb_col, p->sb_count, BG_SCALE_DIV, nullptr, BG_SCALE_NONE,
-                               b.pq, 2 * H, nullptr, 0, nullptr, 0, nullptr, nullptr, BG_SCALE_NONE, b.term, H, S, H, s));
-        BG_TRY(linear(Nv, H, 2, v, H, b.gm, H, nullptr, 0, H, w->Wc, w->ldwc, vn, nullptr, nullptr, BG_ACT_LEAKY, v, b.term,
-                      H, p->story_of_voxel, b.posb, s));
+        // the cross-story mean + the block product: one launch where the row-panel kernel takes the shape (the story
+        // term is then formed while the product loads it), else the two launches
+        const float* A2[4] = {v, b.gm, nullptr, nullptr};
+        const int64_t ld2[4] = {H, H, 0, 0}, Ks2[4] = {H, H, 0, 0};
+        const int rc_nbr = bg_gemm_nbr_f32(Nv, H, 2, A2, ld2, Ks2, w->Wc, w->ldwc, vn, H, nullptr, BG_ACT_LEAKY, 0.01f, v, H,
+                                           b.pq, 2 * H, b.pq + H, 2 * H, p->sb_rowptr, p->sb_col, p->sb_count,
+                                           p->story_of_voxel, b.posb, H, nullptr, 0, s);
+        if (rc_nbr == BG_ERR_SHAPE || rc_nbr == BG_ERR_ALIGN) {
+            BG_TRY(bg_spmm_add_f32(b.pq + H, 2 * H, p->sb_rowptr, p->sb_col, p->sb_count, BG_SCALE_DIV, nullptr, BG_SCALE_NONE,
+                                   b.pq, 2 * H, nullptr, 0, nullptr, 0, nullptr, nullptr, BG_SCALE_NONE, b.term, H, S, H, s));
+            BG_TRY(linear(Nv, H, 2, v, H, b.gm, H, nullptr, 0, H, w->Wc, w->ldwc, vn, nullptr, nullptr, BG_ACT_LEAKY, v, b.term,
+                          H, p->story_of_voxel, b.posb, s));
+        } else {
+            BG_TRY(rc_nbr);
+        }
         float* t = v; v = vn; vn = t;
         if (i % 2 == 0 && i != 0) BG_TRY(attention(call == n_calls - 1));
     }
@@ -696,12 +707,21 @@ extern "C" int bg_gstack_forward_f32(const bgGeneratorWeights* w, const bgGenera
             const int i = g.idx[k];
             BG_TRY(bg_gather_story_f32(v, H, p->vx_rowptr, p->vx_col, p->vx_count, BG_SCALE_DIV, g.gm[i], H, Nv,
                                        p->st_rowptr, p->st_col, p->st_count, w->Wsb, 2 * H, H, g.pq, 2 * H, S, H, s));
-            BG_TRY(bg_spmm_add_f32(g.pq + H, 2 * H, p->sb_rowptr, p->sb_col, p->sb_count, BG_SCALE_DIV, nullptr, BG_SCALE_NONE,
-                                   g.pq, 2 * H, nullptr, 0, nullptr, 0, nullptr, nullptr, BG_SCALE_NONE, g.term, H, S, H, s));
             const float* A[4] = {v, g.gm[i], nullptr, nullptr};
             const int64_t ld[4] = {H, H, 0, 0}, Ks[4] = {H, H, 0, 0};
-            BG_TRY(bg_gemm_f32(0, 1, Nv, H, 2, A, ld, Ks, w->Wc, w->ldwc, vn, H, nullptr, nullptr, BG_ACT_LEAKY, 0.01f, v, H,
-                               g.term, H, p->story_of_voxel, g.posb, H, g.y[i], H, s));
+            // one launch where the row-panel kernel takes the shape (the story term formed on load), else two
+            const int rc_nbr = bg_gemm_nbr_f32(Nv, H, 2, A, ld, Ks, w->Wc, w->ldwc, vn, H, nullptr, BG_ACT_LEAKY, 0.01f, v, H,
+                                               g.pq, 2 * H, g.pq + H, 2 * H, p->sb_rowptr, p->sb_col, p->sb_count,
+                                               p->story_of_voxel, g.posb, H, g.y[i], H, s);
+            if (rc_nbr == BG_ERR_SHAPE || rc_nbr == BG_ERR_ALIGN) {
+                BG_TRY(bg_spmm_add_f32(g.pq + H, 2 * H, p->sb_rowptr, p->sb_col, p->sb_count, BG_SCALE_DIV, nullptr,
+                                       BG_SCALE_NONE, g.pq, 2 * H, nullptr, 0, nullptr, 0, nullptr, nullptr, BG_SCALE_NONE,
+                                       g.term, H, S, H, s));
+                BG_TRY(bg_gemm_f32(0, 1, Nv, H, 2, A, ld, Ks, w->Wc, w->ldwc, vn, H, nullptr, nullptr, BG_ACT_LEAKY, 0.01f, v, H,
+                                   g.term, H, p->story_of_voxel, g.posb, H, g.y[i], H, s));
+            } else {
+                BG_TRY(rc_nbr);
+            }
         }
     }
     return BG_OK;

@@ -507,6 +507,23 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg,
                 const int32_t* pre_add_rows, const float* acc_init, int64_t ld_acc,
                 float* pre_residual_out, int64_t ld_pro, bgStream stream);
 
+/* bg_gemm_f32 (K-contiguous A segments, B = nn.Linear weight W [N, K]: transA = 0, transB = 1) whose gathered
+ * pre-activation addend is FORMED ON LOAD from a small matrix and a neighbour list instead of being read:
+ *   addend(i) = (sum_{k = nbr_rowptr[s]}^{nbr_rowptr[s+1]-1} nbr[nbr_col[k], :]) / nbr_count[s] + self_add[s, :],  s = rows[i]
+ * -- the arithmetic of bg_spmm_add_f32 (slot order starting from +0, IEEE division, then the addend), so the result
+ * equals that launch followed by bg_gemm_f32(pre_add = its output, pre_add_rows = rows) bit for bit.
+ * Only the row-panel kernel does this (N == 128, 2048 <= M <= 16384, every K_s % 64 == 0, 16-byte operands): any other
+ * shape returns BG_ERR_SHAPE before anything is launched and the caller issues the two launches.  acc_init and
+ * pre_residual_out as in bg_gemm_f32.
+ * replaces: one generator VoxelBlock's cross-story mean + update Linear, Model/models.py:163-170, as ONE launch (the
+ * [S, H] story term no longer travels through memory).                                                          */
+int bg_gemm_nbr_f32(int64_t M, int64_t N, int n_seg, const float* const* A, const int64_t* lda, const int64_t* Ks,
+                    const float* W, int64_t ldw, float* C, int64_t ldc, const float* bias, int act, float slope,
+                    const float* residual, int64_t ldr,
+                    const float* self_add, int64_t ld_self, const float* nbr, int64_t ld_nbr,
+                    const int32_t* nbr_rowptr, const int32_t* nbr_col, const float* nbr_count, const int32_t* rows,
+                    const float* acc_init, int64_t ld_acc, float* pre_residual_out, int64_t ld_pro, bgStream stream);
+
 /* C[M,N] = A^T[M,R] * [B_0 | B_1 | ..][R,N] with the long reduction R split over `splits`
  * workgroups per tile: A is [R, M] (pitch lda), B_s is [R, Ns[s]] (pitch ldb[s]), N = sum Ns
  * (n_seg in 1..4: the concatenation of the layer inputs is never built); partial: [splits, M, N].

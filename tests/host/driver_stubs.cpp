@@ -35,6 +35,21 @@ int bg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int n_seg, const f
     rec(1, a, sizeof(a) / 8);
     return 0;
 }
+static int g_nbr_accepts = 0;                     // 0: bg_gemm_nbr_f32 declines (the composites then issue two launches)
+void stub_nbr_accepts(int on) { g_nbr_accepts = on; }
+int bg_gemm_nbr_f32(int64_t M, int64_t N, int n_seg, const float* const* A, const int64_t* lda, const int64_t* Ks,
+                    const float* W, int64_t ldw, float* C, int64_t ldc, const float* bias, int act, float slope,
+                    const float* residual, int64_t ldr, const float* self_add, int64_t ld_self, const float* nbr,
+                    int64_t ld_nbr, const int32_t* nbr_rowptr, const int32_t* nbr_col, const float* nbr_count,
+                    const int32_t* rows, const float* acc_init, int64_t ld_acc, float* pre_residual_out, int64_t ld_pro,
+                    bgStream stream) {
+    if (!g_nbr_accepts) return BG_ERR_SHAPE;
+    int64_t a[] = {M, N, n_seg, P(A[0]), P(A[1]), P(A[2]), P(A[3]), lda[0], lda[1], lda[2], lda[3], Ks[0], Ks[1], Ks[2],
+                   Ks[3], P(W), ldw, P(C), ldc, P(bias), act, P(residual), ldr, P(self_add), ld_self, P(nbr), ld_nbr,
+                   P(nbr_rowptr), P(nbr_col), P(nbr_count), P(rows), P(acc_init), ld_acc, P(pre_residual_out), ld_pro};
+    rec(26, a, sizeof(a) / 8);
+    return 0;
+}
 int bg_spmm_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* edge_w,
                 const int32_t* eperm, const float* row_scale, int row_mode, const float* col_scale, int col_mode,
                 float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream) {

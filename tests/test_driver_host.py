@@ -200,6 +200,43 @@ def test_generator_forward_host_sequence_and_extents(drv):
             assert R.check(a[13], 4, "em") == "exp_mask%d" % c and R.check(a[14], 4, "ea") == "exp_att%d" % c
 
 
+def test_generator_forward_block_as_one_launch_where_the_product_takes_it(drv):
+    """Where bg_gemm_nbr_f32 accepts the shape (the stand-in is told to), a generator block is gather + story projection
+    and ONE product launch: no separate cross-story mean, and the product reads the story pairs [P | Q], the story
+    graph and the voxel -> story map from the buffers the mean used to read."""
+    Np, Nv, S, Ec, H, f = 320, 11520, 80, 46080, 128, 4
+    drv.stub_nbr_accepts(1)
+    try:
+        rc, calls, R = _run(drv, Np, Nv, S, Ec)
+    finally:
+        drv.stub_nbr_accepts(0)
+    assert rc == 0
+    kinds = [k for k, _ in calls]
+    expect = [1] + [2, 1, 1] * 4 + [1, 1] + [1, 5] + [1]
+    for i in range(11):
+        expect += [4, 26] + ([1, 5] if (i % 2 == 0 and i != 0) else [])
+    expect += [6]
+    assert kinds == expect
+    _check_calls([c for c in calls if c[0] != 26], R, H)
+    pq_of = [a[15] for k, a in calls if k == 4]
+    for n, (k, a) in enumerate(c for c in calls if c[0] == 26):
+        M, N, n_seg = a[0:3]
+        A, lda, Ks = a[3:7], a[7:11], a[11:15]
+        (W, ldw, Cp, ldc, bias, act, res, ldr, self_add, ld_self, nbr, ld_nbr, rp, col, cnt, rows, acc, ldacc, pro, ldpro) = a[15:35]
+        assert (M, N, n_seg) == (Nv, H, 2) and Ks[:2] == [H, H] and act == 1 and bias == 0 and pro == 0
+        for s_ in range(2):
+            R.check(A[s_], ((M - 1) * lda[s_] + H) * f, "A%d" % s_)
+            assert A[s_] != Cp
+        R.check(W, ((N - 1) * ldw + 2 * H) * f, "Wc")
+        R.check(Cp, ((M - 1) * ldc + N) * f, "C")
+        assert res == A[0] and ldr == H                                   # the residual is the block's input
+        assert self_add == pq_of[n] and nbr == self_add + H * f and ld_self == ld_nbr == 2 * H
+        R.check(self_add, ((S - 1) * ld_self + 2 * H) * f, "story pairs")
+        assert R.check(rp, (S + 1) * 4, "rowptr") == "sb_rowptr" and R.check(col, 4, "col") == "sb_col"
+        assert R.check(cnt, S * f, "count") == "sb_count" and R.check(rows, M * 4, "rows") == "story_of_voxel"
+        R.check(acc, ((M - 1) * ldacc + N) * f, "position + bias term")
+
+
 def test_generator_forward_host_argument_errors(drv):
     rc, _, _ = _run(drv, 320, 70000, 80, 46080)
     assert rc == -2                                   # more voxels than the fused gather + story launch takes

@@ -1115,3 +1115,50 @@ def test_shift_of_stacked_tables_by_one_launch(cuda):
         assert torch.equal(out[m * P + 1:(m + 1) * P], ref), m
         assert bool((out[m * P] == 0).all())
     assert bool((out[L * P] == 0).all())
+
+
+@pytest.mark.parametrize("M", [3001, 11520, 12577])          # 32-, 48- and 64-row panels (the last one ragged)
+@pytest.mark.parametrize("K", [[128, 128], [64]])             # four K steps / one (the index chain then ends after the loop)
+def test_gemm_with_addend_formed_from_neighbour_rows(cuda, M, K):
+    """bg_gemm_nbr_f32 (the gathered pre-activation addend formed on load: neighbour rows summed in slot order, IEEE
+    division by the count, plus the row's own part) against bg_spmm_add_f32 followed by bg_gemm_f32: bit for bit, with
+    rows of 0..5 neighbours (more than the two that travel through registers), accumulator start, LeakyReLU, residual and
+    the pre-residual copy; shapes the row-panel kernel does not take are declined before anything is launched."""
+    import ctypes as C
+    from building_gan_amd import _lib, ops
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(M + len(K))
+    G, N = 83, 128
+    R = lambda *s: (torch.rand(*s, generator=gen) * 2 - 1)
+    deg = torch.randint(0, 6, (G,), generator=gen)
+    deg[0], deg[1] = 0, 5
+    rowptr = torch.zeros(G + 1, dtype=torch.int32); rowptr[1:] = deg.cumsum(0).to(torch.int32)
+    col = torch.randint(0, G, (int(rowptr[-1]),), generator=gen).to(torch.int32)
+    count = deg.clamp(min=1).float()
+    pq = R(G, 2 * N).to(cuda)                                   # [own part | neighbour part], as the generator block keeps it
+    rows = torch.sort(torch.randint(0, G, (M,), generator=gen))[0].to(torch.int32).to(cuda)
+    xs = [R(M, k).to(cuda) for k in K]
+    W, acc0 = R(N, sum(K)).to(cuda), R(M, N).to(cuda)
+    rowptr, col, count = rowptr.to(cuda), col.to(cuda), count.to(cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    term = torch.empty(G, N, device=cuda)
+    assert lib.bg_spmm_add_f32(pq.data_ptr() + 4 * N, 2 * N, rowptr.data_ptr(), col.data_ptr(), count.data_ptr(), 2, None, 0,
+                               pq.data_ptr(), 2 * N, None, 0, None, 0, None, None, 0, term.data_ptr(), N, G, N, st) == 0
+    pro_ref = torch.empty(M, N, device=cuda)
+    ref = ops.gemm_raw(xs, W, False, True, act=ops.ACT_LEAKY, slope=0.01, residual=xs[0][:, :N] if K[0] >= N else None,
+                       pre_add=term, pre_rows=rows, acc_init=acc0, pre_residual_out=pro_ref)
+    res = xs[0] if K[0] >= N else None
+    pa, la, ka = (C.c_void_p * 4)(), (C.c_int64 * 4)(), (C.c_int64 * 4)()
+    for i, x in enumerate(xs):
+        pa[i], la[i], ka[i] = x.data_ptr(), x.stride(0), x.shape[1]
+    out = torch.full((M, N), float("nan"), device=cuda)
+    pro = torch.full((M, N), float("nan"), device=cuda)
+
+    def call(m):
+        return lib.bg_gemm_nbr_f32(m, N, len(xs), pa, la, ka, W.data_ptr(), W.stride(0), out.data_ptr(), N, None, ops.ACT_LEAKY, 0.01,
+                                   res.data_ptr() if res is not None else None, res.stride(0) if res is not None else 0,
+                                   pq.data_ptr(), 2 * N, pq.data_ptr() + 4 * N, 2 * N, rowptr.data_ptr(), col.data_ptr(),
+                                   count.data_ptr(), rows.data_ptr(), acc0.data_ptr(), N, pro.data_ptr(), N, st)
+    assert call(M) == 0
+    assert torch.equal(out, ref) and torch.equal(pro, pro_ref)
+    assert call(1000) == -2                                    # below the row-panel kernel's range: nothing launched
