@@ -486,12 +486,16 @@ __global__ __launch_bounds__(256) void k_gemm_panel(GemmArgs g) {
     };
 
     // bg_gemm_nbr_f32: the addend row formed from its neighbour rows.  Four dependent loads (row index -> row pointers
-    // -> column indices -> rows), one per K step so that none is waited for where it is issued; what the K loop is too
-    // short for runs after it.  Up to NBR_D neighbours travel through registers, longer rows continue in a loop.
-    constexpr int NBR_D = 2;
-    int32_t n_s[NC], n_b[NC], n_e[NC], n_c[NC][NBR_D];
-    float n_cnt[NC];
-    float4 n_x[NC][NBR_D];
+    // -> column indices -> rows): before the first operand request, after the first LDS write, then one per K step, so
+    // that none is waited for where it is issued; what the K loop is too short for runs after it.  Up to NBR_D neighbours travel through registers, longer rows continue in a loop.
+    // The rows a thread finishes are 16 apart and nearly always share their addend row s (voxels of a story are
+    // contiguous): then ONE neighbour sum serves all of them, up to NBR_D neighbours in registers (a building's
+    // stories: 8-11).  Threads whose rows differ, and longer neighbour lists, take the loop in nbr_finish.
+    constexpr int NBR_D = 12;
+    int32_t n_s[NC], n_b = 0, n_e = 0, n_c[NBR_D];
+    float n_cnt = 1.f;
+    float4 n_x[NBR_D];
+    bool n_same = true;
     auto nbr_stage = [&](const int st) {
         if (!NBR) return;
         if (st == 0) {
@@ -503,42 +507,51 @@ __global__ __launch_bounds__(256) void k_gemm_panel(GemmArgs g) {
             }
         } else if (st == 1) {
 #pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                n_b[i] = g.nbr_rowptr[n_s[i]]; n_e[i] = g.nbr_rowptr[n_s[i] + 1]; n_cnt[i] = g.nbr_count[n_s[i]];
+            for (int i = 1; i < NC; ++i) n_same = n_same && n_s[i] == n_s[0];
+            n_b = g.nbr_rowptr[n_s[0]]; n_e = g.nbr_rowptr[n_s[0] + 1]; n_cnt = g.nbr_count[n_s[0]];
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
                 e_pre[i] = bg_ld4(g.pre_add + (int64_t)n_s[i] * g.ldp + n0 + 4 * c4);      // the row's own part
-            }
         } else if (st == 2) {
 #pragma unroll
-            for (int i = 0; i < NC; ++i)
-#pragma unroll
-                for (int j = 0; j < NBR_D; ++j) n_c[i][j] = n_b[i] + j < n_e[i] ? g.nbr_col[n_b[i] + j] : -1;
+            for (int j = 0; j < NBR_D; ++j) n_c[j] = n_b + j < n_e ? g.nbr_col[n_b + j] : -1;
         } else if (st == 3) {
 #pragma unroll
-            for (int i = 0; i < NC; ++i)
-#pragma unroll
-                for (int j = 0; j < NBR_D; ++j) {
-                    n_x[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);          // + 0 leaves a sum that started at +0 unchanged
-                    if (n_c[i][j] >= 0) n_x[i][j] = bg_ld4(g.nbr + (int64_t)n_c[i][j] * g.ldn + n0 + 4 * c4);
-                }
+            for (int j = 0; j < NBR_D; ++j) {
+                n_x[j] = make_float4(0.f, 0.f, 0.f, 0.f);          // + 0 leaves a sum that started at +0 unchanged
+                if (n_c[j] >= 0) n_x[j] = bg_ld4(g.nbr + (int64_t)n_c[j] * g.ldn + n0 + 4 * c4);
+            }
         }
     };
     auto nbr_finish = [&]() {
         if (!NBR) return;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < NBR_D; ++j) a = bg_add4(a, n_x[j]);
+        for (int32_t k = n_b + NBR_D; k < n_e; ++k)
+            a = bg_add4(a, bg_ld4(g.nbr + (int64_t)g.nbr_col[k] * g.ldn + n0 + 4 * c4));
+        a.x = a.x / n_cnt; a.y = a.y / n_cnt; a.z = a.z / n_cnt; a.w = a.w / n_cnt;
+        e_pre[0] = bg_add4(a, e_pre[0]);
 #pragma unroll
-            for (int j = 0; j < NBR_D; ++j) a = bg_add4(a, n_x[i][j]);
-            for (int32_t k = n_b[i] + NBR_D; k < n_e[i]; ++k)
-                a = bg_add4(a, bg_ld4(g.nbr + (int64_t)g.nbr_col[k] * g.ldn + n0 + 4 * c4));
-            a.x = a.x / n_cnt[i]; a.y = a.y / n_cnt[i]; a.z = a.z / n_cnt[i]; a.w = a.w / n_cnt[i];
-            e_pre[i] = bg_add4(a, e_pre[i]);
+        for (int i = 1; i < NC; ++i) {
+            float4 t = a;
+            if (!n_same && n_s[i] != n_s[0]) {                  // another addend row: its own sum, by the loop
+                const int32_t b2 = g.nbr_rowptr[n_s[i]], e2 = g.nbr_rowptr[n_s[i] + 1];
+                const float c2 = g.nbr_count[n_s[i]];
+                t = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int32_t k = b2; k < e2; ++k)
+                    t = bg_add4(t, bg_ld4(g.nbr + (int64_t)g.nbr_col[k] * g.ldn + n0 + 4 * c4));
+                t.x = t.x / c2; t.y = t.y / c2; t.z = t.z / c2; t.w = t.w / c2;
+            }
+            e_pre[i] = bg_add4(t, e_pre[i]);
         }
     };
 
+    nbr_stage(0);               // ahead of the operands: it has arrived when they have (loads return in order)
     point();
     fetch();
     stash(smem);
+    nbr_stage(1);
     __syncthreads();
     const int steps = g.total_steps;
     // the last step is peeled (MORE = false): the epilogue operands it requests are then not live across the loop
@@ -547,7 +560,7 @@ __global__ __launch_bounds__(256) void k_gemm_panel(GemmArgs g) {
         const float* As = smem + (step & 1) * (A_SZ + B_SZ);
         const float* Bs = As + A_SZ;
         if (more) fetch(); else prefetch_epilogue();
-        if (step < 4) nbr_stage(step);
+        if (step < 2) nbr_stage(step + 2);
 #pragma unroll
         for (int kg = 0; kg < BK / 16; ++kg) {
             float4 af[TMT], bf[NJ];
@@ -580,7 +593,7 @@ __global__ __launch_bounds__(256) void k_gemm_panel(GemmArgs g) {
     for (int step = 0; step + 1 < steps; ++step) one_step(step, std::true_type{});
     one_step(steps - 1, std::false_type{});
 
-    for (int st = steps; st < 4; ++st) nbr_stage(st);
+    for (int st = steps + 2; st < 4; ++st) nbr_stage(st);
     nbr_finish();
 
     // the panel's result through LDS (lane holds column (lane & 15), rows 4*(lane>>4) + q of each 16x16 tile), then
@@ -1386,7 +1399,7 @@ static int gemm_entry(int transA, int transB, int64_t M, int64_t N, int n_seg,
             if (nbr) {
                 if (t <= 2) return launch_gemm_panel<2, 1, true>(g, st);
                 if (t == 3) return launch_gemm_panel<3, 1, true>(g, st);
-                return launch_gemm_panel<4, 1, true>(g, st);
+                return BG_ERR_SHAPE;      // 64-row panels: the neighbour registers would cost the second workgroup per CU
             }
             if (panel_nj() == 2) {
                 if (t <= 2) return launch_gemm_panel<2, 2>(g, st);
@@ -1449,6 +1462,7 @@ int bg_gemm_nbr_f32(int64_t M, int64_t N, int n_seg, const float* const* A, cons
                     const int32_t* nbr_rowptr, const int32_t* nbr_col, const float* nbr_count, const int32_t* rows,
                     const float* acc_init, int64_t ld_acc, float* pre_residual_out, int64_t ld_pro, bgStream stream) {
     if (!nbr || !self_add || !rows) return BG_ERR_ARG;
+    if (bg_tune_int("BG_GEMM_NBR", 1) == 0) return BG_ERR_SHAPE;      // tuning builds: A/B against the two launches
     return gemm_entry(0, 1, M, N, n_seg, A, lda, Ks, W, ldw, C, ldc, bias, nullptr, act, slope, residual, ldr,
                       self_add, ld_self, rows, acc_init, ld_acc, pre_residual_out, ld_pro,
                       nbr, ld_nbr, nbr_rowptr, nbr_col, nbr_count, stream);

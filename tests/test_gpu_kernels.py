@@ -1117,7 +1117,7 @@ def test_shift_of_stacked_tables_by_one_launch(cuda):
     assert bool((out[L * P] == 0).all())
 
 
-@pytest.mark.parametrize("M", [3001, 11520, 12577])          # 32-, 48- and 64-row panels (the last one ragged)
+@pytest.mark.parametrize("M", [3001, 11520, 12281, 12577])   # 32- and 48-row panels (ragged last one); 64-row panels: declined
 @pytest.mark.parametrize("K", [[128, 128], [64]])             # four K steps / one (the index chain then ends after the loop)
 def test_gemm_with_addend_formed_from_neighbour_rows(cuda, M, K):
     """bg_gemm_nbr_f32 (the gathered pre-activation addend formed on load: neighbour rows summed in slot order, IEEE
@@ -1159,6 +1159,10 @@ def test_gemm_with_addend_formed_from_neighbour_rows(cuda, M, K):
                                    res.data_ptr() if res is not None else None, res.stride(0) if res is not None else 0,
                                    pq.data_ptr(), 2 * N, pq.data_ptr() + 4 * N, 2 * N, rowptr.data_ptr(), col.data_ptr(),
                                    count.data_ptr(), rows.data_ptr(), acc0.data_ptr(), N, pro.data_ptr(), N, st)
+    if M > 12288:                 # 64-row panels: the neighbour registers would cost the second workgroup per CU
+        assert call(M) == -2 and bool(torch.isnan(out).all())
+        return
     assert call(M) == 0
     assert torch.equal(out, ref) and torch.equal(pro, pro_ref)
     assert call(1000) == -2                                    # below the row-panel kernel's range: nothing launched
+
