@@ -38,6 +38,7 @@ _int = C.c_int
 SIGNATURES = {
     "bg_zero_bytes": [_p, _i64, _p],
     "bg_copy2d_bytes": [_p, _i64, _p, _i64, _i64, _i64, _p],
+    "bg_fill_copy_batch": [_i32, _p, _p, _p, _p, _p, _p, _p],
     "bg_plan_csr": [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p],
     "bg_plan_segptr": [_p, _i64, _i64, _p, _p, _p],
     "bg_plan_floor_level": [_p, _p, _i64, _i64, _p, _p, _p],

@@ -195,9 +195,12 @@ int d_coef_forward_impl(const float* fe_w, const float* fe_b, const float* le_w,
     if (H <= 0 || L < 0 || ds < nf + ML + 5 || dl < nl || ldw < 4 * H + 4) return BG_ERR_ARG;
     if (basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB) return BG_ERR_ARG;
     const int64_t H2 = 2 * H, du = ds + dl, N = (L + 1) * du, S = N + du;
-    hipStream_t st = (hipStream_t)s;
-    BG_HIP(bg_zero_async(xall, sizeof(float) * (size_t)((L + 1) * S * H2), st));
-    BG_HIP(bg_zero_async(efull, sizeof(float) * (size_t)(N * H2), st));
+    {   // both workspaces start at zero: one launch
+        void* const dst[2] = {xall, efull};
+        const void* const src[2] = {nullptr, nullptr};
+        const int64_t wd[2] = {(int64_t)sizeof(float) * (L + 1) * S * H2, (int64_t)sizeof(float) * N * H2}, one[2] = {1, 1};
+        BG_TRY(bg_fill_copy_batch(2, dst, wd, src, wd, wd, one, s));
+    }
     BG_TRY(bg_d_coef_init_strided_f32(fe_w, fe_b, le_w, le_b, pe, Wc, ldw, bc, ld_bc, H, nf, nl, ML, ds, dl, xall + du * H2,
                                       efull, s));
     for (int64_t m = 0; m < L; ++m) {
@@ -227,13 +230,19 @@ int d_coef_backward_impl(const float* g, const float* xall, const float* Wc, int
     if (H <= 0 || L < 1 || ldw < 4 * H + 4 || ldgw < 4 * H + 4) return BG_ERR_ARG;
     if ((basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB) || (basis == BG_CHAIN_CHEB && !shall)) return BG_ERR_ARG;
     const int64_t H2 = 2 * H, du = ds + dl, N = (L + 1) * du, S = N + du;
-    hipStream_t st = (hipStream_t)s;
     // G^m at rows [0, N) of slab m, du zero rows below it (the shift-up view reads them)
-    BG_HIP(bg_zero_async(gall, sizeof(float) * (size_t)((L + 1) * S * H2), st));
-    BG_HIP(bg_copy_async(gall + L * S * H2, g, sizeof(float) * (size_t)(N * H2), st));
-    // Wab = [Wc[:, :2H]; Wc[:, 2H:4H]]  ([4H, 2H]): G Wa + shiftup(G) Wb
-    BG_HIP(bg_copy2d_async(wab, sizeof(float) * H2, Wc, sizeof(float) * ldw, sizeof(float) * H2, H2, st));
-    BG_HIP(bg_copy2d_async(wab + H2 * H2, sizeof(float) * H2, Wc + H2, sizeof(float) * ldw, sizeof(float) * H2, H2, st));
+    // one launch: G^m at rows [0, N) of slab m with du zero rows below it (the shift-up view reads them) -- slabs 0 .. L-1
+    // and the padding of slab L cleared, G^L = g copied in; Wab = [Wc[:, :2H]; Wc[:, 2H:4H]]  ([4H, 2H]): G Wa + shiftup(G) Wb
+    {
+        const int64_t f = (int64_t)sizeof(float);
+        void* const dst[5] = {gall, gall + L * S * H2 + N * H2, gall + L * S * H2, wab, wab + H2 * H2};
+        const void* const src[5] = {nullptr, nullptr, g, Wc, Wc + H2};
+        const int64_t dp[5] = {f * L * S * H2, f * (S - N) * H2, f * N * H2, f * H2, f * H2};
+        const int64_t sp[5] = {0, 0, f * N * H2, f * ldw, f * ldw};
+        const int64_t wd[5] = {f * L * S * H2, f * (S - N) * H2, f * N * H2, f * H2, f * H2};
+        const int64_t rw[5] = {1, 1, 1, H2, H2};
+        BG_TRY(bg_fill_copy_batch(5, dst, dp, src, sp, wd, rw, s));
+    }
     for (int64_t m = L - 1; m >= 0; --m) {
         const float* nxt = gall + (m + 1) * S * H2;
         if (basis == BG_CHAIN_CHEB) {                                   // second operand = the adjoint shift of G^{m+1}

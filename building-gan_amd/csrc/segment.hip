@@ -532,6 +532,19 @@ __device__ __forceinline__ void story_project_body(const float* __restrict__ x, 
     while (lpr < H4) lpr <<= 1;
     const int spb = nt / lpr, sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
     const int32_t k0 = rowptr[row], k1 = rowptr[row + 1];
+    // the projection's weights do not depend on the mean: requested now (up to 8 float4 per thread), they arrive while
+    // the mean is formed instead of adding a memory round trip after it
+    const int P = nt / (2 * Hout);
+    const bool fast = P >= 2 && (P & (P - 1)) == 0 && P <= 8 && P * 2 * Hout == nt && H % (4 * P) == 0;
+    const int hs = fast ? H / P : 0;
+    const bool pre = fast && hs <= 32;
+    float4 wpre[8];
+    if (pre) {
+        const int o = threadIdx.x / P, pp = threadIdx.x % P;
+        const float* w = W + (int64_t)(o < Hout ? o : o - Hout) * ldw + (o < Hout ? 0 : H) + pp * hs;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wpre[q] = 4 * q < hs ? bg_ld4(w + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (sub < H4) {
         const float* xb = x + 4 * sub;
@@ -561,16 +574,27 @@ __device__ __forceinline__ void story_project_body(const float* __restrict__ x, 
     }
     __syncthreads();
     // projection: P = nt / (2 Hout) adjacent lanes share one output, each over a contiguous quarter (..) of H
-    int P = nt / (2 * Hout);
-    if (P >= 2 && (P & (P - 1)) == 0 && P <= 8 && P * 2 * Hout == nt && H % (4 * P) == 0) {
-        const int o = threadIdx.x / P, pp = threadIdx.x % P, hs = H / P;
+    if (fast) {
+        const int o = threadIdx.x / P, pp = threadIdx.x % P;
         const float* w = W + (int64_t)(o < Hout ? o : o - Hout) * ldw + (o < Hout ? 0 : H) + pp * hs;
         float d = 0.f;
-        for (int h = 0; h < hs; h += 4) {
-            const float4 wv = bg_ld4(w + h);
-            const float4 mv = *reinterpret_cast<const float4*>(mean + mi(pp * hs + h));
-            d = fmaf(wv.x, mv.x, d); d = fmaf(wv.y, mv.y, d);
-            d = fmaf(wv.z, mv.z, d); d = fmaf(wv.w, mv.w, d);
+        if (pre) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (4 * q < hs) {
+                    const float4 wv = wpre[q];
+                    const float4 mv = *reinterpret_cast<const float4*>(mean + mi(pp * hs + 4 * q));
+                    d = fmaf(wv.x, mv.x, d); d = fmaf(wv.y, mv.y, d);
+                    d = fmaf(wv.z, mv.z, d); d = fmaf(wv.w, mv.w, d);
+                }
+            }
+        } else {
+            for (int h = 0; h < hs; h += 4) {
+                const float4 wv = bg_ld4(w + h);
+                const float4 mv = *reinterpret_cast<const float4*>(mean + mi(pp * hs + h));
+                d = fmaf(wv.x, mv.x, d); d = fmaf(wv.y, mv.y, d);
+                d = fmaf(wv.z, mv.z, d); d = fmaf(wv.w, mv.w, d);
+            }
         }
         d += bg_lane_xor<1>(d);                                   // P in {2, 4, 8}: the same pairs as the shuffle butterfly
         if (P >= 4) d += bg_lane_xor<2>(d);

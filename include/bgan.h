@@ -784,6 +784,13 @@ int bg_zero_bytes(void* p, int64_t bytes, bgStream stream);
 int bg_copy2d_bytes(void* dst, int64_t dpitch, const void* src, int64_t spitch, int64_t width, int64_t rows,
                     bgStream stream);
 
+/* Up to 8 of the two calls above as ONE launch: job i zero-fills (src[i] == NULL; dpitch / width / rows as a copy's
+ * destination) or copies rows[i] rows of width[i] bytes.  Jobs must not overlap.
+ * NO COUNTERPART IN THE REFERENCE: the preparation steps of bg_d_coef_* / bg_d_table_* (clear two workspaces; clear one,
+ * copy the incoming gradient and two weight blocks) as one launch each instead of two and four.                      */
+int bg_fill_copy_batch(int32_t n_jobs, void* const* dst, const int64_t* dpitch, const void* const* src,
+                       const int64_t* spitch, const int64_t* width, const int64_t* rows, bgStream stream);
+
 /* One Adam step on a flat fp32 buffer (torch.optim.Adam semantics, no weight decay/amsgrad):
  * m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * t = step, or *step_dev (a device int32) when step_dev is not NULL, so that a captured hipGraph

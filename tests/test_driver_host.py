@@ -954,7 +954,7 @@ def test_d_coef_host_sequence_and_extents(drv, basis, L):
                     for i in range(drv.stub_count())]
     rc, fwd = calls_of(drv.bg_d_coef_forward_f32, *par, Wc, ldw, bc, H, nf, nl, ML, ds, dl, L, basis, xall, efull, None)
     assert rc == 0
-    assert [k for k, _ in fwd] == [25, 25, 30] + [32 if basis else 1] * L
+    assert [k for k, _ in fwd] == [27, 25, 25, 30] + [32 if basis else 1] * L      # 27: the two clears are ONE launch
     cleared = {R.check(a[0], a[2], "memset"): a[2] for k, a in fwd if k == 25}
     assert cleared == {n: R.r[n][1] for n in ("xall", "efull")}
     m = 0
@@ -992,11 +992,13 @@ def test_d_coef_host_sequence_and_extents(drv, basis, L):
     rc, bwd = calls_of(drv.bg_d_coef_backward_f32, g, xall, Wc, ldw, H, nf, nl, ML, ds, dl, L, basis, shall, gall, wab,
                        partial, gW, *outs, None)
     assert rc == 0
-    assert [k for k, _ in bwd] == [25, 20, 20, 20] + [32 if basis else 1] * L + ([33] if basis else []) + [19, 31]
+    # 27: clears (slabs 0 .. L-1, the padding of slab L) and copies (g, the two weight blocks) as ONE launch
+    assert [k for k, _ in bwd] == [27, 25, 25, 20, 20, 20] + [32 if basis else 1] * L + ([33] if basis else []) + [19, 31]
+    assert sum(a[2] for k, a in bwd if k == 25) + N * H2 * f == R.r["gall"][1]
     m = L - 1
     for k, a in bwd:
         if k == 25:
-            assert R.check(a[0], a[2], "memset") == "gall" and a[2] == R.r["gall"][1]
+            assert R.check(a[0], a[2], "memset") == "gall"
         elif k == 20:
             dst, dp, src, sp, width, height = a
             R.check(dst, (height - 1) * dp + width, "copy dst"); R.check(src, (height - 1) * sp + width, "copy src")
@@ -1058,7 +1060,7 @@ def test_d_table_host_sequence_and_extents(drv, basis):
     rc, fwd = calls_of(drv.bg_d_table_forward_f32, Wm, 2 * H2 + 3, bm, Wu, 2 * H2, bu, *par, H, nf, nl, ML, ds, dl, L, basis,
                        wm_ext, r, wcb, xall, efull, None)
     assert rc == 0
-    assert [k for k, _ in fwd] == [35, 1, 25, 25, 30] + [32 if basis else 1] * L
+    assert [k for k, _ in fwd] == [35, 1, 27, 25, 25, 30] + [32 if basis else 1] * L
     prep = fwd[0][1]
     assert prep == [Wm, 2 * H2 + 3, bm, Wu, 2 * H2, bu, H2, wm_ext, r]
     g0 = fwd[1][1]
@@ -1086,7 +1088,7 @@ def test_d_table_host_sequence_and_extents(drv, basis):
     rc, bwd = calls_of(drv.bg_d_table_backward_f32, g, xall, wcb, wm_ext, Wu, 2 * H2, H, nf, nl, ML, ds, dl, L, basis, shall,
                        gall, wab, partial, gp, gwm, *outs, None)
     assert rc == 0
-    assert [k for k, _ in bwd] == [25, 20, 20, 20] + [32 if basis else 1] * L + ([33] if basis else []) + [19, 31, 1, 1, 36]
+    assert [k for k, _ in bwd] == [27, 25, 25, 20, 20, 20] + [32 if basis else 1] * L + ([33] if basis else []) + [19, 31, 1, 1, 36]
     tn = [a for k, a in bwd if k == 19][0]
     assert tn[8] == gp and tn[9] == P                                            # d [Wa | Wb] at the composed rows' pitch
     ib = [a for k, a in bwd if k == 31][0]

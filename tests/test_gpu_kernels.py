@@ -1166,3 +1166,36 @@ def test_gemm_with_addend_formed_from_neighbour_rows(cuda, M, K):
     assert torch.equal(out, ref) and torch.equal(pro, pro_ref)
     assert call(1000) == -2                                    # below the row-panel kernel's range: nothing launched
 
+
+
+def test_fills_and_copies_as_one_launch(cuda):
+    """bg_fill_copy_batch: zero fills and strided copies of different sizes and alignments in one launch, against torch;
+    bytes outside every job keep their contents; bad arguments are refused."""
+    import ctypes as C
+    from building_gan_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(3)
+    st = torch.cuda.current_stream().cuda_stream
+    a = torch.rand(1000, 260, generator=gen).to(cuda)           # destination of a fill: whole buffer, 16-byte aligned
+    b = torch.rand(37, 50, generator=gen).to(cuda)              # fill of rows 3..30, columns 1..41 (4-byte aligned only)
+    c_src = torch.rand(256, 1032, generator=gen).to(cuda)       # strided copy: a [256, 256] block of a wider matrix
+    c_dst = torch.full((256, 256), -1.0, device=cuda)
+    d_src = torch.rand(5, 7, generator=gen).to(cuda)            # small unaligned copy
+    d_dst = torch.full((5, 9), -1.0, device=cuda)
+    b_ref = b.clone(); b_ref[3:31, 1:42] = 0
+    d_ref = d_dst.clone(); d_ref[:, 1:8] = d_src
+    n = 4
+    P, I = C.c_void_p * n, C.c_int64 * n
+    dst = P(a.data_ptr(), b.data_ptr() + 4 * (3 * 50 + 1), c_dst.data_ptr(), d_dst.data_ptr() + 4)
+    src = P(None, None, c_src.data_ptr() + 4 * 256, d_src.data_ptr())
+    dp = I(4 * a.numel(), 4 * 50, 4 * 256, 4 * 9)
+    sp = I(0, 0, 4 * 1032, 4 * 7)
+    wd = I(4 * a.numel(), 4 * 41, 4 * 256, 4 * 7)
+    rw = I(1, 28, 256, 5)
+    assert lib.bg_fill_copy_batch(n, dst, dp, src, sp, wd, rw, st) == 0
+    assert bool((a == 0).all()) and torch.equal(b, b_ref)
+    assert torch.equal(c_dst, c_src[:, 256:512]) and torch.equal(d_dst, d_ref)
+    assert lib.bg_fill_copy_batch(9, dst, dp, src, sp, wd, rw, st) == -1
+    wd[1] = 4 * 41 + 2
+    assert lib.bg_fill_copy_batch(n, dst, dp, src, sp, wd, rw, st) == -1
+    assert lib.bg_fill_copy_batch(0, None, None, None, None, None, None, st) == 0
