@@ -110,10 +110,12 @@ def pmc_traffic(key):
 
 
 def roofline_dominant_gemm(dev, batch, plan, hidden=128):
-    """The kernel with the largest share of the step (profiles/r02_step_kernels*): the generator block's
-    collapsed Linear as the step launches it, [v | mean_j v_j] (K = 2H) -> H starting from the position +
-    bias term (evaluated once per forward), the per-story term gathered in the epilogue, LeakyReLU and the
-    residual.  Algorithmic flops = 2 M N K."""
+    """The generator block's collapsed Linear as the step launches it: [v | mean_j v_j] (K = 2H) -> H starting from the
+    position + bias term (evaluated once per forward), LeakyReLU and the residual, with the per-story term
+    P[s] + mean over the building's stories of Q[s'] FORMED WHILE THE PRODUCT LOADS IT (bg_gemm_nbr_f32, round 3: the
+    launch that used to write that [S, H] matrix is gone).  ``product_alone`` is the same product reading a finished
+    story term (round 2's roofline kernel; what the step still launches where the fused form declines the shape).
+    Algorithmic flops = 2 M N K for both."""
     import torch
     from building_gan_amd import ops
     H, Nv = hidden, int(batch.voxel_feature.shape[0])
@@ -121,32 +123,49 @@ def roofline_dominant_gemm(dev, batch, plan, hidden=128):
     xs = [torch.rand(Nv, H, device=dev) * 2 - 1, torch.rand(Nv, H, device=dev) * 2 - 1]
     W = torch.rand(H, 2 * H, device=dev) * 2 - 1
     posb = torch.rand(Nv, H, device=dev) * 2 - 1
-    term = torch.rand(plan.S, H, device=dev)
+    pq = torch.rand(plan.S, 2 * H, device=dev)
+    sb = plan.ops["story_building_mean"]
+    term = ops.spmm_add_raw(sb, pq[:, H:], pq[:, :H])
     rows = plan.story_gather.csr.col
-    run = lambda: ops.gemm_raw(xs, W, False, True, act=ops.ACT_LEAKY, slope=0.01, pre_add=term, pre_rows=rows,
-                               residual=xs[0], acc_init=posb)
-    # launch-bound in eager mode at this size: time the kernel inside a hipGraph of 20 launches
-    g = torch.cuda.CUDAGraph()
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        run()
-    torch.cuda.current_stream().wait_stream(s)
-    with torch.cuda.graph(g):
-        for _ in range(20):
+    out = torch.empty(Nv, H, device=dev)
+    alone = lambda: ops.gemm_raw(xs, W, False, True, act=ops.ACT_LEAKY, slope=0.01, pre_add=term, pre_rows=rows,
+                                 residual=xs[0], acc_init=posb, out=out)
+    fused = lambda: ops.gemm_nbr_raw(xs, W, pq, sb, rows, act=ops.ACT_LEAKY, slope=0.01, residual=xs[0], acc_init=posb, out=out)
+    took = fused() is not None
+
+    def graph_us(run):           # launch-bound in eager mode at this size: the kernel inside a hipGraph of 20 launches
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
             run()
-    ms = event_time_ms(g.replay, 10) / 20
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(g):
+            for _ in range(20):
+                run()
+        return event_time_ms(g.replay, 10) / 20 * 1e3
     flops = 2.0 * Nv * (2 * H) * H
-    ach = flops / (ms * 1e-3) / 1e12
+    us_alone = graph_us(alone)
+    us = graph_us(fused) if took else us_alone
+    ach = flops / (us * 1e-6) / 1e12
+    key = "gemm_generator_block_fused" if took else "gemm_generator_block"
     return {"kernel": "k_gemm_panel (16x16x4 f32 MFMA, 48-row x 64-column workgroups): generator block Linear, M=%d N=%d "
-                      "K=%d from the position + bias term, fused gather + LeakyReLU + residual epilogue" % (Nv, H, 2 * H),
+                      "K=%d from the position + bias term, %s + LeakyReLU + residual epilogue"
+                      % (Nv, H, 2 * H, "story term formed on load from the [S, 2H] story pairs and the building's story list"
+                         if took else "gathered story term"),
             "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_generator_block"),
+            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(key),
             "traffic_source": TRAFFIC_FILE,
-            "avg_launch_us": round(ms * 1e3, 2), "algorithmic_flops_per_launch": flops,
-            # operands [Nv, 2H] + weight + accumulator start [Nv, H] + result [Nv, H] + story term + row index
+            "avg_launch_us": round(us, 2), "algorithmic_flops_per_launch": flops,
+            # operands [Nv, 2H] + weight + accumulator start [Nv, H] + result [Nv, H] + story pairs + row index
             # (the residual re-reads the first operand)
-            "algorithmic_bytes_per_launch": 4.0 * (Nv * 2 * H + H * 2 * H + 2 * Nv * H + plan.S * H + Nv)}
+            "algorithmic_bytes_per_launch": 4.0 * (Nv * 2 * H + H * 2 * H + 2 * Nv * H + plan.S * 2 * H + Nv),
+            "product_alone": {"avg_launch_us": round(us_alone, 2),
+                              "achieved": round(flops / (us_alone * 1e-6) / 1e12, 3),
+                              "frac": round(flops / (us_alone * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                              "traffic": pmc_traffic("gemm_generator_block"),
+                              "what": "the same product reading a finished [S, H] story term (round 2's roofline kernel); the "
+                                      "fused launch replaces it AND the launch that wrote the term (~4.8 us in the step)"}}
 
 
 def microbench_message_passing(dev, pairs=4):

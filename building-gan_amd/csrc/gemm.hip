@@ -486,8 +486,8 @@ __global__ __launch_bounds__(256) void k_gemm_panel(GemmArgs g) {
     };
 
     // bg_gemm_nbr_f32: the addend row formed from its neighbour rows.  Four dependent loads (row index -> row pointers
-    // -> column indices -> rows): before the first operand request, after the first LDS write, then one per K step, so
-    // that none is waited for where it is issued; what the K loop is too short for runs after it.  Up to NBR_D neighbours travel through registers, longer rows continue in a loop.
+    // -> column indices -> rows): before the first operand request, after the first LDS write, then at K steps 1 and 2,
+    // so that none is waited for where it is issued (each has a whole step to arrive); what the K loop is too short for runs after it.  Up to NBR_D neighbours travel through registers, longer rows continue in a loop.
     // The rows a thread finishes are 16 apart and nearly always share their addend row s (voxels of a story are
     // contiguous): then ONE neighbour sum serves all of them, up to NBR_D neighbours in registers (a building's
     // stories: 8-11).  Threads whose rows differ, and longer neighbour lists, take the loop in nbr_finish.
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void k_gemm_panel(GemmArgs g) {
         const float* As = smem + (step & 1) * (A_SZ + B_SZ);
         const float* Bs = As + A_SZ;
         if (more) fetch(); else prefetch_epilogue();
-        if (step < 2) nbr_stage(step + 2);
+        if (step == 1 || step == 2) nbr_stage(step + 1);      // a whole K step after the level before it
 #pragma unroll
         for (int kg = 0; kg < BK / 16; ++kg) {
             float4 af[TMT], bf[NJ];
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void k_gemm_panel(GemmArgs g) {
     for (int step = 0; step + 1 < steps; ++step) one_step(step, std::true_type{});
     one_step(steps - 1, std::false_type{});
 
-    for (int st = steps + 2; st < 4; ++st) nbr_stage(st);
+    for (int st = steps >= 2 ? steps + 1 : 2; st < 4; ++st) nbr_stage(st);
     nbr_finish();
 
     // the panel's result through LDS (lane holds column (lane & 15), rows 4*(lane>>4) + q of each 16x16 tile), then

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, stream
-from .plan import Csr, LinOp, SCALE_NONE
+from .plan import Csr, LinOp, SCALE_DIV, SCALE_NONE
 
 ACT_NONE, ACT_LEAKY = 0, 1
 # Basis of the collapsed discriminator's polynomial in the aggregation operator A (include/bgan.h BG_CHAIN_*):
@@ -339,6 +339,42 @@ def _gemm_arrays():
     if not hasattr(t, "pa"):
         t.pa, t.la, t.ka = _PtrArr4(), _I64Arr4(), _I64Arr4()
     return t.pa, t.la, t.ka
+
+
+def gemm_nbr_raw(A: Sequence[torch.Tensor], W: torch.Tensor, pairs: torch.Tensor, nbr, rows: torch.Tensor,
+                 act: int = ACT_NONE, slope: float = 0.01, residual: Optional[torch.Tensor] = None,
+                 acc_init: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                 pre_residual_out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """bg_gemm_nbr_f32: C = epilogue(acc_init + cat(A, -1) W^T + addend[rows]) with the addend formed on load from
+    ``pairs`` [G, 2N] = [own part | neighbour part] and the LinOp ``nbr`` over its rows (mean over the neighbour rows +
+    the own part: what spmm_add_raw(nbr, pairs[:, N:], pairs[:, :N]) would write).  Returns None when the library
+    declines the shape (only the row-panel kernel does this): the caller then issues the two launches."""
+    lib = _lib.load()
+    N = W.shape[0]
+    keep = [_f32c(a) for a in A]
+    W2 = _f32c(W)
+    if pairs.dtype != torch.float32 or pairs.stride(1) != 1 or pairs.shape[1] != 2 * N or nbr.row_mode != SCALE_DIV:
+        return None
+    pa, la, ka = _gemm_arrays()
+    for i in range(4):
+        if i < len(keep):
+            pa[i], la[i], ka[i] = keep[i].data_ptr(), keep[i].stride(0), keep[i].shape[1]
+        else:
+            pa[i], la[i], ka[i] = None, 0, 0
+    M = keep[0].shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=W.device)
+    ptr = _lib.ptr
+    rc = lib.bg_gemm_nbr_f32(M, N, len(keep), pa, la, ka, ptr(W2), W2.stride(0), ptr(out), out.stride(0), None, act, slope,
+                             ptr(residual), residual.stride(0) if residual is not None else 0,
+                             ptr(pairs), pairs.stride(0), pairs.data_ptr() + 4 * N, pairs.stride(0),
+                             ptr(nbr.csr.rowptr), ptr(nbr.csr.col), ptr(nbr.row_scale), ptr(rows),
+                             ptr(acc_init), acc_init.stride(0) if acc_init is not None else 0,
+                             ptr(pre_residual_out), pre_residual_out.stride(0) if pre_residual_out is not None else 0, stream())
+    if rc == _lib.BG_ERR_SHAPE:
+        return None
+    check(rc, "bg_gemm_nbr_f32")
+    return out
 
 
 def gemm_raw(A: Sequence[torch.Tensor], B: torch.Tensor, transA: bool, transB: bool,

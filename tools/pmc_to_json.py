@@ -3,7 +3,9 @@ over tools/roofline_kernels.py -> JSON read by bench.py.  FETCH_SIZE is doubled 
 requests at 64 bytes, MI355X_MICROARCH.md); both counters are in KiB."""
 import csv, glob, json, sys, collections
 fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
-KEYS = {"gemm_generator_block": "k_gemm_panel<", "spmm_H128": "k_spmm_batched<32,", "spmm_H256": "k_spmm_batched<64,"}
+# (every substring of a key's tuple must occur in the kernel name)
+KEYS = {"gemm_generator_block": ("k_gemm_panel<", "false>"), "gemm_generator_block_fused": ("k_gemm_panel<", "true>"),
+        "spmm_H128": ("k_spmm_batched<32,",), "spmm_H256": ("k_spmm_batched<64,",)}
 def mean(d, counter):
     acc = collections.defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -11,7 +13,7 @@ def mean(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             for k, pat in KEYS.items():
-                if pat in r["Kernel_Name"]:
+                if all(p_ in r["Kernel_Name"] for p_ in pat):
                     acc[k].append(float(r["Counter_Value"]))
     return {k: sum(v[2:]) / len(v[2:]) for k, v in acc.items() if len(v) > 2}
 fe, wr = mean(fetch_dir, "FETCH_SIZE"), mean(write_dir, "WRITE_SIZE")

@@ -23,6 +23,11 @@ if which in ("gemm", "both"):
     for _ in range(iters):
         ops.gemm_raw(xs, W, False, True, act=ops.ACT_LEAKY, slope=0.01, pre_add=term,
                      pre_rows=plan.story_gather.csr.col, residual=xs[0], acc_init=posb)
+    # the same product with the story term formed on load (bg_gemm_nbr_f32: what the step launches since round 3)
+    pq = torch.rand(plan.S, 2 * H, device=dev)
+    for _ in range(iters):
+        ops.gemm_nbr_raw(xs, W, pq, plan.ops["story_building_mean"], plan.story_gather.csr.col, act=ops.ACT_LEAKY, slope=0.01,
+                         residual=xs[0], acc_init=posb)
 if which in ("spmm", "both"):
     batch = make_batch("microbench", seed=0).to(dev)
     plan = build_plan(batch)
