@@ -382,6 +382,65 @@ __global__ void k_add(const float4* __restrict__ a, const float4* __restrict__ b
 
 }  // namespace
 
+namespace {
+// Backward of a two-layer decoder WITHOUT activation, val = (X W1^T + b1) w2^T + b2 (models.py:251-264: the critic's
+// building / story heads), for the few rows a batch has (2 B graphs, 2 S stories), together with the gradient-penalty
+// path's share.  With dv = d val every gradient is rank one:
+//   u = dv^T X,  t = dv^T h,  sdv = sum dv,  c = column sums of dgp (the penalty's d pooled rows; each is W2 W1's gradient)
+//   g_w1 = w2 (x) (c + u)     g_b1 = sdv w2     g_w2 = t + W1 c     g_b2 = sdv     dX = dv (x) gp (+ add),  gp = w2 W1
+// One launch instead of ~11 (two split-K products with their reductions, four column sums, four small products).
+// Every workgroup forms u, c (all H2 columns) and sdv itself -- a few hundred rows -- then finishes its own rows of g_w1
+// (one per wave at a time) and its own rows of dX.  Fixed summation orders: deterministic.
+struct DecBwdArgs {
+    int R, Rp, H2, Hd;
+    const float* dv; const float* X; int64_t ldx; const float* h; int64_t ldh; const float* dgp; int64_t ldg;
+    const float* w1; int64_t ldw1; const float* w2; const float* gp; const float* add; int64_t lda;
+    float* g_w1; int64_t ldgw1; float* g_b1; float* g_w2; float* g_b2; float* dX; int64_t ldd;
+};
+__global__ __launch_bounds__(256) void k_decoder_bwd(DecBwdArgs a) {
+    extern __shared__ float dec_smem[];                 // cu [H2], c [H2]
+    float* cu = dec_smem;
+    float* cs = dec_smem + a.H2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nb = gridDim.x, b = blockIdx.x;
+    float sdv = 0.f;
+    for (int r = 0; r < a.R; ++r) sdv += a.dv[r];
+    for (int j = tid; j < a.H2; j += 256) {
+        float c = 0.f, u = 0.f;
+        for (int p = 0; p < a.Rp; ++p) c += a.dgp[(int64_t)p * a.ldg + j];
+        int r = 0;
+        for (; r + 4 <= a.R; r += 4) {
+            const float x0 = a.X[(int64_t)r * a.ldx + j], x1 = a.X[(int64_t)(r + 1) * a.ldx + j];
+            const float x2 = a.X[(int64_t)(r + 2) * a.ldx + j], x3 = a.X[(int64_t)(r + 3) * a.ldx + j];
+            u = fmaf(a.dv[r], x0, u); u = fmaf(a.dv[r + 1], x1, u); u = fmaf(a.dv[r + 2], x2, u); u = fmaf(a.dv[r + 3], x3, u);
+        }
+        for (; r < a.R; ++r) u = fmaf(a.dv[r], a.X[(int64_t)r * a.ldx + j], u);
+        cs[j] = c;
+        cu[j] = c + u;
+    }
+    __syncthreads();
+    // rows i = b, b + nb, .. of the first layer's gradients: one per wave at a time
+    for (int i = b + nb * wave; i < a.Hd; i += nb * 4) {
+        float q = 0.f, t = 0.f;
+        for (int j = lane; j < a.H2; j += 64) q = fmaf(cs[j], a.w1[(int64_t)i * a.ldw1 + j], q);
+        for (int r = lane; r < a.R; r += 64) t = fmaf(a.dv[r], a.h[(int64_t)r * a.ldh + i], t);
+        q = bg_wave_sum(q); t = bg_wave_sum(t);
+        const float w2i = a.w2[i];
+        for (int j = lane; j < a.H2; j += 64) a.g_w1[(int64_t)i * a.ldgw1 + j] = w2i * cu[j];
+        if (lane == 0) { a.g_w2[i] = t + q; a.g_b1[i] = sdv * w2i; }
+    }
+    // rows r = b, b + nb, .. of dX
+    for (int r = b; r < a.R; r += nb) {
+        const float d = a.dv[r];
+        for (int j = tid; j < a.H2; j += 256) {
+            float v = d * a.gp[j];
+            if (a.add) v += a.add[(int64_t)r * a.lda + j];
+            a.dX[(int64_t)r * a.ldd + j] = v;
+        }
+    }
+    if (b == 0 && tid == 0) a.g_b2[0] = sdv;
+}
+}  // namespace
+
 extern "C" {
 
 int bg_regroup_f32(const float* src, float* dst, int64_t n, int64_t K, int64_t P, int64_t W, int to_outer, bgStream stream) {
@@ -651,6 +710,23 @@ int bg_d_coef_init_bwd_f32(const float* G, int64_t slab, int64_t L, int64_t H, i
                            float* gw_tail, int64_t ldw, float* g_bc, bgStream stream) {
     return bg_d_coef_init_bwd_strided_f32(G, slab, L, H, nf, nl, ML, ds, dl, g_fe_w, g_fe_b, g_le_w, g_le_b, gw_tail, ldw,
                                           g_bc, 1, 0, stream);
+}
+
+int bg_decoder_bwd_f32(int64_t R, int64_t Rp, int64_t H2, int64_t Hd, const float* dv, const float* X, int64_t ldx,
+                       const float* h, int64_t ldh, const float* dgp, int64_t ldg, const float* w1, int64_t ldw1,
+                       const float* w2, const float* gp, const float* add, int64_t lda, float* g_w1, int64_t ldgw1,
+                       float* g_b1, float* g_w2, float* g_b2, float* dX, int64_t ldd, bgStream stream) {
+    if (R <= 0 || Rp < 0 || H2 <= 0 || Hd <= 0) return BG_ERR_ARG;
+    if (!dv || !X || !h || !w1 || !w2 || !gp || !g_w1 || !g_b1 || !g_w2 || !g_b2 || !dX || (Rp > 0 && !dgp)) return BG_ERR_ARG;
+    if (ldx < H2 || ldh < Hd || (Rp > 0 && ldg < H2) || ldw1 < H2 || ldgw1 < H2 || ldd < H2 || (add && lda < H2)) return BG_ERR_ARG;
+    if (R > (1 << 20) || Rp > (1 << 20) || H2 > 4096 || Hd > (1 << 20)) return BG_ERR_SHAPE;     // a head's sizes, not a layer's
+    DecBwdArgs a{(int)R, (int)Rp, (int)H2, (int)Hd, dv, X, ldx, h, ldh, dgp, ldg, w1, ldw1, w2, gp, add, lda,
+                 g_w1, ldgw1, g_b1, g_w2, g_b2, dX, ldd};
+    int nb = (int)((Hd + 3) / 4);                       // one first-layer row per wave
+    if (nb > 64) nb = 64;
+    k_decoder_bwd<<<nb, 256, 2 * (size_t)H2 * sizeof(float), (hipStream_t)stream>>>(a);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
 }
 
 }  // extern "C"

@@ -531,35 +531,15 @@ extern "C" int bg_critic_head_backward_f32(const bgCriticHead* hp, float coef, c
     BG_TRY(mm(2 * N, H2, K1 * dl, b.dX, K1 * dl, Wl, H2, 0, b.dG2, nullptr, nullptr, s));                   // d G2 = dX Wl
     BG_TRY(bg_gather_arg_f32(b.dG2, H2, b.arg_b, b.dgp_b, H2, B, H2, s));
     BG_TRY(bg_gather_arg_f32(b.dG2 + N * H2, H2, b.arg_s, b.dgp_s, H2, S, H2, s));
-    // every row of d D / d pooled is the same W2 W1: its gradient is the column sum c; g W1 = W2^T c, g W2 = c W1^T
-    BG_TRY(bg_colsum_f32(b.dgp_b, H2, B, H2, b.colsum, colsum_blocks(B), b.c_b, 0, s));
-    BG_TRY(bg_colsum_f32(b.dgp_s, H2, S, H2, b.colsum, colsum_blocks(S), b.c_s, 0, s));
-    {
-        const float* A[4] = {h.b_w2, nullptr, nullptr, nullptr};
-        int64_t ld[4] = {Hd, 0, 0, 0}, Ks[4] = {1, 0, 0, 0};
-        BG_TRY(bg_gemm_f32(1, 0, Hd, H2, 1, A, ld, Ks, b.c_b, H2, g_b_w1, H2, nullptr, nullptr, BG_ACT_NONE, 0.f, nullptr, 0,
-                           nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
-        A[0] = h.s_w2;
-        BG_TRY(bg_gemm_f32(1, 0, Hd, H2, 1, A, ld, Ks, b.c_s, H2, g_s_w1, H2, nullptr, nullptr, BG_ACT_NONE, 0.f, nullptr, 0,
-                           nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
-    }
-    BG_TRY(mm(1, Hd, H2, b.c_b, H2, h.b_w1, H2, 1, g_b_w2, nullptr, nullptr, s));
-    BG_TRY(mm(1, Hd, H2, b.c_s, H2, h.s_w1, H2, 1, g_s_w2, nullptr, nullptr, s));
-    // ---- D(real), D(fake): building decoder, back through the story level, story decoder
-    BG_TRY(tn(1, Hd, 2 * B, b.dvb, b.hb, g_b_w2, b.splitk, 1, s));
-    BG_TRY(bg_colsum_f32(b.dvb, 1, 2 * B, 1, b.colsum, colsum_blocks(2 * B), g_b_b2, 0, s));
-    BG_TRY(mm(2 * B, Hd, 1, b.dvb, 1, h.b_w2, Hd, 0, b.dhb, nullptr, nullptr, s));
-    BG_TRY(tn(Hd, H2, 2 * B, b.dhb, b.Xb, g_b_w1, b.splitk, 1, s));
-    BG_TRY(bg_colsum_f32(b.dhb, Hd, 2 * B, Hd, b.colsum, colsum_blocks(2 * B), g_b_b1, 0, s));
-    BG_TRY(mm(2 * B, H2, Hd, b.dhb, Hd, h.b_w1, H2, 0, b.dXb, nullptr, nullptr, s));
+    // ---- both decoders' backward, one launch each (bg_decoder_bwd_f32: every gradient is rank one).  Penalty share:
+    // every row of d D / d pooled is the same w2 W1, so its gradient is the column sum c of the rows gathered above
+    // (g W1 = w2 (x) c, g W2 = W1 c).  D(real), D(fake): building decoder, back through the story level, story decoder.
+    BG_TRY(bg_decoder_bwd_f32(2 * B, B, H2, Hd, b.dvb, b.Xb, H2, b.hb, Hd, b.dgp_b, H2, h.b_w1, H2, h.b_w2, b.gp_b, nullptr, 0,
+                              g_b_w1, H2, g_b_b1, g_b_w2, g_b_b2, b.dXb, H2, s));
     for (int p = 0; p < 2; ++p)
         BG_TRY(bg_scatter_arg_f32(b.dXb + p * B * H2, H2, b.ab + p * B * H2, h.graph_of_story, b.T + p * S * H2, H2, B, S, H2, s));
-    BG_TRY(tn(1, Hd, 2 * S, b.dvs, b.hs, g_s_w2, b.splitk, 1, s));
-    BG_TRY(bg_colsum_f32(b.dvs, 1, 2 * S, 1, b.colsum, colsum_blocks(2 * S), g_s_b2, 0, s));
-    BG_TRY(mm(2 * S, Hd, 1, b.dvs, 1, h.s_w2, Hd, 0, b.dhs, nullptr, nullptr, s));
-    BG_TRY(tn(Hd, H2, 2 * S, b.dhs, b.Xs, g_s_w1, b.splitk, 1, s));
-    BG_TRY(bg_colsum_f32(b.dhs, Hd, 2 * S, Hd, b.colsum, colsum_blocks(2 * S), g_s_b1, 0, s));
-    BG_TRY(mm(2 * S, H2, Hd, b.dhs, Hd, h.s_w1, H2, 0, b.dXs, nullptr, b.T, s));          // + what arrived through the buildings
+    BG_TRY(bg_decoder_bwd_f32(2 * S, S, H2, Hd, b.dvs, b.Xs, H2, b.hs, Hd, b.dgp_s, H2, h.s_w1, H2, h.s_w2, b.gp_s, b.T, H2,
+                              g_s_w1, H2, g_s_b1, g_s_w2, g_s_b2, b.dXs, H2, s));          // + what arrived through the buildings
     // to the arg-max voxels (v[0], v[1] are free after the forward's pooling: they take d v), then the coefficient table
     for (int p = 0; p < 2; ++p)
         BG_TRY(bg_scatter_arg_f32(b.dXs + p * S * H2, H2, b.as + p * S * H2, h.story_of_voxel, b.v[p], H2, S, N, H2, s));

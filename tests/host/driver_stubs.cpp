@@ -273,6 +273,15 @@ int bg_copy2d_bytes(void* dst, int64_t dpitch, const void* src, int64_t spitch, 
     rec(20, a, sizeof(a) / 8);
     return 0;
 }
+int bg_decoder_bwd_f32(int64_t R, int64_t Rp, int64_t H2, int64_t Hd, const float* dv, const float* X, int64_t ldx,
+                       const float* h, int64_t ldh, const float* dgp, int64_t ldg, const float* w1, int64_t ldw1,
+                       const float* w2, const float* gp, const float* add, int64_t lda, float* g_w1, int64_t ldgw1,
+                       float* g_b1, float* g_w2, float* g_b2, float* dX, int64_t ldd, bgStream) {
+    int64_t a[] = {R, Rp, H2, Hd, P(dv), P(X), ldx, P(h), ldh, P(dgp), ldg, P(w1), ldw1, P(w2), P(gp), P(add), lda,
+                   P(g_w1), ldgw1, P(g_b1), P(g_w2), P(g_b2), P(dX), ldd};
+    rec(37, a, sizeof(a) / 8);
+    return 0;
+}
 // one launch of several fills / copies: a marker (kind 27: the job count) followed by each job as the single call it
 // replaces (kind 25 / 20), so the extent checks of the tests apply unchanged
 int bg_fill_copy_batch(int32_t n_jobs, void* const* dst, const int64_t* dpitch, const void* const* src,

@@ -502,6 +502,18 @@ def _check_critic_calls(calls, R, h):
             dst, dp, src, sp, width, height = a
             R.check(dst, (height - 1) * dp + width, tag + " dst")
             R.check(src, (height - 1) * sp + width, tag + " src")
+        elif kind == 37:
+            (Rr, Rp, H2, Hd, dv, X, ldx, hh, ldh, dgp, ldg, w1, ldw1, w2, gp, add, lda, g_w1, ldgw1, g_b1, g_w2, g_b2, dX, ldd) = a
+            assert (Rr, Rp) in ((2 * B, B), (2 * S, S)) and H2 == h.H2 and Hd == h.Hd
+            R.check(dv, Rr * f, tag + " dv"); R.check(X, ((Rr - 1) * ldx + H2) * f, tag + " X")
+            R.check(hh, ((Rr - 1) * ldh + Hd) * f, tag + " h"); R.check(dgp, ((Rp - 1) * ldg + H2) * f, tag + " dgp")
+            R.check(w1, ((Hd - 1) * ldw1 + H2) * f, tag + " w1"); R.check(w2, Hd * f, tag + " w2"); R.check(gp, H2 * f, tag + " gp")
+            if add:
+                R.check(add, ((Rr - 1) * lda + H2) * f, tag + " add")
+            which = "b" if Rr == 2 * B and Rp == B and not add else "s"
+            assert R.check(g_w1, ((Hd - 1) * ldgw1 + H2) * f, tag) == "g_%s_w1" % which and R.check(g_b1, Hd * f, tag) == "g_%s_b1" % which
+            assert R.check(g_w2, Hd * f, tag) == "g_%s_w2" % which and R.check(g_b2, f, tag) == "g_%s_b2" % which
+            assert R.check(dX, ((Rr - 1) * ldd + H2) * f, tag + " dX") == "workspace" and dX != X and dX != add
         else:
             raise AssertionError("unexpected launcher %d" % kind)
 
@@ -511,24 +523,11 @@ def test_critic_head_host_sequence_and_extents(drv, N, S, B, basis):
     (rc_f, rc_b), fwd, bwd, R, h = _critic_run(drv, N, S, B, basis=basis)
     assert rc_f == 0 and rc_b == 0
     assert [k for k, _ in fwd] == [10, 1, 28, 1, 11, 11, 11, 11, 1, 1, 1, 1, 11, 11, 12, 1, 1, 13, 13, 1, 10, 14, 15]
-    assert [k for k, _ in bwd] == ([16, 20, 14, 10, 1, 12, 12, 17, 17, 1, 1, 1, 1] + [19, 17, 1, 19, 17, 1, 13, 13]
-                                   + [19, 17, 1, 19, 17, 1] + [13, 13, 19, 18, 19])
+    # 37: a decoder's whole backward (penalty share included) as one launch
+    assert [k for k, _ in bwd] == [16, 20, 14, 10, 1, 12, 12, 37, 13, 13, 37, 13, 13, 19, 18, 19]
     _check_critic_calls(fwd, R, h)
     _check_critic_calls(bwd, R, h)
-    # where the gradients land: every one of the nine outputs is written (assigned first, then accumulated into)
-    written = {}
-    for k, a in bwd:
-        if k == 19:
-            written.setdefault(R.check(a[8], 4, "C"), []).append(a[12])
-        elif k == 17 and R.check(a[6], 4, "out") != "workspace":
-            written.setdefault(R.check(a[6], 4, "out"), []).append(a[7])
-        elif k == 1:
-            nm = R.check(a[19], 4, "C")
-            if nm.startswith("g"):
-                written.setdefault(nm, []).append(0)
-    assert set(written) == {"gW", "g_b_w1", "g_b_b1", "g_b_w2", "g_b_b2", "g_s_w1", "g_s_b1", "g_s_w2", "g_s_b2"}
-    for nm, acc in written.items():
-        assert acc[0] == 0 and all(x == 1 for x in acc[1:] if nm != "gW"), (nm, acc)
+    # where the gradients land: the eight decoder outputs by the two decoder launches (checked above), gW by the products
     # gW: static rows assigned once, label rows assigned then accumulated twice
     gw = [(a[8], a[12]) for k, a in bwd if k == 19 and R.check(a[8], 4, "C") == "gW"]
     base = R.r["gW"][0]

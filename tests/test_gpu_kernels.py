@@ -1199,3 +1199,42 @@ def test_fills_and_copies_as_one_launch(cuda):
     wd[1] = 4 * 41 + 2
     assert lib.bg_fill_copy_batch(n, dst, dp, src, sp, wd, rw, st) == -1
     assert lib.bg_fill_copy_batch(0, None, None, None, None, None, None, st) == 0
+
+
+@pytest.mark.parametrize("R,Rp,H2,Hd,with_add", [(16, 8, 256, 128, False), (176, 88, 256, 128, True), (5, 0, 40, 9, True)])
+def test_decoder_backward_in_one_launch(cuda, R, Rp, H2, Hd, with_add):
+    """bg_decoder_bwd_f32 (a two-layer decoder's backward on a batch's pooled rows + the penalty path's share, every
+    gradient a rank-one expression) against autograd in float64 on the same function."""
+    from building_gan_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(R + Hd)
+    rnd = lambda *s: (torch.rand(*s, generator=gen, dtype=torch.float64) * 2 - 1)
+    X, w1, b1, w2, b2 = rnd(R, H2), rnd(Hd, H2).requires_grad_(), rnd(Hd).requires_grad_(), rnd(1, Hd).requires_grad_(), rnd(1).requires_grad_()
+    Xr = X.clone().requires_grad_()
+    dv, add = rnd(R), rnd(R, H2)
+    P = rnd(max(Rp, 1), H2)[:Rp].clone().requires_grad_()          # the penalty's pooled rows: D is linear in them
+    dgp = rnd(max(Rp, 1), H2)[:Rp]
+    h = Xr @ w1.t() + b1
+    val = (h @ w2.t() + b2).view(-1)
+    pen = (((P @ w1.t() + b1) @ w2.t() + b2).view(-1)).sum() * 0         # (value unused: the penalty differentiates d D / d P)
+    gP = torch.autograd.grad(((P @ w1.t() + b1) @ w2.t()).sum(), P, create_graph=True)[0] if Rp else None   # rows = w2 W1
+    obj = (val * dv).sum() + ((gP * dgp).sum() if Rp else 0.0) + pen
+    obj.backward()
+    f = lambda t: t.detach().float().contiguous().to(cuda)
+    gp = f((w2 @ w1).view(-1))
+    out = {n: torch.full(s, float("nan"), device=cuda) for n, s in
+           (("g_w1", (Hd, H2)), ("g_b1", (Hd,)), ("g_w2", (Hd,)), ("g_b2", (1,)), ("dX", (R, H2)))}
+    Xc, hc, dvc, w1c, w2c, dgc, addc = f(X), f(h), f(dv), f(w1), f(w2.view(-1)), f(dgp) if Rp else None, f(add) if with_add else None
+    rc = lib.bg_decoder_bwd_f32(R, Rp, H2, Hd, dvc.data_ptr(), Xc.data_ptr(), H2, hc.data_ptr(), Hd,
+                                dgc.data_ptr() if Rp else None, H2, w1c.data_ptr(), H2, w2c.data_ptr(), gp.data_ptr(),
+                                addc.data_ptr() if with_add else None, H2, out["g_w1"].data_ptr(), H2, out["g_b1"].data_ptr(),
+                                out["g_w2"].data_ptr(), out["g_b2"].data_ptr(), out["dX"].data_ptr(), H2,
+                                torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    ref = {"g_w1": w1.grad, "g_b1": b1.grad, "g_w2": w2.grad.view(-1), "g_b2": b2.grad,
+           "dX": Xr.grad + (add if with_add else 0.0)}
+    for n, r in ref.items():
+        err = float((out[n].cpu().double() - r).abs().max()) / max(float(r.abs().max()), 1e-30)
+        assert err < 1e-5, (n, err)              # fp32 sums of signed terms (sum dv cancels to a few percent of sum |dv|)
+    assert lib.bg_decoder_bwd_f32(0, 0, H2, Hd, *([None] * 2), 0, None, 0, None, 0, None, 0, None, None, None, 0, None, 0,
+                                  None, None, None, None, 0, None) == -1
