@@ -87,8 +87,9 @@ SIGNATURES = {
     "bg_cheb_shift_slabs_f32": [_p, _p, _i64, _i64, _i64, _i64, _i64, _i32, _p],
     "bg_gemm_nbr_f32": [_i64, _i64, _int, _p, _p, _p, _p, _i64, _p, _i64, _p, _int, _f, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p,
                         _p, _i64, _p, _i64, _p],
-    "bg_decoder_bwd_f32": [_i64, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _p, _p,
+    "bg_decoder_bwd_f32": [_i64, _i64, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _p, _p,
                            _p, _i64, _p],
+    "bg_decoder_fwd_f32": [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p],
     "bg_gemm_cheb_f32": [_int, _i64, _i64, _p, _i64, _i64, _i64, _i64, _int, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p],
     "bg_attention_bwd_head_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _i64,
                                   _i64, _i64, _p],

@@ -386,58 +386,141 @@ namespace {
 // Backward of a two-layer decoder WITHOUT activation, val = (X W1^T + b1) w2^T + b2 (models.py:251-264: the critic's
 // building / story heads), for the few rows a batch has (2 B graphs, 2 S stories), together with the gradient-penalty
 // path's share.  With dv = d val every gradient is rank one:
-//   u = dv^T X,  t = dv^T h,  sdv = sum dv,  c = column sums of dgp (the penalty's d pooled rows; each is W2 W1's gradient)
-//   g_w1 = w2 (x) (c + u)     g_b1 = sdv w2     g_w2 = t + W1 c     g_b2 = sdv     dX = dv (x) gp (+ add),  gp = w2 W1
+//   u = dv^T X,  sdv = sum dv,  c = column sums of dgp (the penalty's d pooled rows; each is W2 W1's gradient)
+//   g_w1 = w2 (x) (c + u)     g_b1 = sdv w2     g_w2 = W1 (c + u) + sdv b1     g_b2 = sdv     dX = dv (x) gp (+ add),  gp = w2 W1
+// (dv^T h = W1 u + sdv b1 for the hidden rows h = X W1^T + b1, which are therefore never formed, forward or backward)
 // One launch instead of ~11 (two split-K products with their reductions, four column sums, four small products).
 // Every workgroup forms u, c (all H2 columns) and sdv itself -- a few hundred rows -- then finishes its own rows of g_w1
 // (one per wave at a time) and its own rows of dX.  Fixed summation orders: deterministic.
 struct DecBwdArgs {
     int R, Rp, H2, Hd;
-    const float* dv; const float* X; int64_t ldx; const float* h; int64_t ldh; const float* dgp; int64_t ldg;
+    const float* dv; const float* X; int64_t ldx; const float* b1; const float* dgp; int64_t ldg;
     const float* w1; int64_t ldw1; const float* w2; const float* gp; const float* add; int64_t lda;
     float* g_w1; int64_t ldgw1; float* g_b1; float* g_w2; float* g_b2; float* dX; int64_t ldd;
 };
-__global__ __launch_bounds__(256) void k_decoder_bwd(DecBwdArgs a) {
-    extern __shared__ float dec_smem[];                 // cu [H2], c [H2]
+// 1024 threads: thread (j, q) sums rows r = q (mod 4) of column j with 16 loads in flight (a sequential loop over a few
+// hundred rows was ~20 us of dependent round trips), the four partial sums are added in q order through LDS.
+constexpr int DEC_T = 1024, DEC_Q = 4, DEC_U = 16;
+__global__ __launch_bounds__(DEC_T) void k_decoder_bwd(DecBwdArgs a) {
+    extern __shared__ float dec_smem[];                 // c + u [H2] | partial [DEC_Q][H2] | dv [R]
     float* cu = dec_smem;
-    float* cs = dec_smem + a.H2;
+    float* part = dec_smem + a.H2;
+    float* sdvp = part + DEC_Q * a.H2;                  // [DEC_T / 64] wave partials of sum dv
+    float* dvs = sdvp + DEC_T / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nb = gridDim.x, b = blockIdx.x;
-    float sdv = 0.f;
-    for (int r = 0; r < a.R; ++r) sdv += a.dv[r];
-    for (int j = tid; j < a.H2; j += 256) {
-        float c = 0.f, u = 0.f;
-        for (int p = 0; p < a.Rp; ++p) c += a.dgp[(int64_t)p * a.ldg + j];
-        int r = 0;
-        for (; r + 4 <= a.R; r += 4) {
-            const float x0 = a.X[(int64_t)r * a.ldx + j], x1 = a.X[(int64_t)(r + 1) * a.ldx + j];
-            const float x2 = a.X[(int64_t)(r + 2) * a.ldx + j], x3 = a.X[(int64_t)(r + 3) * a.ldx + j];
-            u = fmaf(a.dv[r], x0, u); u = fmaf(a.dv[r + 1], x1, u); u = fmaf(a.dv[r + 2], x2, u); u = fmaf(a.dv[r + 3], x3, u);
-        }
-        for (; r < a.R; ++r) u = fmaf(a.dv[r], a.X[(int64_t)r * a.ldx + j], u);
-        cs[j] = c;
-        cu[j] = c + u;
-    }
+    float sp = 0.f;
+    for (int r = tid; r < a.R; r += DEC_T) { const float d = a.dv[r]; dvs[r] = d; sp += d; }
+    sp = bg_wave_sum(sp);
+    if (lane == 0) sdvp[wave] = sp;
     __syncthreads();
-    // rows i = b, b + nb, .. of the first layer's gradients: one per wave at a time
-    for (int i = b + nb * wave; i < a.Hd; i += nb * 4) {
-        float q = 0.f, t = 0.f;
-        for (int j = lane; j < a.H2; j += 64) q = fmaf(cs[j], a.w1[(int64_t)i * a.ldw1 + j], q);
-        for (int r = lane; r < a.R; r += 64) t = fmaf(a.dv[r], a.h[(int64_t)r * a.ldh + i], t);
-        q = bg_wave_sum(q); t = bg_wave_sum(t);
-        const float w2i = a.w2[i];
-        for (int j = lane; j < a.H2; j += 64) a.g_w1[(int64_t)i * a.ldgw1 + j] = w2i * cu[j];
-        if (lane == 0) { a.g_w2[i] = t + q; a.g_b1[i] = sdv * w2i; }
+    float sdv = 0.f;
+#pragma unroll
+    for (int w = 0; w < DEC_T / 64; ++w) sdv += sdvp[w];
+    if (a.g_w1) {                                       // (only dX asked for: no column sums needed)
+        const int nj = DEC_T / DEC_Q;                   // columns per pass
+        for (int j0 = 0; j0 < a.H2; j0 += nj) {
+            const int j = j0 + tid % nj, q = tid / nj;
+            float acc = 0.f;
+            if (j < a.H2) {
+                for (int p0 = q; p0 < a.Rp; p0 += DEC_Q * DEC_U) {
+                    float v[DEC_U];
+#pragma unroll
+                    for (int k = 0; k < DEC_U; ++k) { const int p = p0 + DEC_Q * k; v[k] = p < a.Rp ? a.dgp[(int64_t)p * a.ldg + j] : 0.f; }
+#pragma unroll
+                    for (int k = 0; k < DEC_U; ++k) acc += v[k];
+                }
+                for (int r0 = q; r0 < a.R; r0 += DEC_Q * DEC_U) {
+                    float v[DEC_U];
+#pragma unroll
+                    for (int k = 0; k < DEC_U; ++k) { const int r = r0 + DEC_Q * k; v[k] = r < a.R ? a.X[(int64_t)r * a.ldx + j] : 0.f; }
+#pragma unroll
+                    for (int k = 0; k < DEC_U; ++k) { const int r = r0 + DEC_Q * k; acc = fmaf(r < a.R ? dvs[r] : 0.f, v[k], acc); }
+                }
+                part[q * a.H2 + j] = acc;
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < a.H2; j += DEC_T) {
+            float t = part[j];
+#pragma unroll
+            for (int q = 1; q < DEC_Q; ++q) t += part[q * a.H2 + j];
+            cu[j] = t;
+        }
+        __syncthreads();
+        // rows i = b, b + nb, .. of the first layer's gradients: one per wave at a time
+        for (int i = b + nb * wave; i < a.Hd; i += nb * (DEC_T / 64)) {
+            float q = 0.f;
+            for (int j = lane; j < a.H2; j += 64) q = fmaf(cu[j], a.w1[(int64_t)i * a.ldw1 + j], q);
+            q = bg_wave_sum(q);
+            const float w2i = a.w2[i];
+            for (int j = lane; j < a.H2; j += 64) a.g_w1[(int64_t)i * a.ldgw1 + j] = w2i * cu[j];
+            if (lane == 0) { a.g_w2[i] = fmaf(sdv, a.b1[i], q); a.g_b1[i] = sdv * w2i; }
+        }
     }
     // rows r = b, b + nb, .. of dX
-    for (int r = b; r < a.R; r += nb) {
-        const float d = a.dv[r];
-        for (int j = tid; j < a.H2; j += 256) {
-            float v = d * a.gp[j];
-            if (a.add) v += a.add[(int64_t)r * a.lda + j];
-            a.dX[(int64_t)r * a.ldd + j] = v;
+    {
+        const int64_t per = ((int64_t)a.R + nb - 1) / nb, lo = (int64_t)b * per, hi = lo + per < a.R ? lo + per : a.R;
+        for (int64_t e = lo * a.H2 + tid; e < hi * a.H2; e += DEC_T) {
+            const int64_t r = e / a.H2;
+            const int j = (int)(e - r * a.H2);
+            float v = dvs[r] * a.gp[j];
+            if (a.add) v += a.add[r * a.lda + j];
+            a.dX[r * a.ldd + j] = v;
         }
     }
-    if (b == 0 && tid == 0) a.g_b2[0] = sdv;
+    if (a.g_b2 && b == 0 && tid == 0) a.g_b2[0] = sdv;
+}
+
+// The same decoder's forward on those rows: without an activation between the layers val = X (w2 W1)^T + (w2 . b1 + b2),
+// so the launch forms gp = w2 W1 [H2] (kept: the backward and the penalty's closed form need it) and one dot product
+// per row, instead of two Linear launches and a separate product for gp.  Every workgroup forms gp itself.
+struct DecFwdArgs {
+    int R, H2, Hd;
+    const float* X; int64_t ldx; const float* w1; int64_t ldw1; const float* b1; const float* w2; const float* b2;
+    float* val; float* gp;
+};
+__global__ __launch_bounds__(DEC_T) void k_decoder_fwd(DecFwdArgs a) {
+    extern __shared__ float dec_smem[];                 // gp [H2] | partial [DEC_Q][H2]
+    float* gps = dec_smem;
+    float* part = dec_smem + a.H2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nb = gridDim.x, b = blockIdx.x;
+    const int nj = DEC_T / DEC_Q;
+    for (int j0 = 0; j0 < a.H2; j0 += nj) {
+        const int j = j0 + tid % nj, q = tid / nj;
+        float acc = 0.f;
+        if (j < a.H2) {
+            for (int i0 = q; i0 < a.Hd; i0 += DEC_Q * DEC_U) {
+                float v[DEC_U], w[DEC_U];
+#pragma unroll
+                for (int k = 0; k < DEC_U; ++k) {
+                    const int i = i0 + DEC_Q * k;
+                    v[k] = i < a.Hd ? a.w1[(int64_t)i * a.ldw1 + j] : 0.f;
+                    w[k] = i < a.Hd ? a.w2[i] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < DEC_U; ++k) acc = fmaf(w[k], v[k], acc);
+            }
+            part[q * a.H2 + j] = acc;
+        }
+    }
+    float c0 = 0.f;
+    for (int i = lane; i < a.Hd; i += 64) c0 = fmaf(a.w2[i], a.b1[i], c0);
+    c0 = bg_wave_sum(c0) + a.b2[0];
+    __syncthreads();
+    for (int j = tid; j < a.H2; j += DEC_T) {
+        float t = part[j];
+#pragma unroll
+        for (int q = 1; q < DEC_Q; ++q) t += part[q * a.H2 + j];
+        gps[j] = t;
+        if (b == 0) a.gp[j] = t;
+    }
+    __syncthreads();
+    for (int r = b * (DEC_T / 64) + wave; r < a.R; r += nb * (DEC_T / 64)) {
+        float d = 0.f;
+        for (int j = lane; j < a.H2; j += 64) d = fmaf(a.X[(int64_t)r * a.ldx + j], gps[j], d);
+        d = bg_wave_sum(d);
+        if (lane == 0) a.val[r] = d + c0;
+    }
 }
 }  // namespace
 
@@ -713,18 +796,35 @@ int bg_d_coef_init_bwd_f32(const float* G, int64_t slab, int64_t L, int64_t H, i
 }
 
 int bg_decoder_bwd_f32(int64_t R, int64_t Rp, int64_t H2, int64_t Hd, const float* dv, const float* X, int64_t ldx,
-                       const float* h, int64_t ldh, const float* dgp, int64_t ldg, const float* w1, int64_t ldw1,
+                       const float* b1, const float* dgp, int64_t ldg, const float* w1, int64_t ldw1,
                        const float* w2, const float* gp, const float* add, int64_t lda, float* g_w1, int64_t ldgw1,
                        float* g_b1, float* g_w2, float* g_b2, float* dX, int64_t ldd, bgStream stream) {
     if (R <= 0 || Rp < 0 || H2 <= 0 || Hd <= 0) return BG_ERR_ARG;
-    if (!dv || !X || !h || !w1 || !w2 || !gp || !g_w1 || !g_b1 || !g_w2 || !g_b2 || !dX || (Rp > 0 && !dgp)) return BG_ERR_ARG;
-    if (ldx < H2 || ldh < Hd || (Rp > 0 && ldg < H2) || ldw1 < H2 || ldgw1 < H2 || ldd < H2 || (add && lda < H2)) return BG_ERR_ARG;
-    if (R > (1 << 20) || Rp > (1 << 20) || H2 > 4096 || Hd > (1 << 20)) return BG_ERR_SHAPE;     // a head's sizes, not a layer's
-    DecBwdArgs a{(int)R, (int)Rp, (int)H2, (int)Hd, dv, X, ldx, h, ldh, dgp, ldg, w1, ldw1, w2, gp, add, lda,
+    if (!dv || !X || !gp || !dX || (Rp > 0 && !dgp)) return BG_ERR_ARG;
+    const bool grads = g_w1 || g_b1 || g_w2 || g_b2;                  // the four parameter gradients: all or none
+    if (grads && (!g_w1 || !g_b1 || !g_w2 || !g_b2 || !w1 || !w2 || !b1 || ldw1 < H2 || ldgw1 < H2)) return BG_ERR_ARG;
+    if (ldx < H2 || (Rp > 0 && ldg < H2) || ldd < H2 || (add && lda < H2)) return BG_ERR_ARG;
+    if (R > 8192 || Rp > (1 << 20) || H2 > 1024 || Hd > (1 << 20)) return BG_ERR_SHAPE;     // a head's sizes, not a layer's (LDS: dv, column sums)
+    DecBwdArgs a{(int)R, (int)Rp, (int)H2, (int)Hd, dv, X, ldx, b1, dgp, ldg, w1, ldw1, w2, gp, add, lda,
                  g_w1, ldgw1, g_b1, g_w2, g_b2, dX, ldd};
-    int nb = (int)((Hd + 3) / 4);                       // one first-layer row per wave
+    if (R > 8192) return BG_ERR_SHAPE;                  // dv is kept in LDS
+    int nb = (int)((Hd + DEC_T / 64 - 1) / (DEC_T / 64));               // one first-layer row per wave
+    if (nb < 8) nb = 8;
     if (nb > 64) nb = 64;
-    k_decoder_bwd<<<nb, 256, 2 * (size_t)H2 * sizeof(float), (hipStream_t)stream>>>(a);
+    const size_t lds = ((size_t)(1 + DEC_Q) * H2 + DEC_T / 64 + R) * sizeof(float);
+    k_decoder_bwd<<<nb, DEC_T, lds, (hipStream_t)stream>>>(a);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+int bg_decoder_fwd_f32(int64_t R, int64_t H2, int64_t Hd, const float* X, int64_t ldx, const float* w1, int64_t ldw1,
+                       const float* b1, const float* w2, const float* b2, float* val, float* gp, bgStream stream) {
+    if (R <= 0 || H2 <= 0 || Hd <= 0 || !X || !w1 || !b1 || !w2 || !b2 || !val || !gp || ldx < H2 || ldw1 < H2) return BG_ERR_ARG;
+    if (R > (1 << 20) || H2 > 1024 || Hd > (1 << 20)) return BG_ERR_SHAPE;
+    DecFwdArgs a{(int)R, (int)H2, (int)Hd, X, ldx, w1, ldw1, b1, w2, b2, val, gp};
+    int nb = (int)((R + DEC_T / 64 - 1) / (DEC_T / 64));                // one row per wave
+    if (nb > 32) nb = 32;
+    k_decoder_fwd<<<nb, DEC_T, (size_t)(1 + DEC_Q) * H2 * sizeof(float), (hipStream_t)stream>>>(a);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -472,17 +472,14 @@ extern "C" int bg_critic_head_forward_f32(const bgCriticHead* hp, float coef, fl
         BG_TRY(bg_segmax_f32(b.Xs + p * S * H2, H2, h.sg_rowptr, h.sg_col, nullptr, 0, 0, nullptr, nullptr,
                              b.Xb + p * B * H2, H2, b.ab + p * B * H2, B, H2, s));
     }
-    BG_TRY(dec_linear(2 * S, Hd, H2, b.Xs, h.s_w1, h.s_b1, b.hs, s));
-    BG_TRY(dec_linear(2 * S, 1, Hd, b.hs, h.s_w2, h.s_b2, b.vals, s));
-    BG_TRY(dec_linear(2 * B, Hd, H2, b.Xb, h.b_w1, h.b_b1, b.hb, s));
-    BG_TRY(dec_linear(2 * B, 1, Hd, b.hb, h.b_w2, h.b_b2, b.valb, s));
+    // both decoders: one launch each (no activation between their layers: val = X (w2 W1)^T + w2 . b1 + b2; the row
+    // w2 W1 is kept -- d D / d pooled of such a decoder is that constant row)
+    BG_TRY(bg_decoder_fwd_f32(2 * S, H2, Hd, b.Xs, H2, h.s_w1, H2, h.s_b1, h.s_w2, h.s_b2, b.vals, b.gp_s, s));
+    BG_TRY(bg_decoder_fwd_f32(2 * B, H2, Hd, b.Xb, H2, h.b_w1, H2, h.b_b1, h.b_w2, h.b_b2, b.valb, b.gp_b, s));
     // the sample point: which voxel carries each pooled column (losses.py:83-84 in closed form)
     BG_TRY(bg_segmax_f32(b.v[2], H2, h.st_rowptr, h.st_col, nullptr, 0, 0, nullptr, nullptr, b.hat_s, H2, b.arg_s, S, H2, s));
     BG_TRY(bg_segmax_f32(b.hat_s, H2, h.sg_rowptr, h.sg_col, nullptr, 0, 0, nullptr, nullptr, b.hat_b, H2, b.arg_sb, B, H2, s));
     BG_TRY(bg_gather_arg_f32(reinterpret_cast<const float*>(b.arg_s), H2, b.arg_sb, reinterpret_cast<float*>(b.arg_b), H2, B, H2, s));
-    // d D / d pooled of a decoder without activation is the constant row W2 W1
-    BG_TRY(mm(1, H2, Hd, h.b_w2, Hd, h.b_w1, H2, 0, b.gp_b, nullptr, nullptr, s));
-    BG_TRY(mm(1, H2, Hd, h.s_w2, Hd, h.s_w1, H2, 0, b.gp_s, nullptr, nullptr, s));
     // scattered to the arg-max voxels (row pitch 0: every segment reads the same row): building rows, then story rows
     BG_TRY(bg_scatter_arg_f32(b.gp_b, 0, b.arg_b, h.graph_of_voxel, b.G2, H2, B, N, H2, s));
     BG_TRY(bg_scatter_arg_f32(b.gp_s, 0, b.arg_s, h.story_of_voxel, b.G2 + N * H2, H2, S, N, H2, s));
@@ -534,11 +531,11 @@ extern "C" int bg_critic_head_backward_f32(const bgCriticHead* hp, float coef, c
     // ---- both decoders' backward, one launch each (bg_decoder_bwd_f32: every gradient is rank one).  Penalty share:
     // every row of d D / d pooled is the same w2 W1, so its gradient is the column sum c of the rows gathered above
     // (g W1 = w2 (x) c, g W2 = W1 c).  D(real), D(fake): building decoder, back through the story level, story decoder.
-    BG_TRY(bg_decoder_bwd_f32(2 * B, B, H2, Hd, b.dvb, b.Xb, H2, b.hb, Hd, b.dgp_b, H2, h.b_w1, H2, h.b_w2, b.gp_b, nullptr, 0,
+    BG_TRY(bg_decoder_bwd_f32(2 * B, B, H2, Hd, b.dvb, b.Xb, H2, h.b_b1, b.dgp_b, H2, h.b_w1, H2, h.b_w2, b.gp_b, nullptr, 0,
                               g_b_w1, H2, g_b_b1, g_b_w2, g_b_b2, b.dXb, H2, s));
     for (int p = 0; p < 2; ++p)
         BG_TRY(bg_scatter_arg_f32(b.dXb + p * B * H2, H2, b.ab + p * B * H2, h.graph_of_story, b.T + p * S * H2, H2, B, S, H2, s));
-    BG_TRY(bg_decoder_bwd_f32(2 * S, S, H2, Hd, b.dvs, b.Xs, H2, b.hs, Hd, b.dgp_s, H2, h.s_w1, H2, h.s_w2, b.gp_s, b.T, H2,
+    BG_TRY(bg_decoder_bwd_f32(2 * S, S, H2, Hd, b.dvs, b.Xs, H2, h.s_b1, b.dgp_s, H2, h.s_w1, H2, h.s_w2, b.gp_s, b.T, H2,
                               g_s_w1, H2, g_s_b1, g_s_w2, g_s_b2, b.dXs, H2, s));          // + what arrived through the buildings
     // to the arg-max voxels (v[0], v[1] are free after the forward's pooling: they take d v), then the coefficient table
     for (int p = 0; p < 2; ++p)
@@ -987,18 +984,18 @@ extern "C" int bg_pstack_backward_f32(const bgGeneratorWeights* w, const bgGener
 // ---------------------------------------------------------------- generator objective through the frozen discriminator
 namespace {
 struct GLossBuffers {
-    float *Zl, *v, *Xs, *Xb, *hs, *hb, *vals, *valb, *part, *loss2, *dvb, *dvs, *dhb, *dXb, *T, *dhs, *dXs, *dZl, *gl;
+    float *Zl, *v, *Xs, *Xb, *gp_s, *gp_b, *vals, *valb, *part, *loss2, *dvb, *dvs, *dXb, *T, *dXs, *dZl, *gl;
     int32_t *as, *ab;
 };
 GLossBuffers carve_gloss(Arena& ar, const bgCriticHead& h) {
-    const int64_t N = h.N, S = h.S, B = h.B, K1 = h.L + 1, dl = h.dl, H2 = h.H2, Hd = h.Hd;
+    const int64_t N = h.N, S = h.S, B = h.B, K1 = h.L + 1, dl = h.dl, H2 = h.H2;
     GLossBuffers b;
     b.Zl = ar.take(N * K1 * dl); b.v = ar.take(N * H2); b.Xs = ar.take(S * H2); b.Xb = ar.take(B * H2);
     b.as = reinterpret_cast<int32_t*>(ar.take(S * H2)); b.ab = reinterpret_cast<int32_t*>(ar.take(B * H2));
-    b.hs = ar.take(S * Hd); b.hb = ar.take(B * Hd); b.vals = ar.take(S); b.valb = ar.take(B); b.part = ar.take(128);
+    b.gp_s = ar.take(H2); b.gp_b = ar.take(H2); b.vals = ar.take(S); b.valb = ar.take(B); b.part = ar.take(128);
     b.loss2 = ar.take(4);
-    b.dvb = ar.take(B); b.dvs = ar.take(S); b.dhb = ar.take(B * Hd); b.dXb = ar.take(B * H2); b.T = ar.take(S * H2);
-    b.dhs = ar.take(S * Hd); b.dXs = ar.take(S * H2); b.dZl = ar.take(N * K1 * dl); b.gl = ar.take(N * dl);
+    b.dvb = ar.take(B); b.dvs = ar.take(S); b.dXb = ar.take(B * H2); b.T = ar.take(S * H2);
+    b.dXs = ar.take(S * H2); b.dZl = ar.take(N * K1 * dl); b.gl = ar.take(N * dl);
     return b;
 }
 }  // namespace
@@ -1042,10 +1039,8 @@ extern "C" int bg_gloss_head_forward_f32(const bgCriticHead* hp, const float* la
     }
     BG_TRY(bg_segmax_f32(b.v, H2, h.st_rowptr, h.st_col, nullptr, 0, 0, nullptr, nullptr, b.Xs, H2, b.as, S, H2, s));
     BG_TRY(bg_segmax_f32(b.Xs, H2, h.sg_rowptr, h.sg_col, nullptr, 0, 0, nullptr, nullptr, b.Xb, H2, b.ab, B, H2, s));
-    BG_TRY(dec_linear(S, Hd, H2, b.Xs, h.s_w1, h.s_b1, b.hs, s));
-    BG_TRY(dec_linear(S, 1, Hd, b.hs, h.s_w2, h.s_b2, b.vals, s));
-    BG_TRY(dec_linear(B, Hd, H2, b.Xb, h.b_w1, h.b_b1, b.hb, s));
-    BG_TRY(dec_linear(B, 1, Hd, b.hb, h.b_w2, h.b_b2, b.valb, s));
+    BG_TRY(bg_decoder_fwd_f32(S, H2, Hd, b.Xs, H2, h.s_w1, H2, h.s_b1, h.s_w2, h.s_b2, b.vals, b.gp_s, s));
+    BG_TRY(bg_decoder_fwd_f32(B, H2, Hd, b.Xb, H2, h.b_w1, H2, h.b_b1, h.b_w2, h.b_b2, b.valb, b.gp_b, s));
     BG_TRY(bg_critic_loss_f32(b.valb, h.wb, B, b.vals, h.ws, S, nullptr, 0, 0, 0, 0.f, b.part, loss, s));
     return BG_OK;
 }
@@ -1066,11 +1061,12 @@ extern "C" int bg_gloss_head_backward_f32(const bgCriticHead* hp, int64_t n_lab,
     const int64_t ldz = K1 * dl;
     const float* Wl = h.W + K1 * ds * H2;
     BG_TRY(bg_critic_loss_bwd_f32(go, h.wb, B, h.ws, S, nullptr, 0, 0, 0, 0.f, b.dvb, b.dvs, nullptr, s));
-    BG_TRY(mm(B, Hd, 1, b.dvb, 1, h.b_w2, Hd, 0, b.dhb, nullptr, nullptr, s));
-    BG_TRY(mm(B, H2, Hd, b.dhb, Hd, h.b_w1, H2, 0, b.dXb, nullptr, nullptr, s));
+    // the decoders are frozen here: only d X = dv (x) (w2 W1), one launch each
+    BG_TRY(bg_decoder_bwd_f32(B, 0, H2, Hd, b.dvb, b.Xb, H2, nullptr, nullptr, 0, nullptr, 0, nullptr, b.gp_b, nullptr, 0,
+                              nullptr, 0, nullptr, nullptr, nullptr, b.dXb, H2, s));
     BG_TRY(bg_scatter_arg_f32(b.dXb, H2, b.ab, h.graph_of_story, b.T, H2, B, S, H2, s));
-    BG_TRY(mm(S, Hd, 1, b.dvs, 1, h.s_w2, Hd, 0, b.dhs, nullptr, nullptr, s));
-    BG_TRY(mm(S, H2, Hd, b.dhs, Hd, h.s_w1, H2, 0, b.dXs, nullptr, b.T, s));
+    BG_TRY(bg_decoder_bwd_f32(S, 0, H2, Hd, b.dvs, b.Xs, H2, nullptr, nullptr, 0, nullptr, 0, nullptr, b.gp_s, b.T, H2,
+                              nullptr, 0, nullptr, nullptr, nullptr, b.dXs, H2, s));
     BG_TRY(bg_scatter_arg_f32(b.dXs, H2, b.as, h.story_of_voxel, b.v, H2, S, N, H2, s));          // v is free: it takes d v
     BG_TRY(mm(N, ldz, H2, b.v, H2, Wl, H2, 1, b.dZl, nullptr, nullptr, s));                       // d Zl = d v Wl^T
     BG_TRY(bg_spmm_chain_f32(b.dZl + h.L * dl, ldz, h.at_rowptr, h.at_col, nullptr, BG_SCALE_NONE, h.a_count, BG_SCALE_DIV,

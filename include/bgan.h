@@ -472,17 +472,25 @@ int bg_critic_loss_f32(const float* val_b, const float* wb, int64_t nb, const fl
                        const float* grads, int64_t ldg, int64_t n_rows, int64_t W, float coef,
                        float* partial, float* loss, bgStream stream);
 
-/* Backward of a two-layer decoder without activation, val = (X W1^T + b1) w2^T + b2, on a batch's few pooled rows, with
- * the gradient-penalty path's share -- every gradient is rank one:
- *   u = dv^T X, t = dv^T h, sdv = sum dv, c = column sums of dgp [Rp, H2] (Rp may be 0), gp = w2 W1 (given)
- *   g_w1 = w2 (x) (c + u)   g_b1 = sdv w2   g_w2 = t + W1 c   g_b2 = sdv   dX [R, H2] = dv (x) gp (+ add)
- * All outputs are assigned.  X [R, H2], h [R, Hd] (the hidden rows of the forward), w1 [Hd, H2], w2 [Hd].
- * replaces: autograd's backward of building_decoder / story_decoder (Model/models.py:251-264) on D(real), D(fake) and
- * the penalty's sample point: two split-K products with their reductions, four column sums and four small products.  */
+/* Forward of a two-layer decoder WITHOUT activation on a batch's few pooled rows: val [R] = (X W1^T + b1) w2^T + b2
+ * evaluated as X gp^T + (w2 . b1 + b2) with gp = w2 W1 [H2], which is written too (the backward below and the
+ * penalty's closed form read it).  X [R, H2], w1 [Hd, H2], b1 [Hd], w2 [Hd], b2 [1].
+ * replaces: building_decoder / story_decoder (Model/models.py:251-264): two Linear launches + one product as ONE.  */
+int bg_decoder_fwd_f32(int64_t R, int64_t H2, int64_t Hd, const float* X, int64_t ldx, const float* w1, int64_t ldw1,
+                       const float* b1, const float* w2, const float* b2, float* val, float* gp, bgStream stream);
+
+/* Its backward, with the gradient-penalty path's share -- every gradient is rank one:
+ *   u = dv^T X, sdv = sum dv, c = column sums of dgp [Rp, H2] (Rp may be 0), gp = w2 W1 (from the forward)
+ *   g_w1 = w2 (x) (c + u)   g_b1 = sdv w2   g_w2 = W1 (c + u) + sdv b1   g_b2 = sdv   dX [R, H2] = dv (x) gp (+ add)
+ * All outputs are assigned.  The four parameter gradients may all be NULL (a frozen decoder: dX only; w1 / w2 / b1 are
+ * then not read).
+ * replaces: autograd's backward of those decoders on D(real), D(fake) and the penalty's sample point: two split-K
+ * products with their reductions, four column sums and four small products.                                         */
 int bg_decoder_bwd_f32(int64_t R, int64_t Rp, int64_t H2, int64_t Hd, const float* dv, const float* X, int64_t ldx,
-                       const float* h, int64_t ldh, const float* dgp, int64_t ldg, const float* w1, int64_t ldw1,
+                       const float* b1, const float* dgp, int64_t ldg, const float* w1, int64_t ldw1,
                        const float* w2, const float* gp, const float* add, int64_t lda, float* g_w1, int64_t ldgw1,
                        float* g_b1, float* g_w2, float* g_b2, float* dX, int64_t ldd, bgStream stream);
+
 
 /* Its gradient for the upstream scalar go[0]: d_val_b = go*wb, d_val_s = go*ws,
  * d_grads[r,:] = go * coef * 2 (||g_r|| - 1) / ||g_r|| * g_r (0 where the norm is 0); d_grads is [n_rows, W]

@@ -274,12 +274,18 @@ int bg_copy2d_bytes(void* dst, int64_t dpitch, const void* src, int64_t spitch, 
     return 0;
 }
 int bg_decoder_bwd_f32(int64_t R, int64_t Rp, int64_t H2, int64_t Hd, const float* dv, const float* X, int64_t ldx,
-                       const float* h, int64_t ldh, const float* dgp, int64_t ldg, const float* w1, int64_t ldw1,
+                       const float* b1, const float* dgp, int64_t ldg, const float* w1, int64_t ldw1,
                        const float* w2, const float* gp, const float* add, int64_t lda, float* g_w1, int64_t ldgw1,
                        float* g_b1, float* g_w2, float* g_b2, float* dX, int64_t ldd, bgStream) {
-    int64_t a[] = {R, Rp, H2, Hd, P(dv), P(X), ldx, P(h), ldh, P(dgp), ldg, P(w1), ldw1, P(w2), P(gp), P(add), lda,
+    int64_t a[] = {R, Rp, H2, Hd, P(dv), P(X), ldx, P(b1), P(dgp), ldg, P(w1), ldw1, P(w2), P(gp), P(add), lda,
                    P(g_w1), ldgw1, P(g_b1), P(g_w2), P(g_b2), P(dX), ldd};
     rec(37, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_decoder_fwd_f32(int64_t R, int64_t H2, int64_t Hd, const float* X, int64_t ldx, const float* w1, int64_t ldw1,
+                       const float* b1, const float* w2, const float* b2, float* val, float* gp, bgStream) {
+    int64_t a[] = {R, H2, Hd, P(X), ldx, P(w1), ldw1, P(b1), P(w2), P(b2), P(val), P(gp)};
+    rec(38, a, sizeof(a) / 8);
     return 0;
 }
 // one launch of several fills / copies: a marker (kind 27: the job count) followed by each job as the single call it

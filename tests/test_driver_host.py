@@ -503,17 +503,32 @@ def _check_critic_calls(calls, R, h):
             R.check(dst, (height - 1) * dp + width, tag + " dst")
             R.check(src, (height - 1) * sp + width, tag + " src")
         elif kind == 37:
-            (Rr, Rp, H2, Hd, dv, X, ldx, hh, ldh, dgp, ldg, w1, ldw1, w2, gp, add, lda, g_w1, ldgw1, g_b1, g_w2, g_b2, dX, ldd) = a
-            assert (Rr, Rp) in ((2 * B, B), (2 * S, S)) and H2 == h.H2 and Hd == h.Hd
+            (Rr, Rp, H2, Hd, dv, X, ldx, b1, dgp, ldg, w1, ldw1, w2, gp, add, lda, g_w1, ldgw1, g_b1, g_w2, g_b2, dX, ldd) = a
+            assert H2 == h.H2 and Hd == h.Hd
             R.check(dv, Rr * f, tag + " dv"); R.check(X, ((Rr - 1) * ldx + H2) * f, tag + " X")
-            R.check(hh, ((Rr - 1) * ldh + Hd) * f, tag + " h"); R.check(dgp, ((Rp - 1) * ldg + H2) * f, tag + " dgp")
-            R.check(w1, ((Hd - 1) * ldw1 + H2) * f, tag + " w1"); R.check(w2, Hd * f, tag + " w2"); R.check(gp, H2 * f, tag + " gp")
+            assert R.check(gp, H2 * f, tag + " gp") == "workspace"
             if add:
                 R.check(add, ((Rr - 1) * lda + H2) * f, tag + " add")
-            which = "b" if Rr == 2 * B and Rp == B and not add else "s"
-            assert R.check(g_w1, ((Hd - 1) * ldgw1 + H2) * f, tag) == "g_%s_w1" % which and R.check(g_b1, Hd * f, tag) == "g_%s_b1" % which
-            assert R.check(g_w2, Hd * f, tag) == "g_%s_w2" % which and R.check(g_b2, f, tag) == "g_%s_b2" % which
             assert R.check(dX, ((Rr - 1) * ldd + H2) * f, tag + " dX") == "workspace" and dX != X and dX != add
+            if g_w1:                                      # the critic's own decoders: all four gradients, penalty share
+                assert (Rr, Rp) in ((2 * B, B), (2 * S, S))
+                R.check(dgp, ((Rp - 1) * ldg + H2) * f, tag + " dgp")
+                which = "b" if not add else "s"
+                assert R.check(w1, ((Hd - 1) * ldw1 + H2) * f, tag + " w1") == which + "_w1"
+                assert R.check(w2, Hd * f, tag + " w2") == which + "_w2" and R.check(b1, Hd * f, tag + " b1") == which + "_b1"
+                assert R.check(g_w1, ((Hd - 1) * ldgw1 + H2) * f, tag) == "g_%s_w1" % which and R.check(g_b1, Hd * f, tag) == "g_%s_b1" % which
+                assert R.check(g_w2, Hd * f, tag) == "g_%s_w2" % which and R.check(g_b2, f, tag) == "g_%s_b2" % which
+            else:                                         # frozen decoders (generator objective): d X only
+                assert (Rr, Rp) in ((B, 0), (S, 0)) and not (g_b1 or g_w2 or g_b2 or w1 or w2 or b1 or dgp)
+        elif kind == 38:
+            Rr, H2, Hd, X, ldx, w1, ldw1, b1, w2, b2, val, gp = a
+            assert H2 == h.H2 and Hd == h.Hd and Rr in (B, S, 2 * B, 2 * S)
+            which = R.check(w1, ((Hd - 1) * ldw1 + H2) * f, tag + " w1")[0]
+            assert which in "bs" and Rr in ((B, 2 * B) if which == "b" else (S, 2 * S))
+            for q, nm, n in ((b1, "_b1", Hd), (w2, "_w2", Hd), (b2, "_b2", 1)):
+                assert R.check(q, n * f, tag + nm) == which + nm
+            R.check(X, ((Rr - 1) * ldx + H2) * f, tag + " X")
+            assert R.check(val, Rr * f, tag + " val") == "workspace" and R.check(gp, H2 * f, tag + " gp") == "workspace"
         else:
             raise AssertionError("unexpected launcher %d" % kind)
 
@@ -522,7 +537,8 @@ def _check_critic_calls(calls, R, h):
 def test_critic_head_host_sequence_and_extents(drv, N, S, B, basis):
     (rc_f, rc_b), fwd, bwd, R, h = _critic_run(drv, N, S, B, basis=basis)
     assert rc_f == 0 and rc_b == 0
-    assert [k for k, _ in fwd] == [10, 1, 28, 1, 11, 11, 11, 11, 1, 1, 1, 1, 11, 11, 12, 1, 1, 13, 13, 1, 10, 14, 15]
+    # 38: a decoder's forward as one launch (it also leaves w2 W1, which the scatters below read)
+    assert [k for k, _ in fwd] == [10, 1, 28, 1, 11, 11, 11, 11, 38, 38, 11, 11, 12, 13, 13, 1, 10, 14, 15]
     # 37: a decoder's whole backward (penalty share included) as one launch
     assert [k for k, _ in bwd] == [16, 20, 14, 10, 1, 12, 12, 37, 13, 13, 37, 13, 13, 19, 18, 19]
     _check_critic_calls(fwd, R, h)
@@ -902,10 +918,10 @@ def test_gloss_head_host_sequence_and_extents(drv, N, S, B):
         return rc, [(drv.stub_call(i)[0], [drv.stub_call(i)[2 + k] for k in range(drv.stub_call(i)[1])])
                     for i in range(drv.stub_count())]
     rc, fwd = calls_of(drv.bg_gloss_head_forward_f32, C.byref(h), label, 6, 6, work, nws, loss, None)
-    assert rc == 0 and [k for k, _ in fwd] == [20, 14, 1, 11, 11, 1, 1, 1, 1, 15]
+    assert rc == 0 and [k for k, _ in fwd] == [20, 14, 1, 11, 11, 38, 38, 15]
     R.r.pop("go")
     rc, bwd = calls_of(drv.bg_gloss_head_backward_f32, C.byref(h), 6, R.new("go", f), work, nws, R.new("g_label", N * 6 * f), None)
-    assert rc == 0 and [k for k, _ in bwd] == [16, 1, 1, 13, 1, 1, 13, 1, 14, 20]
+    assert rc == 0 and [k for k, _ in bwd] == [16, 37, 13, 37, 13, 1, 14, 20]
     # the generic checker of the critic head covers every launcher used here, except: two-segment product, no penalty
     for kind, a in fwd + bwd:
         if kind == 1 and a[4] == 2:

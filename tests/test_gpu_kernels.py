@@ -1203,8 +1203,9 @@ def test_fills_and_copies_as_one_launch(cuda):
 
 @pytest.mark.parametrize("R,Rp,H2,Hd,with_add", [(16, 8, 256, 128, False), (176, 88, 256, 128, True), (5, 0, 40, 9, True)])
 def test_decoder_backward_in_one_launch(cuda, R, Rp, H2, Hd, with_add):
-    """bg_decoder_bwd_f32 (a two-layer decoder's backward on a batch's pooled rows + the penalty path's share, every
-    gradient a rank-one expression) against autograd in float64 on the same function."""
+    """bg_decoder_fwd_f32 / bg_decoder_bwd_f32 (a two-layer decoder without activation on a batch's pooled rows: the
+    forward as one dot product per row with w2 W1, the backward + the penalty path's share as rank-one expressions)
+    against the two Linears and autograd in float64."""
     from building_gan_amd import _lib
     lib = _lib.load()
     gen = torch.Generator().manual_seed(R + Hd)
@@ -1225,7 +1226,20 @@ def test_decoder_backward_in_one_launch(cuda, R, Rp, H2, Hd, with_add):
     out = {n: torch.full(s, float("nan"), device=cuda) for n, s in
            (("g_w1", (Hd, H2)), ("g_b1", (Hd,)), ("g_w2", (Hd,)), ("g_b2", (1,)), ("dX", (R, H2)))}
     Xc, hc, dvc, w1c, w2c, dgc, addc = f(X), f(h), f(dv), f(w1), f(w2.view(-1)), f(dgp) if Rp else None, f(add) if with_add else None
-    rc = lib.bg_decoder_bwd_f32(R, Rp, H2, Hd, dvc.data_ptr(), Xc.data_ptr(), H2, hc.data_ptr(), Hd,
+    b1c, b2c = f(b1), f(b2)
+    val, gp2 = torch.full((R,), float("nan"), device=cuda), torch.full((H2,), float("nan"), device=cuda)
+    st_ = torch.cuda.current_stream().cuda_stream
+    assert lib.bg_decoder_fwd_f32(R, H2, Hd, Xc.data_ptr(), H2, w1c.data_ptr(), H2, b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(),
+                                  val.data_ptr(), gp2.data_ptr(), st_) == 0
+    vref = ((X @ w1.detach().t() + b1.detach()) @ w2.detach().t() + b2.detach()).view(-1)
+    scale = float((X.abs() @ w1.detach().abs().t() @ w2.detach().abs().t()).max())
+    assert float((val.cpu().double() - vref).abs().max()) < 2e-6 * scale
+    assert float((gp2.cpu().double() - (w2.detach() @ w1.detach()).view(-1)).abs().max()) < 1e-5
+    only_dx = torch.full((R, H2), float("nan"), device=cuda)               # frozen decoder: dX alone, no parameters read
+    assert lib.bg_decoder_bwd_f32(R, 0, H2, Hd, dvc.data_ptr(), Xc.data_ptr(), H2, None, None, 0, None, 0, None, gp.data_ptr(),
+                                  None, 0, None, 0, None, None, None, only_dx.data_ptr(), H2, st_) == 0
+    assert float((only_dx.cpu().double() - Xr.grad).abs().max()) < 1e-5 * float(Xr.grad.abs().max())
+    rc = lib.bg_decoder_bwd_f32(R, Rp, H2, Hd, dvc.data_ptr(), Xc.data_ptr(), H2, b1c.data_ptr(),
                                 dgc.data_ptr() if Rp else None, H2, w1c.data_ptr(), H2, w2c.data_ptr(), gp.data_ptr(),
                                 addc.data_ptr() if with_add else None, H2, out["g_w1"].data_ptr(), H2, out["g_b1"].data_ptr(),
                                 out["g_w2"].data_ptr(), out["g_b2"].data_ptr(), out["dX"].data_ptr(), H2,
@@ -1236,5 +1250,5 @@ def test_decoder_backward_in_one_launch(cuda, R, Rp, H2, Hd, with_add):
     for n, r in ref.items():
         err = float((out[n].cpu().double() - r).abs().max()) / max(float(r.abs().max()), 1e-30)
         assert err < 1e-5, (n, err)              # fp32 sums of signed terms (sum dv cancels to a few percent of sum |dv|)
-    assert lib.bg_decoder_bwd_f32(0, 0, H2, Hd, *([None] * 2), 0, None, 0, None, 0, None, 0, None, None, None, 0, None, 0,
+    assert lib.bg_decoder_bwd_f32(0, 0, H2, Hd, *([None] * 2), 0, None, None, 0, None, 0, None, None, None, 0, None, 0,
                                   None, None, None, None, 0, None) == -1
