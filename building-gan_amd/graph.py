@@ -79,9 +79,12 @@ class VolumeDesignGraph:
         return -1 if key in _LAST_DIM else 0
 
     def to(self, device, non_blocking: bool = False):
-        """As ``batch.to(device)`` of reference train.py:75.  With ``non_blocking=True`` (copies from pinned memory
-        that the host does not wait for) an event is recorded behind the last copy (``_bg_h2d_event``): streams other
-        than the current one -- the plan's prefetch stream -- order themselves behind it before they read the batch."""
+        """As ``batch.to(device)`` of reference train.py:75.  An event is recorded behind the last copy
+        (``_bg_h2d_event``; with ``non_blocking=True`` -- copies from pinned memory -- the host has not waited for
+        them): streams other than the current one -- the plan's prefetch stream -- order themselves behind THAT event
+        instead of behind everything queued on the current stream, so the next batch's plan runs beside the iteration
+        in flight rather than after it.  Code that rewrites a batch's tensors with device ops afterwards must drop the
+        attribute (or move the batch again)."""
         for k in self.keys:
             v = getattr(self, k)
             if torch.is_tensor(v):
@@ -90,7 +93,7 @@ class VolumeDesignGraph:
         self.__dict__.pop("_bg_plan_pending", None)
         self.__dict__.pop("_bg_h2d_event", None)
         dev = torch.device(device) if not isinstance(device, torch.device) else device
-        if non_blocking and dev.type == "cuda":
+        if dev.type == "cuda":
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             self.__dict__["_bg_h2d_event"] = ev

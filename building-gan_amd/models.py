@@ -538,6 +538,28 @@ class VoxelGNN_D(nn.Module):
                                   le.bias, self.pe, L, ds, dl)
         return SpMM.apply(XL, self._coef_row_order(L, ds, dl, XL.device))
 
+    def _table_manual(self, n_feat, ds, dl):
+        """_table_from_parameters without an autograd graph: (W, finish) where finish(gW) returns the gradients of
+        (messageMLP weight, bias, updateMLP weight, bias, feature_enc weight, bias, label_enc weight, bias) -- the same
+        two nodes' forward and backward called directly (DiscriminatorVoxel.critic_objective(manual=True))."""
+        blk, fe, le = self.block, self.feature_enc[0], self.label_enc[0]
+        Wm, Wu = blk.messageMLP[0].weight, blk.updateMLP[0].weight
+        H2, L = Wm.shape[0], self.layer_num
+        H = H2 // 2
+        if not (FUSE_COMPOSE_D and FUSE_COEF_INPUTS and ops.FUSE_COEF_RECURRENCE and Wm.is_cuda and L >= 1
+                and not blk.if_agg_story_in_update and Wm.shape[1] == 2 * H2 + 3 and tuple(Wu.shape) == (H2, 2 * H2)
+                and fe.weight.shape == (H, n_feat) and le.weight.shape[0] == H and H2 % 4 == 0):
+            return None
+        params = (Wm, blk.messageMLP[0].bias, Wu, blk.updateMLP[0].bias, fe.weight, fe.bias, le.weight, le.bias)
+        ctx = ops.ManualCtx(13)
+        XL = ops.PolyCoefDW.forward(ctx, *[t.detach() for t in params], self.pe.detach(), L, ds, dl)
+        order = self._coef_row_order(L, ds, dl, XL.device)
+        W = ops.spmm_raw(order, XL)
+
+        def finish(gW):
+            return params, ops.PolyCoefDW.backward(ctx, ops.spmm_raw(order.T, gW))[:8]
+        return W, finish
+
     def _coef_row_order(self, L, ds, dl, device) -> LinOp:
         key = (L, ds, dl, str(device))
         cache = self.__dict__.setdefault("_row_order", {})
@@ -881,7 +903,7 @@ class DiscriminatorVoxel(nn.Module):
         grad_b, _, grad_s, _ = acc.split([n_lab, dl - n_lab, n_lab, dl - n_lab], dim=1)
         return (*out, grad_b, grad_s)
 
-    def critic_objective(self, graph, label_real, label_fake, label_hat, wb, ws, coef: float):
+    def critic_objective(self, graph, label_real, label_fake, label_hat, wb, ws, coef: float, manual: bool = False):
         """(objective, bare penalty sum) of one WGAN-GP critic update -- <D(real), D(fake), wb / ws> + coef * sum over
         voxels and both outputs of (||d D(hat) / d label|| - 1)^2 -- with everything below the coefficient table issued
         by ONE host call each way (ops.CriticHead) instead of critic_terms' ~90 launches from the interpreter.  Same
@@ -899,12 +921,43 @@ class DiscriminatorVoxel(nn.Module):
             return None
         pos, feat = extract_pos(graph.voxel_feature)
         pdm4 = _pos_terms(plan, pos)
+        bd, sd = self.building_dec, self.story_dec
+        dec = (bd[0].weight, bd[0].bias, bd[1].weight, bd[1].bias, sd[0].weight, sd[0].bias, sd[1].weight, sd[1].bias)
+        if manual:
+            # ``manual``: the update's three nodes (coefficient table, row order, head) called forward and backward
+            # right here, their gradients assigned to ``.grad`` -- no autograd graph, no engine pass (its thread hop,
+            # one AccumulateGrad per parameter): ~0.1 ms of host time per critic update, same kernels in the same order
+            with torch.no_grad():
+                L, n_lab = gnn.layer_num, label_real.shape[1]
+                dl = (n_lab + 3) // 4 * 4
+                Zk = torch.empty(feat.shape[0], L + 1, 3 * dl, device=feat.device)
+                ops.pack_columns_raw([label_real.detach(), label_fake.detach(), label_hat.detach()], dl, Zk.view(feat.shape[0], -1))
+                rider = [Zk, 3 * dl, False]
+                Zs = gnn._static_powers(plan, feat, pdm4, rider)
+                ds = Zs.shape[1] // (L + 1)
+                made = gnn._table_manual(feat.shape[1], ds, dl)
+                if made is None:
+                    return None
+                W, finish = made
+                if not rider[2]:
+                    ops.power_chain_raw(plan.vox_mean, Zk, L, 3 * dl, plan.vox_blocks)
+                if not ops._chain_fits(plan.vox_mean.T, blocks, 2 * dl) or W.shape[1] % 4 != 0:
+                    return None
+                ctx = ops.ManualCtx(18)
+                total, pen = ops.CriticHead.forward(ctx, W.contiguous(), *[t.detach() for t in dec], Zs, Zk, plan, wb, ws,
+                                                    coef, L, ds, dl)
+                grads = ops.CriticHead.backward(ctx, ops.ones_view(1, device=W.device), None)
+                for prm, g in zip(dec, grads[1:9]):
+                    prm.grad = g
+                for prm, g in zip(*finish(grads[0])):
+                    prm.grad = g
+                if gnn._share_coef:       # the generator objective of this iteration re-uses the table (it is taken
+                    gnn._coef_cache = ((ds, dl, False, ops.D_BASIS), W)       # without a graph there)
+            return total, pen
         Zs, Zk, W, ds, dl = gnn._label_powers(feat, [label_real, label_fake, label_hat], plan, pdm4)
         if not ops._chain_fits(plan.vox_mean.T, blocks, 2 * dl) or W.shape[1] % 4 != 0:
             return None
-        bd, sd = self.building_dec, self.story_dec
-        return ops.CriticHead.apply(W.contiguous(), bd[0].weight, bd[0].bias, bd[1].weight, bd[1].bias, sd[0].weight,
-                                    sd[0].bias, sd[1].weight, sd[1].bias, Zs, Zk, plan, wb, ws, coef, gnn.layer_num, ds, dl)
+        return ops.CriticHead.apply(W.contiguous(), *dec, Zs, Zk, plan, wb, ws, coef, gnn.layer_num, ds, dl)
 
     def generator_objective(self, graph, label, wb, ws):
         """<D_building(label), wb> + <D_story(label), ws> for the generator update (the discriminator frozen: only

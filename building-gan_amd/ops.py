@@ -83,6 +83,18 @@ def zeros_view(*shape, device) -> torch.Tensor:
     return buf[:n].view(*shape)
 
 
+_ONES = {}
+
+
+def ones_view(n: int, device) -> torch.Tensor:
+    """A read-only all-one fp32 vector (cached per device, as zeros_view)."""
+    buf = _ONES.get(device)
+    if buf is None or buf.numel() < n:
+        buf = torch.ones(max(n, 16), dtype=torch.float32, device=device)
+        _ONES[device] = buf
+    return buf[:n]
+
+
 def _vec_ok(*ts) -> bool:
     """16-byte path: width % 4 == 0, aligned base, pitch % 4 == 0."""
     return all(t.shape[-1] % 4 == 0 and t.data_ptr() % 16 == 0 and _ld(t) % 4 == 0 for t in ts)
@@ -494,6 +506,24 @@ def colsum_raw(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: 
 
 
 # ------------------------------------------------------------------------------- autograd family
+class ManualCtx:
+    """What an autograd Function's forward / backward use of their ``ctx``, for calling them directly (no graph, no
+    engine pass): models.DiscriminatorVoxel.critic_objective(manual=True)."""
+
+    def __init__(self, n_inputs: int):
+        self.needs_input_grad = (True,) * n_inputs
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
 class SpMM(torch.autograd.Function):
     """y = op(x) for a fixed sparse LinOp; backward is the transposed LinOp."""
 

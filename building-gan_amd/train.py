@@ -241,6 +241,7 @@ class Trainer:
         # (polynomial) evaluation under the current parameters and falls back to the layer-by-layer stack when it
         # would lose more than the fp32 tolerance (models.DiscriminatorVoxel.guard_collapse; one host read)
         self.collapse_check_every = collapse_check_every
+        self.manual_critic = True            # the fused critic update without an autograd pass (critic_objective(manual=True))
         self.group = group
         self._graphs = None
         self._captured_batch = None
@@ -392,6 +393,7 @@ class Trainer:
                 gp = None
                 fused = None
                 head = None
+                manual_done = False
                 if fused_ok:
                     sample = None
                     if self.gp_lambda != 0:      # labels are data in the fused pass: the sample point in one launch
@@ -401,7 +403,13 @@ class Trainer:
                     if sample is not None and self.gan_loss == "WGANGP" and hasattr(D, "critic_objective") and plan_now is not None:
                         # the whole update below the coefficient table as one host call each way
                         wb, ws = self._critic_weights(plan_now.B, plan_now.S, Bg, Sg, dev)
-                        head = D.critic_objective(batch, batch.voxel_label, out.detach(), sample, wb, ws, self.gp_lambda / Nvg)
+                        head = None
+                        if self.manual_critic:       # forward and backward right here, gradients assigned: no autograd pass
+                            head = D.critic_objective(batch, batch.voxel_label, out.detach(), sample, wb, ws,
+                                                      self.gp_lambda / Nvg, manual=True)
+                            manual_done = head is not None
+                        if head is None:
+                            head = D.critic_objective(batch, batch.voxel_label, out.detach(), sample, wb, ws, self.gp_lambda / Nvg)
                     if head is None:
                         fused = D.critic_terms(batch, batch.voxel_label, out.detach(), sample, stacked=True)
                 if head is not None:
@@ -434,7 +442,8 @@ class Trainer:
             if gp is not None:
                 d_loss = d_loss + self.gp_lambda * gp
                 stats["gp"] = gp.detach()
-            d_loss.backward()
+            if not manual_done:
+                d_loss.backward()
             self.opt_d.collect()
             stats["d_loss"] = d_loss.detach()
         return gen, stats

@@ -196,11 +196,19 @@ def test_prefetched_plan_waits_for_a_non_blocking_copy_from_pinned_memory(cuda):
         assert P.prefetch_plan(b) is None and "_bg_plan_pending" in b.__dict__
         got = P.build_plan(b)
         _same({k: v for k, v in got.ops.items() if k != "_arenas"}, want, "plan[%d]" % rep, set())
-    # a blocking move leaves no event and the side stream waits for the whole current stream instead
+    # a blocking move leaves the event too (the plan then runs beside whatever the current stream still holds) ..
     b = copy.deepcopy(cpu).to(cuda)
-    assert "_bg_h2d_event" not in b.__dict__
+    assert "_bg_h2d_event" in b.__dict__
+    for _ in range(8):
+        ops.spmm_raw(direct.vox_mean, x)
     assert P.prefetch_plan(b) is None
     _same({k: v for k, v in P.build_plan(b).ops.items() if k != "_arenas"}, want, "plan[blocking]", set())
+    # .. and a batch without one (assembled by device ops on the current stream) makes the side stream wait for that stream
+    b = copy.deepcopy(cpu).to(cuda)
+    b.__dict__.pop("_bg_h2d_event")
+    b.voxel_edge = b.voxel_edge.clone()
+    assert P.prefetch_plan(b) is None
+    _same({k: v for k, v in P.build_plan(b).ops.items() if k != "_arenas"}, want, "plan[device ops]", set())
     torch.cuda.synchronize()
 
 

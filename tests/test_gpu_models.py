@@ -654,6 +654,35 @@ def test_trainer_iteration_with_and_without_the_one_call_critic_head(cuda, monke
     assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
 
 
+@pytest.mark.parametrize("preset,ragged,seed", [("small", "jitter", 61), ("dataset", "jitter", 62)])
+def test_critic_update_without_an_autograd_pass_equals_the_autograd_path(cuda, preset, ragged, seed):
+    """Trainer.manual_critic (the fused critic update's three nodes called forward and backward directly, gradients
+    assigned to .grad) against the same nodes under autograd, over three iterations incl. one with the generator
+    update: the same launches in the same order, so losses, flat gradient buffers and parameters are bitwise equal."""
+    from building_gan_amd.train import Trainer
+    cpu, gpu, sz, Go, Do, Gh, Dh, noise, pz, vz = _setup(preset, seed, ragged, cuda)
+    u = torch.rand(sz["Nv"], generator=torch.Generator().manual_seed(seed)).to(cuda)
+    res = []
+    for manual in (True, False):
+        torch.manual_seed(seed)
+        tr = Trainer(cuda)
+        tr.manual_critic = manual
+        tr.generator.load_state_dict(Go.state_dict())
+        tr.discriminator.load_state_dict(Do.state_dict())
+        tr.refresh_derived()
+        gpu.__dict__.pop("_bg_plan", None)
+        out = []
+        for i in (1, 2, 5):
+            st = tr.train_iteration(gpu, i, pz.to(cuda), vz.to(cuda), _to(noise, cuda), u)
+            out.append((st["d_loss"].cpu(), st["gp"].cpu(), tr.opt_d.grad.detach().cpu().clone()))
+        res.append((out, tr.opt_d.flat.detach().cpu().clone(), tr.opt_g.flat.detach().cpu().clone()))
+    (o1, d1, g1), (o0, d0, g0) = res
+    for (l1, p1, q1), (l0, p0, q0) in zip(o1, o0):
+        assert torch.equal(l1, l0) and torch.equal(p1, p0) and torch.equal(q1, q0)
+    assert torch.equal(d1, d0) and torch.equal(g1, g0)
+    assert bool(torch.isfinite(d1).all())
+
+
 @pytest.mark.parametrize("preset,ragged,seed", [("small", True, 51), ("small", "jitter", 53), ("dataset", "jitter", 52)])
 def test_generator_stack_in_one_host_call_equals_node_by_node_path(cuda, preset, ragged, seed, monkeypatch):
     """ops.VoxelStackG (bg_gstack_forward_f32 / _backward_f32: the generator's voxel GNN as one autograd node, one host
