@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_cross_logits(const float* __restrict__ 
             const float* bp = B + (int64_t)col[k] * ldb;
             float acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) acc = fmaf(th[j], tanhf(av[j] + bp[lane + 64 * j]), acc);
+            for (int j = 0; j < CPL; ++j) acc = fmaf(th[j], bg_tanh(av[j] + bp[lane + 64 * j]), acc);
             acc = bg_wave_sum(acc);
             if (lane == 0) att[k] = acc;
         }
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_cross_logits_bwd(const float* __restric
             const float gk = g[k];
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
-                float t = tanhf(av[j] + bp[lane + 64 * j]);
+                float t = bg_tanh(av[j] + bp[lane + 64 * j]);
                 float d = gk * th[j] * (1.f - t * t);
                 dpre[(int64_t)k * H + lane + 64 * j] = d;
                 da[j] += d;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const float* __restrict__
                 if (k0 + i < deg) {                                  // wave-uniform
                     float acc = 0.f;
 #pragma unroll
-                    for (int j = 0; j < CPL; ++j) acc = fmaf(th[j], tanhf(av[j] + bv[i][j]), acc);
+                    for (int j = 0; j < CPL; ++j) acc = fmaf(th[j], bg_tanh(av[j] + bv[i][j]), acc);
                     acc = bg_wave_sum(acc);
                     if (lane == k0 + i) y = (acc + (-logf(my_exp))) / tau;
                 }

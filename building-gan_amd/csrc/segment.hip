@@ -277,18 +277,20 @@ __device__ __forceinline__ int64_t row_of_chunk(const int32_t* chunk_ptr, int64_
 // One workgroup per chunk.  LPR lanes own one slot's row (a float4 each); the workgroup keeps
 // 256/LPR slots in flight, each lane group walking its slots with stride 256/LPR; the groups'
 // partial results are then combined through LDS in group order (deterministic; for max the
-// smallest slot wins ties, which is the first-index rule).
-template <bool IS_MAX>
-__global__ __launch_bounds__(256) void k_chunk_reduce(ChunkArgs a, int lpr, int hoff) {
-    __shared__ float4 sval[256];
-    __shared__ int4 sarg[IS_MAX ? 256 : 1];
+// smallest slot wins ties, which is the first-index rule).  T = 1024 is the max of a few long rows (the critic's
+// pooling: 80 stories of ~150 voxels): four times the slots in flight per row, and the groups combine as a tree,
+// which the tie rule makes order-free.
+template <bool IS_MAX, int T = 256>
+__global__ __launch_bounds__(T) void k_chunk_reduce(ChunkArgs a, int lpr, int hoff) {
+    __shared__ float4 sval[T];
+    __shared__ int4 sarg[IS_MAX ? T : 1];
     const int32_t c = blockIdx.x;
     const bool direct = a.chunk_ptr == nullptr;
     if (!direct && c >= a.chunk_ptr[a.n_rows]) return;
     const int64_t row = direct ? (int64_t)c : row_of_chunk(a.chunk_ptr, a.n_rows, c);
     const int32_t k0 = direct ? a.rowptr[row] : a.rowptr[row] + (c - a.chunk_ptr[row]) * a.R;
     const int32_t k1 = direct ? a.rowptr[row + 1] : min(k0 + a.R, a.rowptr[row + 1]);
-    const int spb = 256 / lpr;
+    const int spb = T / lpr;
     const int sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
     const int H4 = (a.H - hoff) / 4 < 64 ? (a.H - hoff) / 4 : 64;
     const bool live = sub < H4;
@@ -334,13 +336,24 @@ __global__ __launch_bounds__(256) void k_chunk_reduce(ChunkArgs a, int lpr, int 
     sval[threadIdx.x] = acc;
     if (IS_MAX) sarg[threadIdx.x] = ak;
     __syncthreads();
+#define BG_CMB(f)                                                                           \
+    if (v.f > acc.f || (v.f == acc.f && kk.f < ak.f)) { acc.f = v.f; ak.f = kk.f; }
+    if (IS_MAX && T > 256) {
+        for (int half = spb >> 1; half >= 1; half >>= 1) {
+            if (grp < half) {
+                float4 v = sval[(grp + half) * lpr + sub];
+                int4 kk = sarg[(grp + half) * lpr + sub];
+                BG_CMB(x) BG_CMB(y) BG_CMB(z) BG_CMB(w)
+                if (half > 1) { sval[threadIdx.x] = acc; sarg[threadIdx.x] = ak; }
+            }
+            if (half > 1) __syncthreads();
+        }
+    }
     if (grp == 0 && live) {
-        for (int g = 1; g < spb; ++g) {
+        for (int g = 1; g < spb && !(IS_MAX && T > 256); ++g) {
             float4 v = sval[g * lpr + sub];
             if (IS_MAX) {
                 int4 kk = sarg[g * lpr + sub];
-#define BG_CMB(f)                                                                           \
-    if (v.f > acc.f || (v.f == acc.f && kk.f < ak.f)) { acc.f = v.f; ak.f = kk.f; }
                 BG_CMB(x) BG_CMB(y) BG_CMB(z) BG_CMB(w)
             } else {
                 acc = bg_add4(acc, v);
@@ -412,7 +425,10 @@ int launch_chunk_reduce(const ChunkArgs& a, int64_t n_chunks_ub, hipStream_t s) 
         int h4 = (a.H - hoff) / 4 < 64 ? (a.H - hoff) / 4 : 64;
         int lpr = 1;
         while (lpr < h4) lpr <<= 1;
-        k_chunk_reduce<IS_MAX><<<(int)n_chunks_ub, 256, 0, s>>>(a, lpr, hoff);
+        if (IS_MAX && !a.chunk_ptr && n_chunks_ub <= 256)      // a few rows: the chip is mostly idle, so widen each row
+            k_chunk_reduce<IS_MAX, 1024><<<(int)n_chunks_ub, 1024, 0, s>>>(a, lpr, hoff);
+        else
+            k_chunk_reduce<IS_MAX><<<(int)n_chunks_ub, 256, 0, s>>>(a, lpr, hoff);
         BG_LAUNCH_CHECK();
     }
     return BG_OK;
@@ -465,6 +481,24 @@ __global__ void k_scatter_arg_dense(const float* __restrict__ g, int64_t ldg, co
     float v = 0.f;
     if (s >= 0 && arg[(int64_t)s * H + h] == (int32_t)r) v = g[(int64_t)s * ldg + h];
     out[r * ldo + h] = v;
+}
+
+// the same, four channels per thread (H % 4 == 0, 16-byte aligned rows, fewer than 2^31 elements)
+__global__ __launch_bounds__(256) void k_scatter_arg_dense4(const float* __restrict__ g, int64_t ldg,
+                                                            const int32_t* __restrict__ arg, const int32_t* __restrict__ seg_of,
+                                                            float* __restrict__ out, int64_t ldo, uint32_t n4, uint32_t H4) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n4) return;
+    const uint32_t r = t / H4, h = 4u * (t - r * H4);
+    const int32_t s = seg_of[r];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s >= 0) {
+        const int4 ar = *reinterpret_cast<const int4*>(arg + (int64_t)s * (4 * H4) + h);
+        const float4 gv = bg_ld4(g + (int64_t)s * ldg + h);
+        v.x = ar.x == (int32_t)r ? gv.x : 0.f; v.y = ar.y == (int32_t)r ? gv.y : 0.f;
+        v.z = ar.z == (int32_t)r ? gv.z : 0.f; v.w = ar.w == (int32_t)r ? gv.w : 0.f;
+    }
+    bg_st4(out + (int64_t)r * ldo + h, v);
 }
 
 // one wave per row; 64/LPR slots in flight, LPR lanes per dot product (float4 per lane per step)
@@ -1190,6 +1224,13 @@ int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, const in
     if (!out || ldo < H || (n_seg > 0 && (!g || !arg))) return BG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (seg_of && n_seg > 0) {          // one launch: every row looks its own value up
+        if (H % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && bg_aligned16(g) && bg_aligned16(arg) && bg_aligned16(out) &&
+            n_rows * (H / 4) < 0x7fffffff) {
+            const uint32_t n4 = (uint32_t)(n_rows * (H / 4));
+            k_scatter_arg_dense4<<<(n4 + 255u) / 256u, 256, 0, s>>>(g, ldg, arg, seg_of, out, ldo, n4, (uint32_t)(H / 4));
+            BG_LAUNCH_CHECK();
+            return BG_OK;
+        }
         k_scatter_arg_dense<<<bg_grid_for(n_rows * H, 256, 0x7fffffff), 256, 0, s>>>(g, ldg, arg, seg_of, out, ldo, n_rows, (int)H);
         BG_LAUNCH_CHECK();
         return BG_OK;

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .ops import ACT_LEAKY, ACT_NONE, SpMM, SpMMW, linear
-from .plan import LinOp, build_plan
+from .plan import LinOp, build_plan, iota_i32
 
 NUMBER_OF_CLASS = 6  # /root/reference/Data/GraphConstructor.py:9
 COMPOSE_BLOCKS = True  # collapse messageMLP into updateMLP where legal (VoxelBlock.compose)
@@ -136,8 +136,7 @@ def _level_op(plan, max_len: int) -> LinOp:
         if plan.ops["max_level"] >= max_len:
             raise IndexError(f"a building has {plan.ops['max_level'] + 1} stories but the position table has "
                              f"{max_len} rows (reference models.py:13,192)")
-        rowptr = torch.arange(n + 1, dtype=torch.int32, device=plan.device)
-        op = LinOp(Csr(rowptr, plan.level, None, n, max_len, n))
+        op = LinOp(Csr(iota_i32(n + 1, plan.device), plan.level, None, n, max_len, n))
         plan.ops[key] = op
     return op
 
@@ -571,7 +570,7 @@ class VoxelGNN_D(nn.Module):
             src = torch.cat([(k + torch.arange(ds)).reshape(-1), (k + ds + torch.arange(dl)).reshape(-1)])
             inv = torch.empty(n, dtype=torch.int64)
             inv[src] = torch.arange(n)
-            rowptr = torch.arange(n + 1, dtype=torch.int32, device=device)
+            rowptr = iota_i32(n + 1, device)
             op = LinOp.pair(Csr(rowptr, src.to(torch.int32).to(device), None, n, n, n),
                             Csr(rowptr, inv.to(torch.int32).to(device), None, n, n, n))
             cache[key] = op

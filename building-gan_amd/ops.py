@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, stream
-from .plan import Csr, LinOp, SCALE_DIV, SCALE_NONE
+from .plan import Csr, LinOp, SCALE_DIV, SCALE_NONE, iota_i32
 
 ACT_NONE, ACT_LEAKY = 0, 1
 # Basis of the collapsed discriminator's polynomial in the aggregation operator A (include/bgan.h BG_CHAIN_*):
@@ -1003,7 +1003,7 @@ def _identity_op(plan) -> LinOp:
     op = plan.ops.get("vox_identity")
     if op is None:
         n = plan.Nv
-        op = LinOp(Csr(torch.arange(n + 1, dtype=torch.int32, device=plan.device), None, None, n, n, n))
+        op = LinOp(Csr(iota_i32(n + 1, plan.device), None, None, n, n, n))
         plan.ops["vox_identity"] = op
     return op
 

@@ -78,6 +78,24 @@ class LinOp:
         return a
 
 
+_IOTA = {}
+
+
+def iota_i32(n: int, device) -> torch.Tensor:
+    """0 .. n-1 as int32: a prefix of ONE array per device (the row pointers of one-slot-per-row operators are the
+    same numbers for every batch; a torch.arange per plan was a launch per step).  The array is written once, and the
+    device is synchronised then, so any stream may read it afterwards; it grows by doubling."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0))
+    buf = _IOTA.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.arange(max(2 * n, 1 << 16), dtype=torch.int32, device=dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        _IOTA[key] = buf
+    return buf[:n]
+
+
 def _i32(n, device):
     return torch.empty(n, dtype=torch.int32, device=device)
 
@@ -114,8 +132,7 @@ class _Builder:
     def gather_csr(self, idx32: torch.Tensor, n_cols: int) -> Csr:
         """One slot per row: y[i] = x[idx[i]] (an index_select as a Csr)."""
         n = int(idx32.numel())
-        rowptr = torch.arange(n + 1, dtype=torch.int32, device=self.device)
-        return Csr(rowptr, idx32, None, n, n_cols, n)
+        return Csr(iota_i32(n + 1, self.device), idx32, None, n, n_cols, n)
 
     def segptr(self, name, seg_id, nseg) -> torch.Tensor:
         p = _i32(nseg + 1, self.device)

@@ -492,6 +492,32 @@ def test_cross_logits_forward_backward(cuda):
     torch.testing.assert_close(thd.grad.cpu(), th.grad, rtol=1e-3, atol=1e-4)
 
 
+def test_attention_tanh_over_the_whole_line(cuda):
+    """The kernels' tanh ((e - 1) / (e + 1) on the hardware exp2 / reciprocal, common.h bg_tanh) against fp64 tanh:
+    a one-hot theta makes every cross-edge logit ONE tanh value, the arguments sweep 1e-7 .. 100 of both signs, +-0, +-1e4.
+    Stated bound: absolute error <= 1.5e-7 everywhere (the oracle's fp32 tanh is itself within 6e-8)."""
+    from building_gan_amd import ops
+    import copy
+    cpu = _batch("small", 8, True)
+    g, p = _plan(copy.deepcopy(cpu), cuda)
+    cev = cpu.cross_edge_voxel_index_select
+    H = 128
+    mag = torch.logspace(-7, 2, p.Nv, dtype=torch.float64)
+    xs = (mag * torch.where(torch.arange(p.Nv) % 2 == 0, 1.0, -1.0)).float()
+    xs[:4] = torch.tensor([0.0, -0.0, 1e4, -1e4])
+    a = torch.zeros(p.Nv, H); a[:, 0] = xs
+    th = torch.zeros(1, H); th[0, 0] = 1.0
+    out = ops.CrossLogits.apply(a.to(cuda), torch.zeros(p.Np, H, device=cuda), th.to(cuda), p).cpu()
+    want = torch.tanh(xs.double())[cev]
+    err = (out.double() - want).abs()
+    assert float(err.max()) <= 1.5e-7, float(err.max())
+    big = xs.abs()[cev] >= 0.3
+    assert float((err[big] / want[big].abs()).max()) <= 2.5e-7            # ~2 ulp where tanh is of order one
+    assert bool((out.abs() <= 1).all())                                   # (so 1 - t^2 >= 0 in the backward)
+    sat = out[xs[cev].abs() == 1e4]
+    assert sat.numel() > 0 and bool((sat.abs() >= 1 - 1.2e-7).all()) and torch.equal(sat.sign(), xs[cev][xs[cev].abs() == 1e4].sign())
+
+
 def test_weighted_sum_and_sddmm(cuda):
     from building_gan_amd import ops
     from oracle.scatter import scatter_sum
@@ -593,18 +619,20 @@ def test_mask_gumbel_two_way(cuda):
     torch.testing.assert_close(lg.grad.cpu(), logits.grad, rtol=1e-4, atol=1e-6)
 
 
-def test_one_launch_segment_sum_and_max(cuda):
+@pytest.mark.parametrize("n_seg,H", [(50, 128), (50, 256), (8, 256), (300, 128)])
+def test_one_launch_segment_sum_and_max(cuda, n_seg, H):
     """chunk_ptr == NULL form (a workgroup per segment) against the oracle: many segments of moderate,
-    ragged length, two of them empty, ties inside a segment."""
+    ragged length, two of them empty, ties inside a segment.  Up to 256 segments the max runs 1024 threads per
+    segment with a tree combine; above, 256 threads with the in-order combine."""
     from building_gan_amd import ops
     from building_gan_amd.plan import LinOp, SCALE_DIV, _Builder
     from oracle.scatter import scatter_max, scatter_mean
     torch.manual_seed(7)
-    n_seg, n = 50, 4000
+    n = 4000 if n_seg >= 32 else 100 * n_seg              # (a few segments go one per workgroup only when short)
     seg = torch.randint(0, n_seg, (n,))
     seg[seg == 11] = 12
     seg[seg == 30] = 29                                   # segments 11 and 30 are empty
-    H = 128
+    seg[seg == 2] = 3                                     # and segment 2 (the 8-segment case has no 11 or 30)
     x = torch.rand(n, H) * 2 - 1
     first = int((seg == 5).nonzero()[0])
     later = int((seg == 5).nonzero()[-1])
