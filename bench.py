@@ -140,7 +140,7 @@ def roofline_dominant_gemm(dev, batch, plan, hidden=128):
         with torch.cuda.stream(s):
             run()
         torch.cuda.current_stream().wait_stream(s)
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):     # (a process group's watchdog thread may poll events meanwhile)
             for _ in range(20):
                 run()
         return event_time_ms(g.replay, 10) / 20 * 1e3

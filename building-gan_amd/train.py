@@ -176,7 +176,8 @@ _PINNED_RING = []
 
 def _pinned_counts():
     """A 3-element pinned buffer out of a small ring (page-locking memory per call would cost more than the copy;
-    a buffer is read one iteration after it is filled, the ring holds sixteen)."""
+    a buffer is read one iteration after it is filled -- prefetch_counts takes two per call, one to send the local counts
+    and one to receive the sums -- and the ring holds sixteen)."""
     if not _PINNED_RING:
         _PINNED_RING.extend([torch.empty(3, dtype=torch.float64, pin_memory=True) for _ in range(16)] + [0])
     k = _PINNED_RING[-1]
@@ -200,7 +201,12 @@ def prefetch_counts(batch, group=None):
         return
     side = prefetch_stream(dev)
     with torch.cuda.stream(side):             # (the counts come from host-side shapes: nothing of the batch is read)
-        t = torch.tensor([B, S, Nv], dtype=torch.float64, device=dev)
+        # through pinned memory: torch.tensor(list, device=...) is a BLOCKING copy, and behind the plan kernels queued on
+        # this stream the host waited ~0.16 ms per step for it (tools/stream_host_profile.py, FORCE_DIST=1)
+        staged = _pinned_counts()
+        staged[0], staged[1], staged[2] = float(B), float(S), float(Nv)
+        t = torch.empty(3, dtype=torch.float64, device=dev)
+        t.copy_(staged, non_blocking=True)
         if dist.get_backend(group) == "gloo":
             side.synchronize()                # gloo reads the buffer from the host side
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -604,11 +610,16 @@ class Trainer:
         torch.cuda.synchronize()
         graphs = {}
         pool = None
+        # With a process group the collectives' watchdog thread polls the events of finished work whenever it likes; in
+        # the default ("global") capture mode such a query from ANOTHER thread during a capture here is an error that
+        # aborts the process (seen once the host stopped blocking in prefetch_counts).  The collectives themselves run
+        # between the segments, never inside one, so only this thread's calls need policing.
+        mode = "thread_local" if _collective(self.group) else "global"
 
         def cap(fn):
             nonlocal pool
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
                 res = fn()
             pool = g.pool()
             return g, res
