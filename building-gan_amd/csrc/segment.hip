@@ -277,9 +277,10 @@ __device__ __forceinline__ int64_t row_of_chunk(const int32_t* chunk_ptr, int64_
 // One workgroup per chunk.  LPR lanes own one slot's row (a float4 each); the workgroup keeps
 // 256/LPR slots in flight, each lane group walking its slots with stride 256/LPR; the groups'
 // partial results are then combined through LDS in group order (deterministic; for max the
-// smallest slot wins ties, which is the first-index rule).  T = 1024 is the max of a few long rows (the critic's
-// pooling: 80 stories of ~150 voxels): four times the slots in flight per row, and the groups combine as a tree,
-// which the tie rule makes order-free.
+// smallest slot wins ties, which is the first-index rule).  T = 1024 serves a few long rows (the critic's pooling and
+// the story sums of the generator's backward: 80 stories of ~150 voxels): four times the slots in flight per row,
+// and the groups combine as a fixed tree (for the max the tie rule makes the order immaterial; a sum is deterministic
+// but rounds in another order than the 256-thread form).
 template <bool IS_MAX, int T = 256>
 __global__ __launch_bounds__(T) void k_chunk_reduce(ChunkArgs a, int lpr, int hoff) {
     __shared__ float4 sval[T];
@@ -338,19 +339,24 @@ __global__ __launch_bounds__(T) void k_chunk_reduce(ChunkArgs a, int lpr, int ho
     __syncthreads();
 #define BG_CMB(f)                                                                           \
     if (v.f > acc.f || (v.f == acc.f && kk.f < ak.f)) { acc.f = v.f; ak.f = kk.f; }
-    if (IS_MAX && T > 256) {
+    if (T > 256) {                    // a fixed tree over the lane groups: deterministic, and order-free for the max
         for (int half = spb >> 1; half >= 1; half >>= 1) {
             if (grp < half) {
                 float4 v = sval[(grp + half) * lpr + sub];
-                int4 kk = sarg[(grp + half) * lpr + sub];
-                BG_CMB(x) BG_CMB(y) BG_CMB(z) BG_CMB(w)
-                if (half > 1) { sval[threadIdx.x] = acc; sarg[threadIdx.x] = ak; }
+                if (IS_MAX) {
+                    int4 kk = sarg[(grp + half) * lpr + sub];
+                    BG_CMB(x) BG_CMB(y) BG_CMB(z) BG_CMB(w)
+                    if (half > 1) sarg[threadIdx.x] = ak;
+                } else {
+                    acc = bg_add4(acc, v);
+                }
+                if (half > 1) sval[threadIdx.x] = acc;
             }
             if (half > 1) __syncthreads();
         }
     }
     if (grp == 0 && live) {
-        for (int g = 1; g < spb && !(IS_MAX && T > 256); ++g) {
+        for (int g = 1; g < spb && T <= 256; ++g) {
             float4 v = sval[g * lpr + sub];
             if (IS_MAX) {
                 int4 kk = sarg[g * lpr + sub];
@@ -425,7 +431,7 @@ int launch_chunk_reduce(const ChunkArgs& a, int64_t n_chunks_ub, hipStream_t s) 
         int h4 = (a.H - hoff) / 4 < 64 ? (a.H - hoff) / 4 : 64;
         int lpr = 1;
         while (lpr < h4) lpr <<= 1;
-        if (IS_MAX && !a.chunk_ptr && n_chunks_ub <= 256)      // a few rows: the chip is mostly idle, so widen each row
+        if (!a.chunk_ptr && n_chunks_ub <= 512)      // a few rows (<= 2 workgroups per CU): the chip is mostly idle, so widen each row
             k_chunk_reduce<IS_MAX, 1024><<<(int)n_chunks_ub, 1024, 0, s>>>(a, lpr, hoff);
         else
             k_chunk_reduce<IS_MAX><<<(int)n_chunks_ub, 256, 0, s>>>(a, lpr, hoff);

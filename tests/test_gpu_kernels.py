@@ -619,11 +619,11 @@ def test_mask_gumbel_two_way(cuda):
     torch.testing.assert_close(lg.grad.cpu(), logits.grad, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("n_seg,H", [(50, 128), (50, 256), (8, 256), (300, 128)])
+@pytest.mark.parametrize("n_seg,H", [(50, 128), (50, 256), (8, 256), (300, 128), (600, 128)])
 def test_one_launch_segment_sum_and_max(cuda, n_seg, H):
     """chunk_ptr == NULL form (a workgroup per segment) against the oracle: many segments of moderate,
-    ragged length, two of them empty, ties inside a segment.  Up to 256 segments the max runs 1024 threads per
-    segment with a tree combine; above, 256 threads with the in-order combine."""
+    ragged length, two of them empty, ties inside a segment.  Up to 512 segments a reduction runs 1024 threads per
+    segment with a tree combine over the lane groups; above, 256 threads with the in-order combine."""
     from building_gan_amd import ops
     from building_gan_amd.plan import LinOp, SCALE_DIV, _Builder
     from oracle.scatter import scatter_max, scatter_mean
