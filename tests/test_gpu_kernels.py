@@ -619,7 +619,7 @@ def test_mask_gumbel_two_way(cuda):
     torch.testing.assert_close(lg.grad.cpu(), logits.grad, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("n_seg,H", [(50, 128), (50, 256), (8, 256), (300, 128), (600, 128)])
+@pytest.mark.parametrize("n_seg,H", [(50, 128), (50, 256), (8, 256), (20, 320), (300, 128), (600, 128)])
 def test_one_launch_segment_sum_and_max(cuda, n_seg, H):
     """chunk_ptr == NULL form (a workgroup per segment) against the oracle: many segments of moderate,
     ragged length, two of them empty, ties inside a segment.  Up to 512 segments a reduction runs 1024 threads per
