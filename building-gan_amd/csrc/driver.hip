@@ -374,11 +374,13 @@ CriticBuffers carve_critic(Arena& ar, const bgCriticHead& h) {
     b.v[1] = b.v[0] ? b.v[0] + N * H2 : nullptr; b.v[2] = b.v[0] ? b.v[0] + 2 * N * H2 : nullptr;
     b.dS = ar.take(N * H2);
     b.idx3 = reinterpret_cast<int32_t*>(ar.take(3 * N));
-    b.Xs = ar.take(2 * S * H2); b.Xb = ar.take(2 * B * H2);
-    b.as = reinterpret_cast<int32_t*>(ar.take(2 * S * H2)); b.ab = reinterpret_cast<int32_t*>(ar.take(2 * B * H2));
+    // pooled rows and arg-max ids of the three label sets in one piece each (real, fake, sample: one pooling launch per
+    // level serves all three; the decoders read the first two sets' rows)
+    b.Xs = ar.take(3 * S * H2); b.Xb = ar.take(3 * B * H2);
+    b.as = reinterpret_cast<int32_t*>(ar.take(3 * S * H2)); b.ab = reinterpret_cast<int32_t*>(ar.take(3 * B * H2));
     b.hs = ar.take(2 * S * Hd); b.hb = ar.take(2 * B * Hd); b.vals = ar.take(2 * S); b.valb = ar.take(2 * B);
-    b.hat_s = ar.take(S * H2); b.hat_b = ar.take(B * H2);
-    b.arg_s = reinterpret_cast<int32_t*>(ar.take(S * H2)); b.arg_sb = reinterpret_cast<int32_t*>(ar.take(B * H2));
+    b.hat_s = b.Xs ? b.Xs + 2 * S * H2 : nullptr; b.hat_b = b.Xb ? b.Xb + 2 * B * H2 : nullptr;
+    b.arg_s = b.as ? b.as + 2 * S * H2 : nullptr; b.arg_sb = b.ab ? b.ab + 2 * B * H2 : nullptr;
     b.arg_b = reinterpret_cast<int32_t*>(ar.take(B * H2));
     b.gp_b = ar.take(H2); b.gp_s = ar.take(H2);
     b.G2 = b.v[2]; b.X = ar.take(2 * N * K1 * dl); b.Ys = ar.take(N * K1 * 2 * dl); b.acc = ar.take(N * 2 * dl);
@@ -465,20 +467,15 @@ extern "C" int bg_critic_head_forward_f32(const bgCriticHead* hp, float coef, fl
         BG_TRY(bg_gemm_f32(0, 0, 3 * N, H2, 1, A, ld, Ks, Wl, H2, b.v[0], H2, nullptr, nullptr, BG_ACT_NONE, 0.f, nullptr, 0,
                            b.Sb, H2, b.idx3, nullptr, 0, nullptr, 0, s));
     }
-    // D(real), D(fake): max over each story, then over the stories of each graph; both sets share one run of a decoder
-    for (int p = 0; p < 2; ++p) {
-        BG_TRY(bg_segmax_f32(b.v[p], H2, h.st_rowptr, h.st_col, nullptr, 0, 0, nullptr, nullptr, b.Xs + p * S * H2, H2,
-                             b.as + p * S * H2, S, H2, s));
-        BG_TRY(bg_segmax_f32(b.Xs + p * S * H2, H2, h.sg_rowptr, h.sg_col, nullptr, 0, 0, nullptr, nullptr,
-                             b.Xb + p * B * H2, H2, b.ab + p * B * H2, B, H2, s));
-    }
+    // D(real), D(fake) and the sample point: max over each story, then over the stories of each graph -- the three label
+    // sets by ONE launch per level (set 2's rows are hat_s / hat_b, its ids arg_s / arg_sb: which voxel carries each pooled
+    // column, losses.py:83-84 in closed form); real and fake share one run of a decoder
+    BG_TRY(bg_segmax_batch_f32(b.v[0], H2, N * H2, h.st_rowptr, h.st_col, b.Xs, H2, S * H2, b.as, S * H2, S, H2, 3, s));
+    BG_TRY(bg_segmax_batch_f32(b.Xs, H2, S * H2, h.sg_rowptr, h.sg_col, b.Xb, H2, B * H2, b.ab, B * H2, B, H2, 3, s));
     // both decoders: one launch each (no activation between their layers: val = X (w2 W1)^T + w2 . b1 + b2; the row
     // w2 W1 is kept -- d D / d pooled of such a decoder is that constant row)
     BG_TRY(bg_decoder_fwd_f32(2 * S, H2, Hd, b.Xs, H2, h.s_w1, H2, h.s_b1, h.s_w2, h.s_b2, b.vals, b.gp_s, s));
     BG_TRY(bg_decoder_fwd_f32(2 * B, H2, Hd, b.Xb, H2, h.b_w1, H2, h.b_b1, h.b_w2, h.b_b2, b.valb, b.gp_b, s));
-    // the sample point: which voxel carries each pooled column (losses.py:83-84 in closed form)
-    BG_TRY(bg_segmax_f32(b.v[2], H2, h.st_rowptr, h.st_col, nullptr, 0, 0, nullptr, nullptr, b.hat_s, H2, b.arg_s, S, H2, s));
-    BG_TRY(bg_segmax_f32(b.hat_s, H2, h.sg_rowptr, h.sg_col, nullptr, 0, 0, nullptr, nullptr, b.hat_b, H2, b.arg_sb, B, H2, s));
     BG_TRY(bg_gather_arg_f32(reinterpret_cast<const float*>(b.arg_s), H2, b.arg_sb, reinterpret_cast<float*>(b.arg_b), H2, B, H2, s));
     // scattered to the arg-max voxels (row pitch 0: every segment reads the same row): building rows, then story rows
     BG_TRY(bg_scatter_arg_f32(b.gp_b, 0, b.arg_b, h.graph_of_voxel, b.G2, H2, B, N, H2, s));
@@ -533,13 +530,11 @@ extern "C" int bg_critic_head_backward_f32(const bgCriticHead* hp, float coef, c
     // (g W1 = w2 (x) c, g W2 = W1 c).  D(real), D(fake): building decoder, back through the story level, story decoder.
     BG_TRY(bg_decoder_bwd_f32(2 * B, B, H2, Hd, b.dvb, b.Xb, H2, h.b_b1, b.dgp_b, H2, h.b_w1, H2, h.b_w2, b.gp_b, nullptr, 0,
                               g_b_w1, H2, g_b_b1, g_b_w2, g_b_b2, b.dXb, H2, s));
-    for (int p = 0; p < 2; ++p)
-        BG_TRY(bg_scatter_arg_f32(b.dXb + p * B * H2, H2, b.ab + p * B * H2, h.graph_of_story, b.T + p * S * H2, H2, B, S, H2, s));
+    BG_TRY(bg_scatter_arg_batch_f32(b.dXb, H2, B * H2, b.ab, B * H2, h.graph_of_story, b.T, H2, S * H2, B, S, H2, 2, s));
     BG_TRY(bg_decoder_bwd_f32(2 * S, S, H2, Hd, b.dvs, b.Xs, H2, h.s_b1, b.dgp_s, H2, h.s_w1, H2, h.s_w2, b.gp_s, b.T, H2,
                               g_s_w1, H2, g_s_b1, g_s_w2, g_s_b2, b.dXs, H2, s));          // + what arrived through the buildings
     // to the arg-max voxels (v[0], v[1] are free after the forward's pooling: they take d v), then the coefficient table
-    for (int p = 0; p < 2; ++p)
-        BG_TRY(bg_scatter_arg_f32(b.dXs + p * S * H2, H2, b.as + p * S * H2, h.story_of_voxel, b.v[p], H2, S, N, H2, s));
+    BG_TRY(bg_scatter_arg_batch_f32(b.dXs, H2, S * H2, b.as, S * H2, h.story_of_voxel, b.v[0], H2, N * H2, S, N, H2, 2, s));
     // label rows: Zp0^T dv0 + Zp1^T dv1 + dX^T G2 as one product over the 4 N stacked rows
     BG_TRY(tn(K1 * dl, H2, 4 * N, b.Zp[0], b.v[0], gWl, b.splitk, 0, s));
     BG_TRY(bg_add_f32(b.v[0], b.v[1], b.dS, N * H2, s));

@@ -262,6 +262,8 @@ struct ChunkArgs {
     float* partial; int32_t* partial_arg; int H;
     // direct mode (chunk_ptr == nullptr): one workgroup per ROW, final result written here
     float* out; int64_t ldo; int32_t* arg; const float* row_scale; int row_mode;
+    // direct mode, blockIdx.y = b: the same reduction of x + b * x_step into out + b * out_step (arg + b * arg_step)
+    int64_t x_step, out_step, arg_step;
 };
 
 // binary search: the row r with chunk_ptr[r] <= c < chunk_ptr[r+1]
@@ -287,6 +289,11 @@ __global__ __launch_bounds__(T) void k_chunk_reduce(ChunkArgs a, int lpr, int ho
     __shared__ int4 sarg[IS_MAX ? T : 1];
     const int32_t c = blockIdx.x;
     const bool direct = a.chunk_ptr == nullptr;
+    if (direct && blockIdx.y) {
+        a.x += (int64_t)blockIdx.y * a.x_step;
+        a.out += (int64_t)blockIdx.y * a.out_step;
+        if (IS_MAX) a.arg += (int64_t)blockIdx.y * a.arg_step;
+    }
     if (!direct && c >= a.chunk_ptr[a.n_rows]) return;
     const int64_t row = direct ? (int64_t)c : row_of_chunk(a.chunk_ptr, a.n_rows, c);
     const int32_t k0 = direct ? a.rowptr[row] : a.rowptr[row] + (c - a.chunk_ptr[row]) * a.R;
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(256) void k_chunk_reduce_scalar(ChunkArgs a) {
 }
 
 template <bool IS_MAX>
-int launch_chunk_reduce(const ChunkArgs& a, int64_t n_chunks_ub, hipStream_t s) {
+int launch_chunk_reduce(const ChunkArgs& a, int64_t n_chunks_ub, hipStream_t s, int64_t n_batch = 1) {
     bool vec = (a.H % 4 == 0) && (a.ldx % 4 == 0) && bg_aligned16(a.x);
     if (a.chunk_ptr) vec = vec && bg_aligned16(a.partial) && (!IS_MAX || bg_aligned16(a.partial_arg));
     else vec = vec && bg_aligned16(a.out) && (a.ldo % 4 == 0) && (!IS_MAX || bg_aligned16(a.arg));
@@ -431,10 +438,11 @@ int launch_chunk_reduce(const ChunkArgs& a, int64_t n_chunks_ub, hipStream_t s) 
         int h4 = (a.H - hoff) / 4 < 64 ? (a.H - hoff) / 4 : 64;
         int lpr = 1;
         while (lpr < h4) lpr <<= 1;
-        if (!a.chunk_ptr && n_chunks_ub <= 512)      // a few rows (<= 2 workgroups per CU): the chip is mostly idle, so widen each row
-            k_chunk_reduce<IS_MAX, 1024><<<(int)n_chunks_ub, 1024, 0, s>>>(a, lpr, hoff);
+        const dim3 grid((unsigned)n_chunks_ub, (unsigned)n_batch);
+        if (!a.chunk_ptr && n_chunks_ub * n_batch <= 512)      // a few rows (<= 2 workgroups per CU): the chip is mostly idle, so widen each row
+            k_chunk_reduce<IS_MAX, 1024><<<grid, 1024, 0, s>>>(a, lpr, hoff);
         else
-            k_chunk_reduce<IS_MAX><<<(int)n_chunks_ub, 256, 0, s>>>(a, lpr, hoff);
+            k_chunk_reduce<IS_MAX><<<grid, 256, 0, s>>>(a, lpr, hoff);
         BG_LAUNCH_CHECK();
     }
     return BG_OK;
@@ -492,9 +500,11 @@ __global__ void k_scatter_arg_dense(const float* __restrict__ g, int64_t ldg, co
 // the same, four channels per thread (H % 4 == 0, 16-byte aligned rows, fewer than 2^31 elements)
 __global__ __launch_bounds__(256) void k_scatter_arg_dense4(const float* __restrict__ g, int64_t ldg,
                                                             const int32_t* __restrict__ arg, const int32_t* __restrict__ seg_of,
-                                                            float* __restrict__ out, int64_t ldo, uint32_t n4, uint32_t H4) {
+                                                            float* __restrict__ out, int64_t ldo, uint32_t n4, uint32_t H4,
+                                                            int64_t g_step = 0, int64_t arg_step = 0, int64_t out_step = 0) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n4) return;
+    g += (int64_t)blockIdx.y * g_step; arg += (int64_t)blockIdx.y * arg_step; out += (int64_t)blockIdx.y * out_step;   // (batch)
     const uint32_t r = t / H4, h = 4u * (t - r * H4);
     const int32_t s = seg_of[r];
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1250,6 +1260,44 @@ int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, const in
     k_scatter_arg<<<bg_grid_for(n_seg * H, 256, 0x7fffffff), 256, 0, s>>>(g, ldg, arg, out, ldo, n_seg, (int)H);
     BG_LAUNCH_CHECK();
     return BG_OK;
+}
+
+// n_batch scatters that share the segments (rows' segment ids) in one launch: batch b reads g + b * g_step and
+// arg + b * arg_step and writes out + b * out_step (the critic's pooling backward for D(real) and D(fake))
+int bg_scatter_arg_batch_f32(const float* g, int64_t ldg, int64_t g_step, const int32_t* arg, int64_t arg_step,
+                             const int32_t* seg_of, float* out, int64_t ldo, int64_t out_step, int64_t n_seg, int64_t n_rows,
+                             int64_t H, int64_t n_batch, bgStream stream) {
+    if (n_seg <= 0 || H < 0 || n_rows < 0 || n_batch < 1 || n_batch > 65535) return BG_ERR_ARG;
+    if (n_rows == 0 || H == 0) return BG_OK;
+    if (!out || !g || !arg || !seg_of || ldo < H) return BG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (H % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && g_step % 4 == 0 && arg_step % 4 == 0 && out_step % 4 == 0 &&
+        bg_aligned16(g) && bg_aligned16(arg) && bg_aligned16(out) && n_rows * (H / 4) < 0x7fffffff) {
+        const uint32_t n4 = (uint32_t)(n_rows * (H / 4));
+        k_scatter_arg_dense4<<<dim3((n4 + 255u) / 256u, (unsigned)n_batch), 256, 0, s>>>(g, ldg, arg, seg_of, out, ldo, n4,
+                                                                                        (uint32_t)(H / 4), g_step, arg_step, out_step);
+        BG_LAUNCH_CHECK();
+        return BG_OK;
+    }
+    for (int64_t b = 0; b < n_batch; ++b) {
+        int rc = bg_scatter_arg_f32(g + b * g_step, ldg, arg + b * arg_step, seg_of, out + b * out_step, ldo, n_seg, n_rows, H, stream);
+        if (rc != BG_OK) return rc;
+    }
+    return BG_OK;
+}
+
+// n_batch segment maxima over the SAME segments in one launch (a workgroup per segment and batch; the form of
+// bg_segmax_f32 without chunk tables): batch b reduces x + b * x_step into out + b * out_step, arg + b * arg_step
+int bg_segmax_batch_f32(const float* x, int64_t ldx, int64_t x_step, const int32_t* rowptr, const int32_t* col,
+                        float* out, int64_t ldo, int64_t out_step, int32_t* arg, int64_t arg_step,
+                        int64_t n_rows, int64_t H, int64_t n_batch, bgStream stream) {
+    if (n_rows < 0 || H < 0 || n_batch < 1 || n_batch > 65535) return BG_ERR_ARG;
+    if (n_rows == 0 || H == 0) return BG_OK;
+    if (!x || !rowptr || !out || !arg || ldx < H || ldo < H) return BG_ERR_ARG;
+    if (x_step % 4 != 0 || out_step % 4 != 0 || arg_step % 4 != 0) return BG_ERR_ALIGN;
+    ChunkArgs a{x, ldx, rowptr, col, nullptr, nullptr, nullptr, 0, n_rows, nullptr, nullptr, (int)H,
+                out, ldo, arg, nullptr, 0, x_step, out_step, arg_step};
+    return launch_chunk_reduce<true>(a, n_rows, (hipStream_t)stream, n_batch);
 }
 
 int bg_sddmm_f32(const float* a, int64_t lda, const float* b, int64_t ldb,

@@ -201,6 +201,34 @@ def segmax_raw(c: Csr, x: torch.Tensor):
     return out, arg
 
 
+def segmax_batch_raw(c: Csr, x: torch.Tensor):
+    """Segment max + arg of ``x`` [n_batch, n_cols, H] over the same segments for every batch, one launch
+    (bg_segmax_batch_f32: the one-launch form, a workgroup per segment and batch)."""
+    lib = _lib.load()
+    if x.dim() != 3 or x.shape[1] != c.n_cols or x.dtype != torch.float32 or not x.is_contiguous():
+        raise _lib.BganError("segmax_batch: x must be a contiguous float32 [n_batch, n_cols, H]")
+    nb, _, H = x.shape
+    out = torch.empty(nb, c.n_rows, H, dtype=torch.float32, device=x.device)
+    arg = torch.empty(nb, c.n_rows, H, dtype=torch.int32, device=x.device)
+    check(lib.bg_segmax_batch_f32(ptr(x), H, c.n_cols * H, ptr(c.rowptr), ptr(c.col), ptr(out), H, c.n_rows * H, ptr(arg),
+                                  c.n_rows * H, c.n_rows, H, nb, stream()), "bg_segmax_batch_f32")
+    return out, arg
+
+
+def scatter_arg_batch_raw(g: torch.Tensor, arg: torch.Tensor, n_rows: int, seg_of: torch.Tensor) -> torch.Tensor:
+    """scatter_arg_raw's row-lookup form for g, arg [n_batch, n_seg, H] sharing ``seg_of``: one launch."""
+    lib = _lib.load()
+    if g.dim() != 3 or g.shape != arg.shape or not g.is_contiguous() or not arg.is_contiguous() or g.dtype != torch.float32:
+        raise _lib.BganError("scatter_arg_batch: g and arg must be contiguous [n_batch, n_seg, H]")
+    if seg_of.dtype != torch.int32 or seg_of.numel() != n_rows:
+        raise _lib.BganError("scatter_arg_batch: seg_of must be int32 [n_rows]")
+    nb, S, H = g.shape
+    out = torch.empty(nb, n_rows, H, dtype=torch.float32, device=g.device)
+    check(lib.bg_scatter_arg_batch_f32(ptr(g), H, S * H, ptr(arg), S * H, ptr(seg_of), ptr(out), H, n_rows * H, S, n_rows, H,
+                                       nb, stream()), "bg_scatter_arg_batch_f32")
+    return out
+
+
 def gather_arg_raw(x: torch.Tensor, arg: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x2 = _f32c(x)

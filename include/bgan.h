@@ -244,6 +244,15 @@ int bg_segmax_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int3
                   float* partial_val, int32_t* partial_arg,
                   float* out, int64_t ldo, int32_t* arg, int64_t n_rows, int64_t H, bgStream stream);
 
+/* n_batch maxima over the SAME segments in one launch (bg_segmax_f32's one-launch form, chunk_ptr == NULL): batch b
+ * reduces the rows x + b * x_step into out + b * out_step and arg + b * arg_step.  Steps are in elements and multiples
+ * of 4; H % 4 == 0, 16-byte aligned operands (BG_ERR_ALIGN otherwise); n_batch <= 65535.
+ * replaces: the global_max_pool calls of D(real), D(fake) and D(sample) in one critic update, Model/models.py:262-263
+ * reached three times from train.py:88-96.                                                                          */
+int bg_segmax_batch_f32(const float* x, int64_t ldx, int64_t x_step, const int32_t* rowptr, const int32_t* col,
+                        float* out, int64_t ldo, int64_t out_step, int32_t* arg, int64_t arg_step,
+                        int64_t n_rows, int64_t H, int64_t n_batch, bgStream stream);
+
 /* bg_segmax_f32's two-phase form for callers that cannot allocate (code under hipGraph capture, tight serving
  * loops, harnesses that forbid hipMalloc): the chunk partials live in a buffer of BG_SEGMAX_STATIC_ELEMS values +
  * as many arg entries (8 MiB in all) that the library holds in every GPU's memory until the process ends, so the
@@ -270,6 +279,13 @@ int bg_gather_arg_f32(const float* x, int64_t ldx, const int32_t* arg, float* ou
  * replaces: torch_scatter.scatter_max backward (gradient to the arg element only).          */
 int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, const int32_t* seg_of, float* out, int64_t ldo,
                        int64_t n_seg, int64_t n_rows, int64_t H, bgStream stream);
+
+/* n_batch scatters of bg_scatter_arg_f32's row-lookup form (seg_of required) that share the segments, in one launch:
+ * batch b reads g + b * g_step and arg + b * arg_step and writes out + b * out_step (steps in elements).
+ * replaces: the scatter_max backward of the pooled D(real) and D(fake) in d_loss.backward(), train.py:98.        */
+int bg_scatter_arg_batch_f32(const float* g, int64_t ldg, int64_t g_step, const int32_t* arg, int64_t arg_step,
+                             const int32_t* seg_of, float* out, int64_t ldo, int64_t out_step, int64_t n_seg,
+                             int64_t n_rows, int64_t H, int64_t n_batch, bgStream stream);
 
 /* out[k] = dot(a[r_k,:], b[c_k,:]) for every CSR slot k (r_k = the row owning slot k),
  * written to out[eperm ? eperm[k] : k].   The weight-gradient of bg_spmm_f32.                */

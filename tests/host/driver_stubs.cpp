@@ -165,6 +165,20 @@ int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, const in
     rec(13, a, sizeof(a) / 8);
     return 0;
 }
+int bg_segmax_batch_f32(const float* x, int64_t ldx, int64_t x_step, const int32_t* rowptr, const int32_t* col, float* out,
+                        int64_t ldo, int64_t out_step, int32_t* arg, int64_t arg_step, int64_t n_rows, int64_t H,
+                        int64_t n_batch, bgStream) {
+    int64_t a[] = {P(x), ldx, x_step, P(rowptr), P(col), P(out), ldo, out_step, P(arg), arg_step, n_rows, H, n_batch};
+    rec(39, a, sizeof(a) / 8);
+    return 0;
+}
+int bg_scatter_arg_batch_f32(const float* g, int64_t ldg, int64_t g_step, const int32_t* arg, int64_t arg_step,
+                             const int32_t* seg_of, float* out, int64_t ldo, int64_t out_step, int64_t n_seg, int64_t n_rows,
+                             int64_t H, int64_t n_batch, bgStream) {
+    int64_t a[] = {P(g), ldg, g_step, P(arg), arg_step, P(seg_of), P(out), ldo, out_step, n_seg, n_rows, H, n_batch};
+    rec(40, a, sizeof(a) / 8);
+    return 0;
+}
 int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* row_scale,
                       int row_mode, const float* col_scale, int col_mode, const int32_t* blk_ptr, int64_t n_blk,
                       int64_t max_rows, int64_t max_nnz, int64_t max_deg, const float* add, int64_t ld_add, int64_t add_step,

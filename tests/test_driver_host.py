@@ -444,6 +444,24 @@ def _check_critic_calls(calls, R, h):
             R.check(out, ((nseg - 1) * ldo + H) * f, tag + " out")
             R.check(arg, nseg * H * 4, tag + " arg")
             assert out != x
+        elif kind == 39:
+            x, ldx, xs, rp, col, out, ldo, os_, arg, as_, n_rows, H, nb = a
+            nseg, xr = rows_of[R.check(rp, 4, tag + " rowptr")]
+            assert n_rows == nseg and nb == 3 and xs == xr * ldx and os_ == nseg * ldo and as_ == nseg * H
+            R.check(rp, (nseg + 1) * 4, tag + " rowptr")
+            R.check(col, xr * 4, tag + " col")
+            R.check(x, ((nb * xr - 1) * ldx + H) * f, tag + " x (all sets)")
+            R.check(out, ((nb * nseg - 1) * ldo + H) * f, tag + " out (all sets)")
+            R.check(arg, nb * nseg * H * 4, tag + " arg (all sets)")
+            assert out != x
+        elif kind == 40:
+            g, ldg, gs, arg, as_, seg_of, out, ldo, os_, n_seg, n_rows, H, nb = a
+            assert nb == 2 and gs == n_seg * ldg and as_ == n_seg * H and os_ == n_rows * ldo
+            R.check(g, ((nb * n_seg - 1) * ldg + H) * f, tag + " g (both sets)")
+            R.check(arg, nb * n_seg * H * 4, tag + " arg (both sets)")
+            R.check(seg_of, n_rows * 4, tag + " seg_of")
+            R.check(out, ((nb * n_rows - 1) * ldo + H) * f, tag + " out (both sets)")
+            assert out != g
         elif kind == 12:
             x, ldx, arg, out, ldo, n_seg, H = a
             R.check(arg, n_seg * H * 4, tag + " arg")
@@ -538,9 +556,10 @@ def test_critic_head_host_sequence_and_extents(drv, N, S, B, basis):
     (rc_f, rc_b), fwd, bwd, R, h = _critic_run(drv, N, S, B, basis=basis)
     assert rc_f == 0 and rc_b == 0
     # 38: a decoder's forward as one launch (it also leaves w2 W1, which the scatters below read)
-    assert [k for k, _ in fwd] == [10, 1, 28, 1, 11, 11, 11, 11, 38, 38, 11, 11, 12, 13, 13, 1, 10, 14, 15]
-    # 37: a decoder's whole backward (penalty share included) as one launch
-    assert [k for k, _ in bwd] == [16, 20, 14, 10, 1, 12, 12, 37, 13, 13, 37, 13, 13, 19, 18, 19]
+    # 39: the three label sets pooled by one launch per level (voxel -> story, story -> graph)
+    assert [k for k, _ in fwd] == [10, 1, 28, 1, 39, 39, 38, 38, 12, 13, 13, 1, 10, 14, 15]
+    # 37: a decoder's whole backward (penalty share included) as one launch; 40: real and fake scattered by one launch
+    assert [k for k, _ in bwd] == [16, 20, 14, 10, 1, 12, 12, 37, 40, 37, 40, 19, 18, 19]
     _check_critic_calls(fwd, R, h)
     _check_critic_calls(bwd, R, h)
     # where the gradients land: the eight decoder outputs by the two decoder launches (checked above), gW by the products

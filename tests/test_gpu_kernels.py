@@ -1073,6 +1073,32 @@ def test_scatter_arg_row_lookup_equals_fill_and_scatter(cuda):
         assert float(want.abs().sum()) > 0
 
 
+def test_pooling_of_several_label_sets_in_one_launch(cuda):
+    """bg_segmax_batch_f32 / bg_scatter_arg_batch_f32 (the critic's real, fake and sample rows pooled by one launch per
+    level, their backward scattered by one) against one call per set: values, arg-max ids and scattered rows identical,
+    for the voxel -> story and the story -> graph plans, three sets of H = 256 and two of H = 128, a tie included."""
+    from building_gan_amd import ops
+    import copy
+    g_, p = _plan(copy.deepcopy(_batch("small", 12, True)), cuda)
+    gen = torch.Generator().manual_seed(29)
+    for csr, n in ((p.story_seg, p.Nv), (p.story_graph_seg, p.S)):
+        for H, nb in ((256, 3), (128, 2)):
+            x = (torch.rand(nb, n, H, generator=gen) * 2 - 1).to(cuda)
+            x[0, 1] = x[0, 0]                                         # a tie inside the first segment: first index wins
+            val, arg = ops.segmax_batch_raw(csr, x)
+            for b in range(nb):
+                v1, a1 = ops.segmax_raw(csr, x[b])
+                assert torch.equal(val[b], v1) and torch.equal(arg[b], a1)
+            g = (torch.rand(nb, csr.n_rows, H, generator=gen) * 2 - 1).to(cuda)
+            got = ops.scatter_arg_batch_raw(g, arg, n, csr.seg_of)
+            for b in range(nb):
+                assert torch.equal(got[b], ops.scatter_arg_raw(g[b], arg[b], n, seg_of=csr.seg_of))
+            assert float(got.abs().sum()) > 0
+    lib_err = ops._lib.BganError
+    with pytest.raises(lib_err):
+        ops.segmax_batch_raw(p.story_seg, torch.zeros(2, p.Nv + 1, 8, device=cuda))
+
+
 def test_pos_terms_and_static_columns(cuda):
     """bg_pos_terms_f32 against the scatter-mean statement (has * pos - mean_j pos_j: bit-exact, including an
     isolated voxel) and bg_d_static_cols_f32 against the concatenation it replaces."""
