@@ -89,6 +89,8 @@ def iota_i32(n: int, device) -> torch.Tensor:
     key = (dev.type, dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0))
     buf = _IOTA.get(key)
     if buf is None or buf.numel() < n:
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return torch.arange(n, dtype=torch.int32, device=dev)      # (no synchronisation inside a capture: not kept)
         buf = torch.arange(max(2 * n, 1 << 16), dtype=torch.int32, device=dev)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
