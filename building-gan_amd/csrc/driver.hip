@@ -844,14 +844,21 @@ extern "C" int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGener
 namespace {
 struct PStack {
     float *x[33], *both[32], *aggr[32], *y[32];
-    float *g0, *g1, *gz, *gcat, *gpre, *gcat2, *t, *splitk, *colsum;
+    // backward: the layers' gz / gpre and the two halves of `both` as contiguous [L Np, H] stacks -- the shared weights'
+    // gradients are ONE product (and one column sum) each over the stacked layers after the loop, as in the voxel stack
+    float *gz_all, *gpre_all, *top_all, *bot_all;
+    float *g0, *g1, *gcat, *gcat2, *t, *splitk, *colsum;
 };
 int carve_pstack(Arena& ar, int64_t Np, int64_t H, int64_t kin, int64_t L, PStack& b) {
     if (L < 0 || L > 32) return BG_ERR_SHAPE;
-    for (int64_t l = 0; l <= L; ++l) b.x[l] = ar.take(Np * H);
-    for (int64_t l = 0; l < L; ++l) { b.both[l] = ar.take(2 * Np * H); b.aggr[l] = ar.take(Np * H); b.y[l] = ar.take(Np * H); }
-    b.g0 = ar.take(Np * H); b.g1 = ar.take(Np * H); b.gz = ar.take(Np * H); b.gcat = ar.take(Np * 3 * H);
-    b.gpre = ar.take(Np * H); b.gcat2 = ar.take(Np * 2 * H); b.t = ar.take(Np * H);
+    for (int64_t l = 0; l <= L; ++l) b.x[l] = ar.take(Np * H);                 // x[0 .. L-1] and aggr[.]: contiguous stacks
+    for (int64_t l = 0; l < L; ++l) b.aggr[l] = ar.take(Np * H);
+    for (int64_t l = 0; l < L; ++l) { b.both[l] = ar.take(2 * Np * H); b.y[l] = ar.take(Np * H); }
+    const int64_t Ls = L > 0 ? L : 1;
+    b.gz_all = ar.take(Ls * Np * H); b.gpre_all = ar.take(Ls * Np * H);
+    b.top_all = ar.take(Ls * Np * H); b.bot_all = ar.take(Ls * Np * H);
+    b.g0 = ar.take(Np * H); b.g1 = ar.take(Np * H); b.gcat = ar.take(Np * 3 * H);
+    b.gcat2 = ar.take(Np * 2 * H); b.t = ar.take(Np * H);
     int64_t sk = 0;
     auto need = [&](int64_t M, std::initializer_list<int64_t> ns, int64_t R) {
         int64_t Ns[4] = {0, 0, 0, 0}, N = 0; int n = 0;
@@ -859,7 +866,7 @@ int carve_pstack(Arena& ar, int64_t Np, int64_t H, int64_t kin, int64_t L, PStac
         const int64_t x = (int64_t)tn_splits_multi(M, Ns, n, R) * M * N;
         if (x > sk) sk = x;
     };
-    need(H, {H, H, H}, Np); need(H, {H, H}, Np); need(H, {kin}, Np);
+    need(H, {H, H, H}, Ls * Np); need(H, {H, H}, Ls * Np); need(H, {kin}, Np);
     b.splitk = ar.take(sk);
     b.colsum = ar.take(256 * H);
     return BG_OK;
@@ -928,32 +935,20 @@ extern "C" int bg_pstack_backward_f32(const bgGeneratorWeights* w, const bgGener
         BG_TRY(bg_fill_f32(g_upd_w, H * 3 * H, 0.f, s)); BG_TRY(bg_fill_f32(g_upd_b, H, 0.f, s));
     }
     for (int64_t l = L - 1; l >= 0; --l) {
-        const int acc = l == L - 1 ? 0 : 1;
-        const float* x = b.x[l];
         float* gout = bufs[flip];
         flip ^= 1;
-        BG_TRY(bg_leaky_bwd_f32(gin, b.y[l], 0.01f, b.gz, Np * H, s));
+        float* gz = b.gz_all + l * Np * H;
+        float* gpre = b.gpre_all + l * Np * H;
+        BG_TRY(bg_leaky_bwd_f32(gin, b.y[l], 0.01f, gz, Np * H, s));
         {
-            const float* Bs[4] = {x, b.aggr[l], b.both[l] + Np * H, nullptr};
-            const int64_t ldb[4] = {H, H, H, 0}, Ns[4] = {H, H, H, 0};
-            BG_TRY(tn_multi(H, Np, b.gz, 3, Bs, ldb, Ns, g_upd_w, b.splitk, acc, s));
-        }
-        BG_TRY(bg_colsum_f32(b.gz, H, Np, H, b.colsum, colsum_blocks(Np), g_upd_b, acc, s));
-        {
-            const float* A[4] = {b.gz, nullptr, nullptr, nullptr};
+            const float* A[4] = {gz, nullptr, nullptr, nullptr};
             const int64_t ld[4] = {H, 0, 0, 0}, Ks[4] = {H, 0, 0, 0};
             BG_TRY(bg_gemm_f32(0, 0, Np, 3 * H, 1, A, ld, Ks, w->p_upd_w, 3 * H, b.gcat, 3 * H, nullptr, nullptr, BG_ACT_NONE, 0.f,
                                nullptr, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
         }
-        BG_TRY(bg_rowscale_f32(b.gcat + H, 3 * H, p->prog_has, b.gpre, H, Np, H, s));
+        BG_TRY(bg_rowscale_f32(b.gcat + H, 3 * H, p->prog_has, gpre, H, Np, H, s));
         {
-            const float* Bs[4] = {x, b.both[l], nullptr, nullptr};
-            const int64_t ldb[4] = {H, H, 0, 0}, Ns[4] = {H, H, 0, 0};
-            BG_TRY(tn_multi(H, Np, b.gpre, 2, Bs, ldb, Ns, g_msg_w, b.splitk, acc, s));
-        }
-        BG_TRY(bg_colsum_f32(b.gpre, H, Np, H, b.colsum, colsum_blocks(Np), g_msg_b, acc, s));
-        {
-            const float* A[4] = {b.gpre, nullptr, nullptr, nullptr};
+            const float* A[4] = {gpre, nullptr, nullptr, nullptr};
             const int64_t ld[4] = {H, 0, 0, 0}, Ks[4] = {H, 0, 0, 0};
             BG_TRY(bg_gemm_f32(0, 0, Np, 2 * H, 1, A, ld, Ks, w->p_msg_w, 2 * H, b.gcat2, 2 * H, nullptr, nullptr, BG_ACT_NONE, 0.f,
                                nullptr, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s));
@@ -966,6 +961,34 @@ extern "C" int bg_pstack_backward_f32(const bgGeneratorWeights* w, const bgGener
                                BG_SCALE_NONE, b.t, H, b.gcat2, 2 * H, nullptr, 0, nullptr, nullptr, BG_SCALE_NONE, gout, H, Np,
                                H, s));
         gin = gout;
+    }
+    if (L > 0) {
+        // the block's weights are shared by the layers: their gradients' sum over the layers IS the reduction dimension of one
+        // product over the stacked rows.  `both` holds [neighbour mean; class-slot rows] per layer; its halves are copied
+        // into two stacks by one launch per 4 layers (the other operands are carved as stacks)
+        const int64_t bytes = (int64_t)sizeof(float) * Np * H;
+        for (int64_t l0 = 0; l0 < L; l0 += 4) {
+            void* dst[8]; const void* src[8]; int64_t wd[8], one[8];
+            int n = 0;
+            for (int64_t l = l0; l < L && l < l0 + 4; ++l) {
+                dst[n] = b.top_all + l * Np * H; src[n] = b.both[l]; wd[n] = bytes; one[n++] = 1;
+                dst[n] = b.bot_all + l * Np * H; src[n] = b.both[l] + Np * H; wd[n] = bytes; one[n++] = 1;
+            }
+            BG_TRY(bg_fill_copy_batch(n, dst, wd, src, wd, wd, one, s));
+        }
+        const int64_t Rl = L * Np;
+        {
+            const float* Bs[4] = {b.x[0], b.aggr[0], b.bot_all, nullptr};
+            const int64_t ldb[4] = {H, H, H, 0}, Ns[4] = {H, H, H, 0};
+            BG_TRY(tn_multi(H, Rl, b.gz_all, 3, Bs, ldb, Ns, g_upd_w, b.splitk, 0, s));
+        }
+        BG_TRY(bg_colsum_f32(b.gz_all, H, Rl, H, b.colsum, colsum_blocks(Rl), g_upd_b, 0, s));
+        {
+            const float* Bs[4] = {b.x[0], b.top_all, nullptr, nullptr};
+            const int64_t ldb[4] = {H, H, 0, 0}, Ns[4] = {H, H, 0, 0};
+            BG_TRY(tn_multi(H, Rl, b.gpre_all, 2, Bs, ldb, Ns, g_msg_w, b.splitk, 0, s));
+        }
+        BG_TRY(bg_colsum_f32(b.gpre_all, H, Rl, H, b.colsum, colsum_blocks(Rl), g_msg_b, 0, s));
     }
     {
         const float* Bs[4] = {program_in, nullptr, nullptr, nullptr};

@@ -865,7 +865,12 @@ def test_pstack_host_sequence_and_extents(drv, Np, L):
             R.new("g_upd_w", H * 3 * H * f), R.new("g_upd_b", H * f)]
     rc, bwd = calls_of(drv.bg_pstack_backward_f32, C.byref(w), C.byref(p), R.new("pr_rowptr", (Np + 1) * 4),
                        R.new("pr_col", Ep * 4), R.new("pf_count", Np * f), pin, R.new("g", Np * H * f), work, nws, *outs, None)
-    assert rc == 0 and [k for k, _ in bwd] == [26, 19, 17, 1, 27, 19, 17, 1, 3, 3] * L + [19, 17]
+    # per layer: leaky backward, product, row scale (27 with 7 arguments), product, two operator launches; then the halves
+    # of `both` copied into stacks (27 with one argument = the job count, each job as a copy, kind 20) and ONE weight-gradient
+    # product + column sum per shared weight over the L stacked layers; then the encoder's
+    assert rc == 0 and [k for k, _ in bwd] == [26, 1, 27, 1, 3, 3] * L + [27] + [20] * (2 * L) + [19, 17, 19, 17] + [19, 17]
+    stacked = [a for k, a in bwd if k == 19][:2]
+    assert [a[1] for a in stacked] == [L * Np, L * Np] and [a[12] for a in stacked] == [0, 0]      # rows, no accumulation
     last_x = [a[19] for k, a in fwd if k == 1][-1]
     assert R.check(last_x, 4, "x") == "x_out"
     for kind, a in fwd + bwd:
@@ -908,9 +913,16 @@ def test_pstack_host_sequence_and_extents(drv, Np, L):
             for q in (g, y, out):
                 R.check(q, n * f, tag)
             assert out != g and out != y and n == Np * H
+        elif kind == 27 and len(a) == 1:
+            assert a[0] == min(2 * L, 8)                   # the copy launch's job count (two halves of `both` per layer)
         elif kind == 27:
             x, ldx, sc, out, ldo, n, Hh = a
             R.check(x, ((n - 1) * ldx + Hh) * f, tag); R.check(sc, n * f, tag); R.check(out, ((n - 1) * ldo + Hh) * f, tag)
+        elif kind == 20:
+            dst, dp, src, sp, wd, rows = a
+            assert wd == Np * H * f and rows == 1
+            R.check(dst, wd, tag + " stack"); R.check(src, wd, tag + " half of both")
+            assert dst != src
         else:
             raise AssertionError("unexpected launcher %d" % kind)
 
