@@ -345,10 +345,15 @@ struct CriticBuffers {
     float *dvb, *dvs, *dacc, *dYs, *dX, *dG2, *dgp_b, *dgp_s, *c_b, *c_s, *dhs, *dhb, *dXs, *dXb, *T, *splitk, *colsum;
 };
 
+// workgroups a split-K product aims at: ~2 per CU fill the chip; a long reduction dimension (the products over the
+// stacked calls of the generator update: R = 70 k .. 130 k rows) runs faster with shorter K ranges per workgroup
+// (tools/gemm_tn_bench.py: R = 126,720: 152 us at 512, 129 at 1,024, 111 at the 256-split cap; R = 11,520 is best at 512)
+int64_t tn_target(int64_t R) { return R >= 65536 ? 4096 : (R >= 32768 ? 1024 : 512); }
+
 int32_t tn_splits(int64_t M, int64_t N, int64_t R) {           // ops.gemm_tn_raw's rule (one B segment)
     const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
     const int64_t steps = (R + 31) / 32;
-    int64_t s = (512 + tiles - 1) / tiles;
+    int64_t s = (tn_target(R) + tiles - 1) / tiles;
     if (s > steps) s = steps;
     if (s > 256) s = 256;
     if (s < 1) s = 1;
@@ -564,7 +569,7 @@ int32_t tn_splits_multi(int64_t M, const int64_t* Ns, int n_seg, int64_t R) {   
     int64_t ct = 0;
     for (int i = 0; i < n_seg; ++i) ct += (Ns[i] + 63) / 64;
     const int64_t tiles = ((M + 63) / 64) * ct, steps = (R + 31) / 32;
-    int64_t s = (512 + tiles - 1) / tiles;
+    int64_t s = (tn_target(R) + tiles - 1) / tiles;
     if (s > steps) s = steps;
     if (s > 256) s = 256;
     return (int32_t)(s < 1 ? 1 : s);

@@ -507,7 +507,8 @@ def gemm_tn_raw(A: torch.Tensor, B, out: Optional[torch.Tensor] = None, accumula
         return out
     tiles = ((M + 63) // 64) * sum((n + 63) // 64 for n in Ns)
     steps = (R + 31) // 32
-    splits = max(1, min(steps, (512 + tiles - 1) // tiles, 256))
+    target = 4096 if R >= 65536 else (1024 if R >= 32768 else 512)       # csrc/driver.hip tn_target: long reductions split finer
+    splits = max(1, min(steps, (target + tiles - 1) // tiles, 256))
     partial = torch.empty(splits, M, N, dtype=torch.float32, device=A.device)
     pb = _PtrArr4(*([b.data_ptr() for b in Bs] + [None] * (4 - len(Bs))))
     lb = _I64Arr4(*([_ld(b) for b in Bs] + [0] * (4 - len(Bs))))

@@ -9,7 +9,10 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 shapes = [("critic label rows  M=104 N=256 R=46080", 104, [256], 46080), ("critic static rows M=416 N=256 R=11520", 416, [256], 11520),
           ("block weight       M=128 N=260 R=11520", 128, [128, 128, 4], 11520), ("story weight       M=128 N=256 R=80", 128, [128, 128], 80),
-          ("attention weight   M=132 N=128 R=11520", 132, [128], 11520)]
+          ("attention weight   M=132 N=128 R=11520", 132, [128], 11520),
+          # the generator update's products over the stacked calls (11 block calls, 6 attention calls)
+          ("stacked block weight     M=128 N=260 R=126720", 128, [128, 128, 4], 126720),
+          ("stacked attention weight M=132 N=128 R=69120", 132, [128], 69120)]
 for name, M, Ns, R in shapes:
     A = torch.rand(R, M, device=dev) - 0.5
     Bs = [torch.rand(R, n, device=dev) - 0.5 for n in Ns]
@@ -18,7 +21,7 @@ for name, M, Ns, R in shapes:
     tiles = ((M + 63) // 64) * sum((n + 63) // 64 for n in Ns)
     steps = (R + 31) // 32
     res = []
-    for target in (128, 256, 512, 1024):
+    for target in (512, 1024, 2048, 4096):
         splits = max(1, min(steps, (target + tiles - 1) // tiles, 256))
         partial = torch.empty(splits, M, N, device=dev)
         pb = ops._PtrArr4(*([b.data_ptr() for b in Bs] + [None] * (4 - len(Bs))))
