@@ -54,6 +54,7 @@ SIGNATURES = {
     "bg_segmax_static_f32": [_p, _i64, _p, _p, _p, _i32, _i64, _p, _i64, _p, _i64, _i64, _p],
     "bg_gather_arg_f32": [_p, _i64, _p, _p, _i64, _i64, _i64, _p],
     "bg_scatter_arg_f32": [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "bg_segsum_acc_f32": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "bg_segmax_batch_f32": [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _p],
     "bg_scatter_arg_batch_f32": [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "bg_sddmm_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p],

@@ -754,17 +754,23 @@ extern "C" int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGener
                                              last ? g_mask_hard : nullptr, -1.0f, g.gg, H, g.d_att, G_al + H, H + 4, Nv, H, s));
             if (!last) {                       // (the last call's gg is zero: nothing reaches x through its gather)
                 float* dst = have_np ? g.tmpNp : g.gx_acc;
-                if (bp->cp_one_launch)
-                    BG_TRY(bg_segreduce_sum_f32(g.gg, H, bp->cp_rowptr, bp->cp_col, soft, bp->cp_perm, nullptr, BG_SCALE_NONE,
-                                                nullptr, 0, 0, nullptr, dst, H, Np, H, s));
-                else
-                    BG_TRY(bg_spmm_f32(g.gg, H, bp->cp_rowptr, bp->cp_col, soft, bp->cp_perm, nullptr, BG_SCALE_NONE, nullptr,
-                                       BG_SCALE_NONE, dst, H, Np, H, s));
-                if (have_np) BG_TRY(bg_add_f32(g.gx_acc, g.tmpNp, g.gx_acc, Np * H, s));
+                if (bp->cp_one_launch && have_np) {      // sum and accumulation in one launch (same bits as sum, then add)
+                    BG_TRY(bg_segsum_acc_f32(g.gg, H, bp->cp_rowptr, bp->cp_col, soft, bp->cp_perm, g.gx_acc, H, Np, H, s));
+                } else {
+                    if (bp->cp_one_launch)
+                        BG_TRY(bg_segreduce_sum_f32(g.gg, H, bp->cp_rowptr, bp->cp_col, soft, bp->cp_perm, nullptr, BG_SCALE_NONE,
+                                                    nullptr, 0, 0, nullptr, dst, H, Np, H, s));
+                    else
+                        BG_TRY(bg_spmm_f32(g.gg, H, bp->cp_rowptr, bp->cp_col, soft, bp->cp_perm, nullptr, BG_SCALE_NONE, nullptr,
+                                           BG_SCALE_NONE, dst, H, Np, H, s));
+                    if (have_np) BG_TRY(bg_add_f32(g.gx_acc, g.tmpNp, g.gx_acc, Np * H, s));
+                }
             }
             BG_TRY(bg_cross_logits_bwd_f32(g.a[c], H, g.nnp, H, w->theta, p->cx_rowptr, p->cx_col, g.d_att, g.dpre, G_al,
                                            H + 4, dth_p, nb, Nv, H, s));
-            {
+            if (bp->cp_one_launch && have_att) {
+                BG_TRY(bg_segsum_acc_f32(g.dpre, H, bp->cp_rowptr, bp->cp_perm, nullptr, nullptr, g.gb_acc, H, Np, H, s));
+            } else {
                 float* dst = have_att ? g.tmpNp : g.gb_acc;
                 if (bp->cp_one_launch)
                     BG_TRY(bg_segreduce_sum_f32(g.dpre, H, bp->cp_rowptr, bp->cp_perm, nullptr, nullptr, nullptr, BG_SCALE_NONE,

@@ -264,6 +264,7 @@ struct ChunkArgs {
     float* out; int64_t ldo; int32_t* arg; const float* row_scale; int row_mode;
     // direct mode, blockIdx.y = b: the same reduction of x + b * x_step into out + b * out_step (arg + b * arg_step)
     int64_t x_step, out_step, arg_step;
+    int accumulate;      // direct-mode sum: out += the segment's (scaled) sum, formed first and then added
 };
 
 // binary search: the row r with chunk_ptr[r] <= c < chunk_ptr[r+1]
@@ -389,6 +390,7 @@ __global__ __launch_bounds__(T) void k_chunk_reduce(ChunkArgs a, int lpr, int ho
                 acc.x = apply_scale(acc.x, sc, a.row_mode); acc.y = apply_scale(acc.y, sc, a.row_mode);
                 acc.z = apply_scale(acc.z, sc, a.row_mode); acc.w = apply_scale(acc.w, sc, a.row_mode);
             }
+            if (!IS_MAX && a.accumulate) acc = bg_add4(bg_ld4(a.out + row * a.ldo + hoff + 4 * sub), acc);
             bg_st4(a.out + row * a.ldo + hoff + 4 * sub, acc);
         } else {
             bg_st4(a.partial + (int64_t)c * a.H + hoff + 4 * sub, acc);
@@ -1147,6 +1149,18 @@ int bg_segreduce_sum_f32(const float* x, int64_t ldx, const int32_t* rowptr, con
     SpmmArgs p{partial, H, chunk_ptr, nullptr, nullptr, nullptr, row_scale, row_mode, nullptr, 0, out, ldo, n_rows, 0,
                nullptr, 0, nullptr, 0};
     return spmm_dispatch(p, H, s);
+}
+
+// out += the segments' sums (bg_segreduce_sum_f32's one-launch form, no row scale): a segment's sum is formed in the
+// same order as there and then added to what out holds -- the bits of that call followed by an elementwise add
+int bg_segsum_acc_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* edge_w,
+                      const int32_t* eperm, float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream) {
+    if (n_rows < 0 || H < 0) return BG_ERR_ARG;
+    if (n_rows == 0 || H == 0) return BG_OK;
+    if (!x || !rowptr || !out || ldx < H || ldo < H || (eperm && !edge_w)) return BG_ERR_ARG;
+    ChunkArgs a{x, ldx, rowptr, col, edge_w, eperm, nullptr, 0, n_rows, nullptr, nullptr, (int)H,
+                out, ldo, nullptr, nullptr, 0, 0, 0, 0, 1};
+    return launch_chunk_reduce<false>(a, n_rows, (hipStream_t)stream);
 }
 
 int bg_segmax_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,

@@ -201,6 +201,18 @@ def segmax_raw(c: Csr, x: torch.Tensor):
     return out, arg
 
 
+def segsum_acc_raw(c: Csr, x: torch.Tensor, out: torch.Tensor, edge_w: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out += the segments' (edge-weighted) sums of x's rows, one launch (bg_segsum_acc_f32: a workgroup per segment)."""
+    lib = _lib.load()
+    x2 = _f32c(x)
+    H = x2.shape[1]
+    if tuple(out.shape) != (c.n_rows, H) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise _lib.BganError("segsum_acc: `out` must be an fp32 [n_rows, H] matrix with contiguous rows")
+    check(lib.bg_segsum_acc_f32(ptr(x2), _ld(x2), ptr(c.rowptr), ptr(c.col), ptr(edge_w), ptr(c.perm) if edge_w is not None else None,
+                                ptr(out), out.stride(0), c.n_rows, H, stream()), "bg_segsum_acc_f32")
+    return out
+
+
 def segmax_batch_raw(c: Csr, x: torch.Tensor):
     """Segment max + arg of ``x`` [n_batch, n_cols, H] over the same segments for every batch, one launch
     (bg_segmax_batch_f32: the one-launch form, a workgroup per segment and batch)."""

@@ -235,6 +235,14 @@ int bg_gather_story_f32(const float* x, int64_t ldx, const int32_t* rowptr, cons
                         const float* W, int64_t ldw, int64_t Hout, float* pq, int64_t ldq, int64_t n_story,
                         int64_t H, bgStream stream);
 
+/* out[s,:] += sum_{k in seg s} w_k x[c_k,:]: bg_segreduce_sum_f32's one-launch form (no row scale) ADDED to what out
+ * holds -- each segment's sum is formed in that call's order and then added, so the result equals that call followed
+ * by an elementwise addition, in one launch.  Needs the 16-byte path (BG_ERR_ALIGN otherwise).
+ * replaces: the accumulation of the program features' gradient over the Attention calls of one g_loss.backward()
+ * (autograd's add of the gradients arriving at a tensor used several times, Model/models.py:185-203).           */
+int bg_segsum_acc_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* edge_w,
+                      const int32_t* eperm, float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream);
+
 /* Segment max with arg: out[s,h] = max_{k in seg s} x[c_k,h], arg[s,h] = c_k of the FIRST maximum
  * (slot order); an empty segment gives 0 and arg = -1.  Two phases as above;
  * partial_val / partial_arg: [n_chunks_ub, H]; chunk_ptr == NULL: one launch, a workgroup per row.

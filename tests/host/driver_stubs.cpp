@@ -246,6 +246,12 @@ int bg_segreduce_sum_f32(const float* x, int64_t ldx, const int32_t* rowptr, con
     rec(24, a, sizeof(a) / 8);
     return 0;
 }
+int bg_segsum_acc_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* edge_w,
+                      const int32_t* eperm, float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream) {
+    int64_t a[] = {P(x), ldx, P(rowptr), P(col), P(edge_w), P(eperm), P(out), ldo, n_rows, H};
+    rec(41, a, sizeof(a) / 8);
+    return 0;
+}
 int bg_leaky_bwd_f32(const float* g, const float* y, float, float* out, int64_t n, bgStream) {
     int64_t a[] = {P(g), P(y), P(out), n};
     rec(26, a, sizeof(a) / 8);

@@ -685,6 +685,15 @@ def _check_generic(calls, R, z):
             if rm:
                 R.check(rsc, n_rows * f, tag + " row_scale")
             assert x != out
+        elif kind == 41:                                    # segment sum added to an accumulator (program side of the cross edges)
+            x, ldx, rp, col, ew, ep, out, ldo, n_rows, Hh = a
+            assert R.check(rp, (n_rows + 1) * 4, tag + " rowptr") == "cp_rowptr" and n_rows == Np
+            R.check(x, ((Ec - 1) * ldx + Hh) * f, tag + " x")
+            R.check(out, ((n_rows - 1) * ldo + Hh) * f, tag + " accumulator")
+            if ew:
+                R.check(ew, Ec * f, tag + " edge_w")
+                R.check(ep, Ec * 4, tag + " eperm")
+            assert x != out
         elif kind == 3:
             x, ldx, rp, col, rsc, rm, csc, cm, a1, ld1, a2, ld2, ga, ldg, grow, gs, gm_, out, ldo, n_rows, Hh = a
             name = R.check(rp, (n_rows + 1) * 4, tag + " rowptr")
@@ -791,8 +800,12 @@ def test_gstack_host_sequence_and_extents(drv, Np, Nv, S, Ec, one):
     red = 24 if one else 2
     # (no weight-gradient product inside the loop: the shared weights' gradients are ONE product each over the stacked calls)
     att_last = [22, 23, red, 1]
-    att_first_np = [22, red, 23, red, 18, 1]                              # first call that reaches x: assigns g_x's sum
-    att = [22, red, 18, 23, red, 18, 1]
+    if one:      # 41: a segment sum ADDED to the accumulator in one launch (bg_segsum_acc_f32) instead of sum (24) + add (18)
+        att_first_np = [22, 24, 23, 41, 1]                                # first call that reaches x: assigns g_x's sum
+        att = [22, 41, 23, 41, 1]
+    else:
+        att_first_np = [22, red, 23, red, 18, 1]
+        att = [22, red, 18, 23, red, 18, 1]
     blk = [21, 2, 1, 1, 3, 3]
     seq = [25] + att_last
     n_att_seen = 1

@@ -1073,6 +1073,32 @@ def test_scatter_arg_row_lookup_equals_fill_and_scatter(cuda):
         assert float(want.abs().sum()) > 0
 
 
+def test_segment_sum_added_to_an_accumulator_in_one_launch(cuda):
+    """bg_segsum_acc_f32 (the program features' gradient accumulated over the Attention calls of the generator backward):
+    the sums themselves against a float64 index_add (weighted by edge id and plain), and accumulator + sums against the same
+    launch into zeros followed by an elementwise add -- identical bits.  Cross edges grouped by program node (long ragged
+    rows, more than 256 segments' worth of work per launch) and the story plan."""
+    from building_gan_amd import ops
+    import copy
+    g_, p = _plan(copy.deepcopy(_batch("small", 13, True)), cuda)
+    gen = torch.Generator().manual_seed(31)
+    H = 128
+    for csr, weighted in ((p.cross_p, True), (p.cross_p, False), (p.story_seg, False)):
+        x = (torch.rand(csr.n_cols, H, generator=gen) * 2 - 1).to(cuda)
+        w = torch.rand(csr.nnz, generator=gen).to(cuda) if weighted else None
+        sums = ops.segsum_acc_raw(csr, x, torch.zeros(csr.n_rows, H, device=cuda), w)
+        rp, col = csr.rowptr.cpu().long(), csr.col.cpu().long()
+        seg = torch.repeat_interleave(torch.arange(csr.n_rows), rp[1:] - rp[:-1])
+        rows = x.cpu().double()[col]
+        if weighted:
+            rows = rows * w.cpu().double()[csr.perm.cpu().long()].view(-1, 1)
+        want = torch.zeros(csr.n_rows, H, dtype=torch.float64).index_add_(0, seg, rows)
+        torch.testing.assert_close(sums.cpu().double(), want, rtol=1e-5, atol=1e-5)
+        acc0 = (torch.rand(csr.n_rows, H, generator=gen) * 2 - 1).to(cuda)
+        got = ops.segsum_acc_raw(csr, x, acc0.clone(), w)
+        assert torch.equal(got, acc0 + sums)
+
+
 def test_pooling_of_several_label_sets_in_one_launch(cuda):
     """bg_segmax_batch_f32 / bg_scatter_arg_batch_f32 (the critic's real, fake and sample rows pooled by one launch per
     level, their backward scattered by one) against one call per set: values, arg-max ids and scattered rows identical,
