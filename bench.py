@@ -397,6 +397,7 @@ class HipWorkload:
         self.fixed.to(dev)
         torch.manual_seed(0)
         self.trainer = Trainer(dev)
+        self.trainer.grad_exchange = getattr(args, "grad_exchange", "all_reduce")
         self.trainer.broadcast_parameters(0)
         torch.manual_seed(1000 + rank)
         build_plan(self.fixed)                    # first build also loads the library and warms the allocator
@@ -492,7 +493,9 @@ class HipWorkload:
                 "Nv_min": min(s["Nv"] for s in self.sizes), "Nv_max": max(s["Nv"] for s in self.sizes),
                 "hidden": 128, "voxel_layer": 12, "program_layer": 4, "n_critic_g": 5,
                 "parallelism": "dp%d" % self.world,
-                "launch": "eager kernels + eager RCCL all-reduce of the flat gradient buffers",
+                "launch": "eager kernels + eager RCCL " + ("all-gather + local sum in rank order (--grad-exchange gather_sum)"
+                                                           if self.trainer.grad_exchange == "gather_sum" else "all-reduce")
+                          + " of the flat gradient buffers",
                 "collectives": ("issued on a 1-rank RCCL group (--force-dist)" if self.force_dist else
                                 ("RCCL, %d ranks" % self.world if self.world > 1 else "none (one rank)"))}
 
@@ -528,6 +531,9 @@ def main(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: create a 1-rank process group (RCCL) and issue every collective of the "
                          "data-parallel path anyway (train.FORCE_COLLECTIVES); the line says so")
+    ap.add_argument("--grad-exchange", choices=("all_reduce", "gather_sum"), default="all_reduce",
+                    help="how the ranks' flat gradient buffers are summed: RCCL's all-reduce (default), or one all-gather and "
+                         "a local sum in rank order (FlatAdam.all_reduce: the one-shot form for these ~1 MB messages)")
     ap.add_argument("--no-replay", action="store_true", help="skip the fixed-batch hipGraph replay figure")
     ap.add_argument("--workload", default=None, metavar="MODULE:CLASS",
                     help="replace the HIP workload by MODULE:CLASS(args, rank, world) with the same methods "

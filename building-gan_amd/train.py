@@ -116,11 +116,26 @@ class FlatAdam:
         for p, view in zip(self.params, self._grad_views()):
             p.grad = view
 
-    def all_reduce(self, group=None):
+    def all_reduce(self, group=None, exchange: str = "all_reduce"):
+        """Sum the flat gradient buffer over the ranks.  ``exchange``: "all_reduce" = the backend's all-reduce (RCCL's
+        default algorithm choice); "gather_sum" = the one-shot form SURVEY section 5 names for these latency-bound 1 MB
+        messages: ONE all-gather (every rank sends its buffer to every peer over its own xGMI link at once), then a
+        local sum over the gathered copies in rank order -- one communication step instead of a ring's 2 (N - 1), and a
+        summation order that is the same on every rank and in every run."""
         if _collective(group):
             if self.grad.is_cuda and dist.get_backend(group) == "gloo":
                 torch.cuda.current_stream().synchronize()      # gloo reads the buffer from the host side
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+            if exchange == "gather_sum":
+                w = _world(group)
+                buf = self.__dict__.get("_gathered")
+                if buf is None or buf.shape[0] != w:
+                    buf = self._gathered = torch.empty(w, self.grad.numel(), dtype=self.grad.dtype, device=self.grad.device)
+                dist.all_gather_into_tensor(buf.view(-1), self.grad, group=group)
+                torch.sum(buf, dim=0, out=self.grad)           # rank order 0 .. N-1 on every rank
+            elif exchange == "all_reduce":
+                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+            else:
+                raise ValueError("exchange must be 'all_reduce' or 'gather_sum'")
 
     def _need_device(self, what):
         if self.t is None:
@@ -248,6 +263,7 @@ class Trainer:
         # would lose more than the fp32 tolerance (models.DiscriminatorVoxel.guard_collapse; one host read)
         self.collapse_check_every = collapse_check_every
         self.manual_critic = True            # the fused critic update without an autograd pass (critic_objective(manual=True))
+        self.grad_exchange = "all_reduce"    # or "gather_sum": see FlatAdam.all_reduce
         self.group = group
         self._graphs = None
         self._captured_batch = None
@@ -519,11 +535,11 @@ class Trainer:
             self.discriminator.guard_collapse(batch, reduce_max=self._reduce_max())
         gen, stats = self._phase_d(batch, counts, do_d, program_z, voxel_z, noise, u, g_update=i % self.n_critic_g == 0)
         if do_d:
-            self.opt_d.all_reduce(self.group)
+            self.opt_d.all_reduce(self.group, self.grad_exchange)
             self.opt_d.step()
         if i % self.n_critic_g == 0:
             stats.update(self._phase_g(batch, counts, gen))
-            self.opt_g.all_reduce(self.group)
+            self.opt_g.all_reduce(self.group, self.grad_exchange)
             self.opt_g.step()
             self.refresh_derived()
         else:
@@ -667,13 +683,13 @@ class Trainer:
         if i % self.n_critic_g == 0:
             gA, gB, gC, stats = self._graphs["with_g"]
             gA.replay()
-            self.opt_d.all_reduce(self.group)
+            self.opt_d.all_reduce(self.group, self.grad_exchange)
             gB.replay()
-            self.opt_g.all_reduce(self.group)
+            self.opt_g.all_reduce(self.group, self.grad_exchange)
             gC.replay()
         else:
             gA, gB, stats = self._graphs["no_g"]
             gA.replay()
-            self.opt_d.all_reduce(self.group)
+            self.opt_d.all_reduce(self.group, self.grad_exchange)
             gB.replay()
         return stats

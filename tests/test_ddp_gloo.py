@@ -87,8 +87,14 @@ def _worker(rank, world, port, ret):
         counts = global_counts(mine)
         assert counts == direct and "_bg_counts" not in mine.__dict__
         gen, stats = tr._phase_d(mine, counts, True, *a)
+        local = tr.opt_d.grad.clone()
         tr.opt_d.all_reduce()
         d_grad = tr.opt_d.grad.clone()
+        # the one-shot exchange (all-gather, then a local sum in rank order) gives the same sums
+        tr.opt_d.grad.copy_(local)
+        tr.opt_d.all_reduce(exchange="gather_sum")
+        assert torch.equal(tr.opt_d.grad, d_grad) and tr.opt_d._gathered.shape == (world, local.numel())
+        assert torch.equal(tr.opt_d._gathered[rank], local)
         tr._phase_g(mine, counts, gen)
         tr.opt_g.all_reduce()
         g_grad = tr.opt_g.grad.clone()

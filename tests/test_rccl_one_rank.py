@@ -75,11 +75,12 @@ def _assert_same(a, b, what):
     assert a[7:] == b[7:], (what, "step counts", a[7:], b[7:])
 
 
-def _eager_run(cuda, group, force, batches):
+def _eager_run(cuda, group, force, batches, exchange="all_reduce"):
     from building_gan_amd import train
     train.FORCE_COLLECTIVES = force
     torch.manual_seed(0)
     tr = train.Trainer(cuda, group=group, collapse_check_every=3)
+    tr.grad_exchange = exchange
     tr.broadcast_parameters(0)
     torch.manual_seed(77)
     snaps = []
@@ -111,6 +112,13 @@ def test_eager_iterations_with_rccl_collectives_equal_iterations_without(cuda, r
     assert calls["broadcast"] == 2 and calls["all_reduce"] == 6 + 2 + 6 + 1 + 2, calls
     for i, (a, b) in enumerate(zip(plain, forced)):
         _assert_same(a, b, "eager iteration %d" % i)
+    # the one-shot gradient exchange (RCCL all-gather + local sum in rank order) on the same path: the 8 gradient
+    # all-reduces become all-gathers, everything else as before, same bits
+    n0 = dict(calls)
+    gathered = _eager_run(cuda, group, True, batches, exchange="gather_sum")
+    assert calls["all_reduce"] - n0["all_reduce"] == 6 + 1 + 2, (n0, calls)
+    for i, (a, b) in enumerate(zip(plain, gathered)):
+        _assert_same(a, b, "eager iteration %d, gather_sum" % i)
 
 
 def _graphed_run(cuda, group, force, batch):
