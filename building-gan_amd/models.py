@@ -26,17 +26,11 @@ from .ops import ACT_LEAKY, ACT_NONE, SpMM, SpMMW, linear
 from .plan import LinOp, build_plan, iota_i32
 
 NUMBER_OF_CLASS = 6  # /root/reference/Data/GraphConstructor.py:9
-COMPOSE_BLOCKS = True  # collapse messageMLP into updateMLP where legal (VoxelBlock.compose)
 COMPOSE_STACK = True   # run the discriminator's 12 composed layers as one autograd node (ops.AffineStack)
-FUSE_STORY_TERM = True  # generator block: story mean + its projections in one launch when no graph is built
-FUSE_PROGRAM_BLOCK = True   # ProgramBlock: one launch for both aggregations, residual in the epilogue (no-grad passes)
 FUSE_GATHER_STORY_MAX_ROWS = 1 << 16   # gather-mean + story projection share a launch up to this many voxels
 FUSE_ATTENTION_NODE = True   # Attention call with a graph: one autograd node with a hand-written backward
 FUSE_GBLOCK = True      # generator block with a graph: one autograd node with a hand-written backward
 SHARE_WEIGHT_GRADS = True   # the calls of one module in a forward sum their weight gradients in the producing launches
-FUSE_OUTPUT = True     # construct_output as one launch when no autograd graph is being built
-FUSE_ATTENTION = True  # one launch per Attention call when no autograd graph is being built
-FUSE_POS_TERM = True      # generator: position columns x weight + bias once per forward, the 12 products start from it
 FUSE_COEF_INPUTS = True   # collapsed discriminator: the recurrence's parameter rows by one launch (ops.PolyCoefD)
 FUSE_GENERATOR_FORWARD = True   # graph-free Generator.forward as ONE host call (bg_generator_forward_f32)
 FUSE_PSTACK = True        # generator update: ProgramGNN as ONE autograd node, one host call each way (ops.ProgramStack)
@@ -174,7 +168,7 @@ class ProgramGNN(nn.Module):
 
     def forward(self, cf, slf, tr, z, plan):
         program_in = torch.cat([cf, slf.view(-1, 1), z], dim=-1)
-        if (FUSE_PSTACK and torch.is_grad_enabled() and program_in.is_cuda and FUSE_PROGRAM_BLOCK and "prog_pair" in plan.ops
+        if (FUSE_PSTACK and torch.is_grad_enabled() and program_in.is_cuda and "prog_pair" in plan.ops
                 and "story_building_mean" in plan.ops and len(self.enc) == 1 and program_in.dtype == torch.float32
                 and self.enc[0].weight.shape[0] % 4 == 0 and plan.Np > 0 and plan.Ep > 0):
             # a graph is being built (generator update): the whole program GNN as one autograd node
@@ -183,7 +177,7 @@ class ProgramGNN(nn.Module):
             return ops.ProgramStack.apply(self.enc[0].weight, self.enc[0].bias, blk.messageMLP[0].weight, blk.messageMLP[0].bias,
                                           blk.updateMLP[0].weight, blk.updateMLP[0].bias, program_in, plan, self.layer_num)
         x = run_mlp(self.enc, program_in)
-        fused = FUSE_PROGRAM_BLOCK and not torch.is_grad_enabled() and "prog_pair" in plan.ops
+        fused = not torch.is_grad_enabled() and "prog_pair" in plan.ops
         for _ in range(self.layer_num):
             x = self.block.forward_residual(x, plan) if fused else x + self.block(x, plan, tr)
         return x
@@ -228,7 +222,7 @@ class Attention(nn.Module):
         exp_mask, exp_att = (None, None) if noise is None else noise
         b, Wcat, bcat = shared if shared is not None else self.shared_terms(program_graph_feature)
         H = self.NN_v.weight.shape[0]
-        if (Wcat is not None and FUSE_ATTENTION and not torch.is_grad_enabled() and 0 < plan.cross_v.max_len <= 64
+        if (Wcat is not None and not torch.is_grad_enabled() and 0 < plan.cross_v.max_len <= 64
                 and H % 64 == 0):
             # nothing will be differentiated: NN_v as one [Nv,H] x [H,H] product (no ragged 4-column tile), then
             # ONE launch for the rest of the call, the two-row composed mask decoder included
@@ -261,7 +255,7 @@ class Attention(nn.Module):
             a = linear(voxel_feature, self.NN_v.weight, self.NN_v.bias)
         if exp_mask is None:
             exp_mask = torch.empty(logits.shape, dtype=logits.dtype, device=logits.device).exponential_()
-        if FUSE_ATTENTION and not torch.is_grad_enabled() and 0 < plan.cross_v.max_len <= 64:
+        if not torch.is_grad_enabled() and 0 < plan.cross_v.max_len <= 64:
             # nothing will be differentiated: the rest of the call is one launch
             if exp_att is None:
                 exp_att = torch.empty(plan.Ec, dtype=logits.dtype, device=logits.device).exponential_()
@@ -283,7 +277,7 @@ class Attention(nn.Module):
 
     @staticmethod
     def construct_output(program_class_feature, num_voxel, att, mask, plan, cross_edge_program_index):
-        if (FUSE_OUTPUT and not torch.is_grad_enabled() and program_class_feature.shape[1] <= 8
+        if (not torch.is_grad_enabled() and program_class_feature.shape[1] <= 8
                 and plan.ops["flags"]["cross_by_voxel"][1] == 0):
             # nothing will be differentiated: one launch (slots are in edge order on voxel-major cross edges)
             return ops.construct_output_raw(mask["hard"], att["hard"], att["soft"], plan, program_class_feature)
@@ -332,7 +326,7 @@ class VoxelBlock(nn.Module):
         ``posb`` = ops.block_pos_term(pdm4, Wc, bc) when the caller evaluated it once for all calls of a forward."""
         Wc, bc, Wsb = composed
         H = voxel_feature.shape[1]
-        if (self.if_agg_story_in_update and FUSE_STORY_TERM and not torch.is_grad_enabled()
+        if (self.if_agg_story_in_update and not torch.is_grad_enabled()
                 and "story_building_mean" in plan.ops and H % 4 == 0 and H <= 256):
             # graph-free pass: the gather-mean, the story mean and both of its projections in one launch, then
             # term[s] = P[s] + mean over the stories of s's graph of Q  (P, Q = the two halves)
@@ -399,8 +393,8 @@ class VoxelGNN_G(nn.Module):
         and plan pieces the one-call backward can run (bg_gstack_backward_f32)."""
         H = x.shape[1]
         o = plan.ops
-        if not (FUSE_GSTACK and torch.is_grad_enabled() and x.is_cuda and COMPOSE_BLOCKS and FUSE_GBLOCK and FUSE_ATTENTION_NODE
-                and FUSE_POS_TERM and SHARE_WEIGHT_GRADS and PDM4_PAD == 1.0 and self.noise_dim == 0 and len(self.enc) == 1
+        if not (FUSE_GSTACK and torch.is_grad_enabled() and x.is_cuda and FUSE_GBLOCK and FUSE_ATTENTION_NODE
+                and SHARE_WEIGHT_GRADS and PDM4_PAD == 1.0 and self.noise_dim == 0 and len(self.enc) == 1
                 and self.block.if_agg_story_in_update and plan.vox_all_has and self.layer_num >= 1
                 and H % 64 == 0 and H <= 256 and 0 < plan.Nv <= FUSE_GATHER_STORY_MAX_ROWS and plan.Np > 0
                 and 0 < plan.cross_v.max_len <= 64 and "story_building_mean" in o and "prog_pair" in o
@@ -445,10 +439,10 @@ class VoxelGNN_G(nn.Module):
         _, _, v = self.attention(x, v, plan, next(draws), shared, (sg, True) if sg is not None else None)
         out_mask = out_att = None
         composed = None
-        if COMPOSE_BLOCKS and plan.vox_all_has:
+        if plan.vox_all_has:
             composed = tuple(derived[:3]) if derived is not None else self.block.compose()
         posb = None
-        if (composed is not None and FUSE_POS_TERM and self.block.if_agg_story_in_update and plan.Nv <= FUSE_GATHER_STORY_MAX_ROWS
+        if (composed is not None and self.block.if_agg_story_in_update and plan.Nv <= FUSE_GATHER_STORY_MAX_ROWS
                 and "story_building_mean" in plan.ops and v.shape[1] % 4 == 0 and v.shape[1] <= 256):
             # the position columns and the bias enter every one of the 12 calls alike (same module): once
             posb = ops.block_pos_term(pdm4, composed[0], composed[1])
@@ -667,12 +661,12 @@ class VoxelGNN_D(nn.Module):
     def forward(self, v, l, plan):
         pos, v = extract_pos(v)
         pdm4 = _pos_terms(plan, pos)
-        if COLLAPSE_D and self.collapse_ok and COMPOSE_BLOCKS and plan.vox_all_has and self.layer_num > 0:
+        if COLLAPSE_D and self.collapse_ok and plan.vox_all_has and self.layer_num > 0:
             return self.forward_collapsed(v, l, plan, pdm4)
         v = run_mlp(self.feature_enc, v)
         v = v + ops.spmm_raw(_level_op(plan, self.pe.shape[0]), self.pe)
         v = torch.cat([v, run_mlp(self.label_enc, l)], dim=-1)
-        composed = self.block.compose() if (COMPOSE_BLOCKS and plan.vox_all_has) else None
+        composed = self.block.compose() if plan.vox_all_has else None
         if composed is not None and COMPOSE_STACK and self.layer_num > 0:
             return ops.AffineStack.apply(v, composed[0], composed[1], pdm4, plan.vox_mean, self.layer_num)
         for _ in range(self.layer_num):
@@ -720,8 +714,7 @@ class Generator(nn.Module):
         gnn, att, pg = self.voxelGNN, self.voxelGNN.attention, self.programGNN
         H, L = self.hidden_dim, gnn.layer_num
         ops_ = plan.ops
-        if not (COMPOSE_BLOCKS and FUSE_STORY_TERM and FUSE_PROGRAM_BLOCK and FUSE_OUTPUT and FUSE_ATTENTION and FUSE_POS_TERM
-                and plan.vox_all_has and 0 < plan.cross_v.max_len <= 64 and H % 64 == 0 and H <= 256 and L >= 1
+        if not (plan.vox_all_has and 0 < plan.cross_v.max_len <= 64 and H % 64 == 0 and H <= 256 and L >= 1
                 and 0 < plan.Nv <= FUSE_GATHER_STORY_MAX_ROWS and plan.Np > 0 and "story_building_mean" in ops_
                 and "prog_pair" in ops_ and gnn.noise_dim == 0 and gnn.block.if_agg_story_in_update
                 and ops_["flags"]["cross_by_voxel"][1] == 0 and graph.program_class_feature.shape[1] <= 8
@@ -858,7 +851,7 @@ class DiscriminatorVoxel(nn.Module):
         grads[:, 0] / grads[:, 1] are grad_b / grad_s zero-padded to dl columns."""
         plan = build_plan(graph)
         gnn = self.voxelGNN_D
-        if not (COLLAPSE_D and gnn.collapse_ok and COMPOSE_BLOCKS and plan.vox_all_has and gnn.layer_num > 0):
+        if not (COLLAPSE_D and gnn.collapse_ok and plan.vox_all_has and gnn.layer_num > 0):
             return None
         pos, feat = extract_pos(graph.voxel_feature)
         pdm4 = _pos_terms(plan, pos)
@@ -911,7 +904,7 @@ class DiscriminatorVoxel(nn.Module):
         critic_terms."""
         plan = build_plan(graph)
         gnn = self.voxelGNN_D
-        if not (FUSE_CRITIC_HEAD and COLLAPSE_D and gnn.collapse_ok and COMPOSE_BLOCKS and plan.vox_all_has
+        if not (FUSE_CRITIC_HEAD and COLLAPSE_D and gnn.collapse_ok and plan.vox_all_has
                 and gnn.layer_num > 0 and self.piecewise_linear and label_hat is not None):
             return None
         blocks, st, sg = plan.vox_blocks, plan.story_seg, plan.story_graph_seg
@@ -964,7 +957,7 @@ class DiscriminatorVoxel(nn.Module):
         (ops.GLossHead).  None where it does not apply; the caller then calls forward() and forms the sums."""
         plan = build_plan(graph)
         gnn = self.voxelGNN_D
-        if not (FUSE_CRITIC_HEAD and COLLAPSE_D and gnn.collapse_ok and COMPOSE_BLOCKS and plan.vox_all_has
+        if not (FUSE_CRITIC_HEAD and COLLAPSE_D and gnn.collapse_ok and plan.vox_all_has
                 and gnn.layer_num > 0 and self.piecewise_linear and not any(p.requires_grad for p in self.parameters())):
             return None
         blocks, st, sg = plan.vox_blocks, plan.story_seg, plan.story_graph_seg
@@ -1001,7 +994,7 @@ class DiscriminatorVoxel(nn.Module):
         value (NaN counts as +inf), so no rank evaluates the discriminator in another order than its peers."""
         plan = build_plan(graph)
         gnn = self.voxelGNN_D
-        applies = bool(COLLAPSE_D and COMPOSE_BLOCKS and plan.vox_all_has and gnn.layer_num > 0)
+        applies = bool(COLLAPSE_D and plan.vox_all_has and gnn.layer_num > 0)
         if not applies and reduce_max is None:
             return 0.0
         if applies:
@@ -1023,7 +1016,7 @@ class DiscriminatorVoxel(nn.Module):
         table), e.g. on a side stream while the generator runs."""
         plan = build_plan(graph)
         gnn = self.voxelGNN_D
-        if not (COLLAPSE_D and gnn.collapse_ok and COMPOSE_BLOCKS and plan.vox_all_has and gnn.layer_num > 0 and gnn._share_coef):
+        if not (COLLAPSE_D and gnn.collapse_ok and plan.vox_all_has and gnn.layer_num > 0 and gnn._share_coef):
             return
         pos, feat = extract_pos(graph.voxel_feature)
         Zs = gnn._static_powers(plan, feat, _pos_terms(plan, pos))
