@@ -56,7 +56,7 @@ SIGNATURES = {
     "bg_scatter_arg_f32": [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "bg_segsum_acc_f32": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "bg_segmax_batch_f32": [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _p],
-    "bg_scatter_arg_batch_f32": [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p],
+    "bg_scatter_arg_batch_f32": [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _i64, _p],
     "bg_sddmm_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p],
     "bg_cross_logits_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p],
     "bg_cross_logits_bwd_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _p, _i32, _i64, _i64, _p],

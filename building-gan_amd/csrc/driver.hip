@@ -535,14 +535,14 @@ extern "C" int bg_critic_head_backward_f32(const bgCriticHead* hp, float coef, c
     // (g W1 = w2 (x) c, g W2 = W1 c).  D(real), D(fake): building decoder, back through the story level, story decoder.
     BG_TRY(bg_decoder_bwd_f32(2 * B, B, H2, Hd, b.dvb, b.Xb, H2, h.b_b1, b.dgp_b, H2, h.b_w1, H2, h.b_w2, b.gp_b, nullptr, 0,
                               g_b_w1, H2, g_b_b1, g_b_w2, g_b_b2, b.dXb, H2, s));
-    BG_TRY(bg_scatter_arg_batch_f32(b.dXb, H2, B * H2, b.ab, B * H2, h.graph_of_story, b.T, H2, S * H2, B, S, H2, 2, s));
+    BG_TRY(bg_scatter_arg_batch_f32(b.dXb, H2, B * H2, b.ab, B * H2, h.graph_of_story, b.T, H2, S * H2, B, S, H2, 2, nullptr, 0, s));
     BG_TRY(bg_decoder_bwd_f32(2 * S, S, H2, Hd, b.dvs, b.Xs, H2, h.s_b1, b.dgp_s, H2, h.s_w1, H2, h.s_w2, b.gp_s, b.T, H2,
                               g_s_w1, H2, g_s_b1, g_s_w2, g_s_b2, b.dXs, H2, s));          // + what arrived through the buildings
     // to the arg-max voxels (v[0], v[1] are free after the forward's pooling: they take d v), then the coefficient table
-    BG_TRY(bg_scatter_arg_batch_f32(b.dXs, H2, S * H2, b.as, S * H2, h.story_of_voxel, b.v[0], H2, N * H2, S, N, H2, 2, s));
+    // (the same launch leaves d v0 + d v1 in dS: what reaches the label-free rows, which both sets share)
+    BG_TRY(bg_scatter_arg_batch_f32(b.dXs, H2, S * H2, b.as, S * H2, h.story_of_voxel, b.v[0], H2, N * H2, S, N, H2, 2, b.dS, H2, s));
     // label rows: Zp0^T dv0 + Zp1^T dv1 + dX^T G2 as one product over the 4 N stacked rows
     BG_TRY(tn(K1 * dl, H2, 4 * N, b.Zp[0], b.v[0], gWl, b.splitk, 0, s));
-    BG_TRY(bg_add_f32(b.v[0], b.v[1], b.dS, N * H2, s));
     BG_TRY(tn(K1 * ds, H2, N, h.Zs, b.dS, gWs, b.splitk, 0, s));
     return BG_OK;
 }

@@ -519,6 +519,31 @@ __global__ __launch_bounds__(256) void k_scatter_arg_dense4(const float* __restr
     bg_st4(out + (int64_t)r * ldo + h, v);
 }
 
+// the batches of one row by one thread, and their sum (in batch order: (v_0 + v_1) + ..) written beside them
+__global__ __launch_bounds__(256) void k_scatter_arg_dense4_sum(const float* __restrict__ g, int64_t ldg,
+                                                                const int32_t* __restrict__ arg, const int32_t* __restrict__ seg_of,
+                                                                float* __restrict__ out, int64_t ldo, uint32_t n4, uint32_t H4,
+                                                                int64_t g_step, int64_t arg_step, int64_t out_step, int n_batch,
+                                                                float* __restrict__ sum_out, int64_t ld_sum) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n4) return;
+    const uint32_t r = t / H4, h = 4u * (t - r * H4);
+    const int32_t s = seg_of[r];
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < n_batch; ++b) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s >= 0) {
+            const int4 ar = *reinterpret_cast<const int4*>(arg + b * arg_step + (int64_t)s * (4 * H4) + h);
+            const float4 gv = bg_ld4(g + b * g_step + (int64_t)s * ldg + h);
+            v.x = ar.x == (int32_t)r ? gv.x : 0.f; v.y = ar.y == (int32_t)r ? gv.y : 0.f;
+            v.z = ar.z == (int32_t)r ? gv.z : 0.f; v.w = ar.w == (int32_t)r ? gv.w : 0.f;
+        }
+        bg_st4(out + b * out_step + (int64_t)r * ldo + h, v);
+        sum = b == 0 ? v : bg_add4(sum, v);
+    }
+    bg_st4(sum_out + (int64_t)r * ld_sum + h, sum);
+}
+
 // one wave per row; 64/LPR slots in flight, LPR lanes per dot product (float4 per lane per step)
 template <int LPR>
 __global__ __launch_bounds__(256) void k_sddmm(const float* __restrict__ A, int64_t lda,
@@ -1277,16 +1302,27 @@ int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, const in
 }
 
 // n_batch scatters that share the segments (rows' segment ids) in one launch: batch b reads g + b * g_step and
-// arg + b * arg_step and writes out + b * out_step (the critic's pooling backward for D(real) and D(fake))
+// arg + b * arg_step and writes out + b * out_step (the critic's pooling backward for D(real) and D(fake)); sum_out
+// (optional): the elementwise sum of the batches' results, in batch order, written by the same launch
 int bg_scatter_arg_batch_f32(const float* g, int64_t ldg, int64_t g_step, const int32_t* arg, int64_t arg_step,
                              const int32_t* seg_of, float* out, int64_t ldo, int64_t out_step, int64_t n_seg, int64_t n_rows,
-                             int64_t H, int64_t n_batch, bgStream stream) {
+                             int64_t H, int64_t n_batch, float* sum_out, int64_t ld_sum, bgStream stream) {
     if (n_seg <= 0 || H < 0 || n_rows < 0 || n_batch < 1 || n_batch > 65535) return BG_ERR_ARG;
     if (n_rows == 0 || H == 0) return BG_OK;
-    if (!out || !g || !arg || !seg_of || ldo < H) return BG_ERR_ARG;
+    if (!out || !g || !arg || !seg_of || ldo < H || (sum_out && ld_sum < H)) return BG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (H % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && g_step % 4 == 0 && arg_step % 4 == 0 && out_step % 4 == 0 &&
-        bg_aligned16(g) && bg_aligned16(arg) && bg_aligned16(out) && n_rows * (H / 4) < 0x7fffffff) {
+    const bool vec = H % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && g_step % 4 == 0 && arg_step % 4 == 0 && out_step % 4 == 0 &&
+                     bg_aligned16(g) && bg_aligned16(arg) && bg_aligned16(out) && n_rows * (H / 4) < 0x7fffffff;
+    if (sum_out) {          // the batches' sum as well, by the launch that writes them (16-byte path only, <= 8 batches)
+        if (!vec || !bg_aligned16(sum_out) || ld_sum % 4 != 0) return BG_ERR_ALIGN;
+        if (n_batch > 8) return BG_ERR_SHAPE;
+        const uint32_t n4 = (uint32_t)(n_rows * (H / 4));
+        k_scatter_arg_dense4_sum<<<(n4 + 255u) / 256u, 256, 0, s>>>(g, ldg, arg, seg_of, out, ldo, n4, (uint32_t)(H / 4), g_step,
+                                                                   arg_step, out_step, (int)n_batch, sum_out, ld_sum);
+        BG_LAUNCH_CHECK();
+        return BG_OK;
+    }
+    if (vec) {
         const uint32_t n4 = (uint32_t)(n_rows * (H / 4));
         k_scatter_arg_dense4<<<dim3((n4 + 255u) / 256u, (unsigned)n_batch), 256, 0, s>>>(g, ldg, arg, seg_of, out, ldo, n4,
                                                                                         (uint32_t)(H / 4), g_step, arg_step, out_step);

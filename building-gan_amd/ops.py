@@ -227,8 +227,10 @@ def segmax_batch_raw(c: Csr, x: torch.Tensor):
     return out, arg
 
 
-def scatter_arg_batch_raw(g: torch.Tensor, arg: torch.Tensor, n_rows: int, seg_of: torch.Tensor) -> torch.Tensor:
-    """scatter_arg_raw's row-lookup form for g, arg [n_batch, n_seg, H] sharing ``seg_of``: one launch."""
+def scatter_arg_batch_raw(g: torch.Tensor, arg: torch.Tensor, n_rows: int, seg_of: torch.Tensor,
+                          sum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """scatter_arg_raw's row-lookup form for g, arg [n_batch, n_seg, H] sharing ``seg_of``: one launch; ``sum_out``
+    [n_rows, H] also receives the batches' sum."""
     lib = _lib.load()
     if g.dim() != 3 or g.shape != arg.shape or not g.is_contiguous() or not arg.is_contiguous() or g.dtype != torch.float32:
         raise _lib.BganError("scatter_arg_batch: g and arg must be contiguous [n_batch, n_seg, H]")
@@ -236,8 +238,10 @@ def scatter_arg_batch_raw(g: torch.Tensor, arg: torch.Tensor, n_rows: int, seg_o
         raise _lib.BganError("scatter_arg_batch: seg_of must be int32 [n_rows]")
     nb, S, H = g.shape
     out = torch.empty(nb, n_rows, H, dtype=torch.float32, device=g.device)
+    if sum_out is not None and (tuple(sum_out.shape) != (n_rows, H) or sum_out.dtype != torch.float32 or not sum_out.is_contiguous()):
+        raise _lib.BganError("scatter_arg_batch: sum_out must be a contiguous fp32 [n_rows, H]")
     check(lib.bg_scatter_arg_batch_f32(ptr(g), H, S * H, ptr(arg), S * H, ptr(seg_of), ptr(out), H, n_rows * H, S, n_rows, H,
-                                       nb, stream()), "bg_scatter_arg_batch_f32")
+                                       nb, ptr(sum_out), H, stream()), "bg_scatter_arg_batch_f32")
     return out
 
 

@@ -290,10 +290,13 @@ int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, const in
 
 /* n_batch scatters of bg_scatter_arg_f32's row-lookup form (seg_of required) that share the segments, in one launch:
  * batch b reads g + b * g_step and arg + b * arg_step and writes out + b * out_step (steps in elements).
- * replaces: the scatter_max backward of the pooled D(real) and D(fake) in d_loss.backward(), train.py:98.        */
+ * sum_out (may be NULL; pitch ld_sum): the elementwise sum of the batches' results in batch order, (v_0 + v_1) + ..,
+ * written by the same launch (16-byte path, n_batch <= 8) -- what an addition launch after the scatters would give.
+ * replaces: the scatter_max backward of the pooled D(real) and D(fake) in d_loss.backward(), train.py:98, and
+ * autograd's sum of the two gradients arriving at the shared label-free activations.                            */
 int bg_scatter_arg_batch_f32(const float* g, int64_t ldg, int64_t g_step, const int32_t* arg, int64_t arg_step,
                              const int32_t* seg_of, float* out, int64_t ldo, int64_t out_step, int64_t n_seg,
-                             int64_t n_rows, int64_t H, int64_t n_batch, bgStream stream);
+                             int64_t n_rows, int64_t H, int64_t n_batch, float* sum_out, int64_t ld_sum, bgStream stream);
 
 /* out[k] = dot(a[r_k,:], b[c_k,:]) for every CSR slot k (r_k = the row owning slot k),
  * written to out[eperm ? eperm[k] : k].   The weight-gradient of bg_spmm_f32.                */

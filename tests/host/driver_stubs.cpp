@@ -174,8 +174,9 @@ int bg_segmax_batch_f32(const float* x, int64_t ldx, int64_t x_step, const int32
 }
 int bg_scatter_arg_batch_f32(const float* g, int64_t ldg, int64_t g_step, const int32_t* arg, int64_t arg_step,
                              const int32_t* seg_of, float* out, int64_t ldo, int64_t out_step, int64_t n_seg, int64_t n_rows,
-                             int64_t H, int64_t n_batch, bgStream) {
-    int64_t a[] = {P(g), ldg, g_step, P(arg), arg_step, P(seg_of), P(out), ldo, out_step, n_seg, n_rows, H, n_batch};
+                             int64_t H, int64_t n_batch, float* sum_out, int64_t ld_sum, bgStream) {
+    int64_t a[] = {P(g), ldg, g_step, P(arg), arg_step, P(seg_of), P(out), ldo, out_step, n_seg, n_rows, H, n_batch,
+                   P(sum_out), ld_sum};
     rec(40, a, sizeof(a) / 8);
     return 0;
 }

@@ -455,8 +455,11 @@ def _check_critic_calls(calls, R, h):
             R.check(arg, nb * nseg * H * 4, tag + " arg (all sets)")
             assert out != x
         elif kind == 40:
-            g, ldg, gs, arg, as_, seg_of, out, ldo, os_, n_seg, n_rows, H, nb = a
+            g, ldg, gs, arg, as_, seg_of, out, ldo, os_, n_seg, n_rows, H, nb, sum_out, ld_sum = a
             assert nb == 2 and gs == n_seg * ldg and as_ == n_seg * H and os_ == n_rows * ldo
+            if sum_out:
+                R.check(sum_out, ((n_rows - 1) * ld_sum + H) * f, tag + " sum of the sets")
+                assert sum_out != out and sum_out != g
             R.check(g, ((nb * n_seg - 1) * ldg + H) * f, tag + " g (both sets)")
             R.check(arg, nb * n_seg * H * 4, tag + " arg (both sets)")
             R.check(seg_of, n_rows * 4, tag + " seg_of")
@@ -559,7 +562,10 @@ def test_critic_head_host_sequence_and_extents(drv, N, S, B, basis):
     # 39: the three label sets pooled by one launch per level (voxel -> story, story -> graph)
     assert [k for k, _ in fwd] == [10, 1, 28, 1, 39, 39, 38, 38, 12, 13, 13, 1, 10, 14, 15]
     # 37: a decoder's whole backward (penalty share included) as one launch; 40: real and fake scattered by one launch
-    assert [k for k, _ in bwd] == [16, 20, 14, 10, 1, 12, 12, 37, 40, 37, 40, 19, 18, 19]
+    # (the voxel-level scatter also leaves the two sets' sum: no addition launch, kind 18, between the two products)
+    assert [k for k, _ in bwd] == [16, 20, 14, 10, 1, 12, 12, 37, 40, 37, 40, 19, 19]
+    sums = [a[13] for k, a in bwd if k == 40]
+    assert sums[0] == 0 and R.check(sums[1], N * 256 * 4, "sum of the sets") == "workspace"
     _check_critic_calls(fwd, R, h)
     _check_critic_calls(bwd, R, h)
     # where the gradients land: the eight decoder outputs by the two decoder launches (checked above), gW by the products

@@ -1120,6 +1120,10 @@ def test_pooling_of_several_label_sets_in_one_launch(cuda):
             for b in range(nb):
                 assert torch.equal(got[b], ops.scatter_arg_raw(g[b], arg[b], n, seg_of=csr.seg_of))
             assert float(got.abs().sum()) > 0
+            total = torch.full((n, H), float("nan"), device=cuda)          # the sets' sum by the same launch, in set order
+            again = ops.scatter_arg_batch_raw(g, arg, n, csr.seg_of, sum_out=total)
+            want = got[0] + got[1] if nb == 2 else (got[0] + got[1]) + got[2]
+            assert torch.equal(again, got) and torch.equal(total, want)
     lib_err = ops._lib.BganError
     with pytest.raises(lib_err):
         ops.segmax_batch_raw(p.story_seg, torch.zeros(2, p.Nv + 1, 8, device=cuda))
