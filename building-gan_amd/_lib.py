@@ -56,6 +56,8 @@ SIGNATURES = {
     "bg_scatter_arg_f32": [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "bg_segsum_acc_f32": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "bg_segmax_batch_f32": [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _p],
+    "bg_gather_arg_pair_f32": [_p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p],
+    "bg_scatter_arg_pair_f32": [_p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "bg_scatter_arg_batch_f32": [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _i64, _p],
     "bg_sddmm_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p],
     "bg_cross_logits_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p],
@@ -92,6 +94,8 @@ SIGNATURES = {
                         _p, _i64, _p, _i64, _p],
     "bg_decoder_bwd_f32": [_i64, _i64, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _p, _p,
                            _p, _i64, _p],
+    "bg_decoder_fwd_pair_f32": [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p,
+                                _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p],
     "bg_decoder_fwd_f32": [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p],
     "bg_gemm_cheb_f32": [_int, _i64, _i64, _p, _i64, _i64, _i64, _i64, _int, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p],
     "bg_attention_bwd_head_f32": [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _i64,

@@ -479,11 +479,11 @@ struct DecFwdArgs {
     const float* X; int64_t ldx; const float* w1; int64_t ldw1; const float* b1; const float* w2; const float* b2;
     float* val; float* gp;
 };
-__global__ __launch_bounds__(DEC_T) void k_decoder_fwd(DecFwdArgs a) {
+__device__ __forceinline__ void decoder_fwd_body(const DecFwdArgs& a, const int b, const int nb) {
     extern __shared__ float dec_smem[];                 // gp [H2] | partial [DEC_Q][H2]
     float* gps = dec_smem;
     float* part = dec_smem + a.H2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nb = gridDim.x, b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nj = DEC_T / DEC_Q;
     for (int j0 = 0; j0 < a.H2; j0 += nj) {
         const int j = j0 + tid % nj, q = tid / nj;
@@ -521,6 +521,12 @@ __global__ __launch_bounds__(DEC_T) void k_decoder_fwd(DecFwdArgs a) {
         d = bg_wave_sum(d);
         if (lane == 0) a.val[r] = d + c0;
     }
+}
+__global__ __launch_bounds__(DEC_T) void k_decoder_fwd(DecFwdArgs a) { decoder_fwd_body(a, blockIdx.x, gridDim.x); }
+// two decoders side by side: workgroups [0, nb0) run the first exactly as its own launch would, the rest the second
+__global__ __launch_bounds__(DEC_T) void k_decoder_fwd_pair(DecFwdArgs a0, DecFwdArgs a1, int nb0) {
+    if ((int)blockIdx.x < nb0) decoder_fwd_body(a0, blockIdx.x, nb0);
+    else decoder_fwd_body(a1, blockIdx.x - nb0, gridDim.x - nb0);
 }
 }  // namespace
 
@@ -825,6 +831,24 @@ int bg_decoder_fwd_f32(int64_t R, int64_t H2, int64_t Hd, const float* X, int64_
     int nb = (int)((R + DEC_T / 64 - 1) / (DEC_T / 64));                // one row per wave
     if (nb > 32) nb = 32;
     k_decoder_fwd<<<nb, DEC_T, (size_t)(1 + DEC_Q) * H2 * sizeof(float), (hipStream_t)stream>>>(a);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+// Two decoders of the same widths on their own rows in one launch (the critic's story decoder and building decoder
+// do not depend on each other): the results of two bg_decoder_fwd_f32 calls, bit for bit
+int bg_decoder_fwd_pair_f32(int64_t H2, int64_t Hd, int64_t R0, const float* X0, int64_t ldx0, const float* w1_0, int64_t ldw1_0,
+                            const float* b1_0, const float* w2_0, const float* b2_0, float* val0, float* gp0,
+                            int64_t R1, const float* X1, int64_t ldx1, const float* w1_1, int64_t ldw1_1,
+                            const float* b1_1, const float* w2_1, const float* b2_1, float* val1, float* gp1, bgStream stream) {
+    if (R0 <= 0 || R1 <= 0 || H2 <= 0 || Hd <= 0 || !X0 || !w1_0 || !b1_0 || !w2_0 || !b2_0 || !val0 || !gp0 || !X1 || !w1_1 ||
+        !b1_1 || !w2_1 || !b2_1 || !val1 || !gp1 || ldx0 < H2 || ldw1_0 < H2 || ldx1 < H2 || ldw1_1 < H2) return BG_ERR_ARG;
+    if (R0 > (1 << 20) || R1 > (1 << 20) || H2 > 1024 || Hd > (1 << 20)) return BG_ERR_SHAPE;
+    DecFwdArgs a0{(int)R0, (int)H2, (int)Hd, X0, ldx0, w1_0, ldw1_0, b1_0, w2_0, b2_0, val0, gp0};
+    DecFwdArgs a1{(int)R1, (int)H2, (int)Hd, X1, ldx1, w1_1, ldw1_1, b1_1, w2_1, b2_1, val1, gp1};
+    auto blocks = [](int64_t R) { int nb = (int)((R + DEC_T / 64 - 1) / (DEC_T / 64)); return nb > 32 ? 32 : nb; };   // as the single form
+    const int nb0 = blocks(R0), nb1 = blocks(R1);
+    k_decoder_fwd_pair<<<nb0 + nb1, DEC_T, (size_t)(1 + DEC_Q) * H2 * sizeof(float), (hipStream_t)stream>>>(a0, a1, nb0);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

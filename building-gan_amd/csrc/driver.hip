@@ -479,12 +479,13 @@ extern "C" int bg_critic_head_forward_f32(const bgCriticHead* hp, float coef, fl
     BG_TRY(bg_segmax_batch_f32(b.Xs, H2, S * H2, h.sg_rowptr, h.sg_col, b.Xb, H2, B * H2, b.ab, B * H2, B, H2, 3, s));
     // both decoders: one launch each (no activation between their layers: val = X (w2 W1)^T + w2 . b1 + b2; the row
     // w2 W1 is kept -- d D / d pooled of such a decoder is that constant row)
-    BG_TRY(bg_decoder_fwd_f32(2 * S, H2, Hd, b.Xs, H2, h.s_w1, H2, h.s_b1, h.s_w2, h.s_b2, b.vals, b.gp_s, s));
-    BG_TRY(bg_decoder_fwd_f32(2 * B, H2, Hd, b.Xb, H2, h.b_w1, H2, h.b_b1, h.b_w2, h.b_b2, b.valb, b.gp_b, s));
+    BG_TRY(bg_decoder_fwd_pair_f32(H2, Hd, 2 * S, b.Xs, H2, h.s_w1, H2, h.s_b1, h.s_w2, h.s_b2, b.vals, b.gp_s,
+                                   2 * B, b.Xb, H2, h.b_w1, H2, h.b_b1, h.b_w2, h.b_b2, b.valb, b.gp_b, s));
     BG_TRY(bg_gather_arg_f32(reinterpret_cast<const float*>(b.arg_s), H2, b.arg_sb, reinterpret_cast<float*>(b.arg_b), H2, B, H2, s));
-    // scattered to the arg-max voxels (row pitch 0: every segment reads the same row): building rows, then story rows
-    BG_TRY(bg_scatter_arg_f32(b.gp_b, 0, b.arg_b, h.graph_of_voxel, b.G2, H2, B, N, H2, s));
-    BG_TRY(bg_scatter_arg_f32(b.gp_s, 0, b.arg_s, h.story_of_voxel, b.G2 + N * H2, H2, S, N, H2, s));
+    // scattered to the arg-max voxels (row pitch 0: every segment reads the same row): building rows and story rows,
+    // one launch
+    BG_TRY(bg_scatter_arg_pair_f32(b.gp_b, 0, b.arg_b, h.graph_of_voxel, b.G2, B,
+                                   b.gp_s, 0, b.arg_s, h.story_of_voxel, b.G2 + N * H2, S, H2, N, H2, s));
     // sum_k (A^T)^k G Wl_k^T: all powers' columns by one product, both outputs side by side through one chain
     BG_TRY(mm(2 * N, K1 * dl, H2, b.G2, H2, Wl, H2, 1, b.X, nullptr, nullptr, s));
     BG_TRY(bg_regroup_f32(b.X, b.Ys, N, K1, 2, dl, 0, s));
@@ -528,8 +529,7 @@ extern "C" int bg_critic_head_backward_f32(const bgCriticHead* hp, float coef, c
                              nullptr, 0, 0, b.dYs + W2c, ldy, W2c, h.L, W2c, h.basis ? BG_CHAIN_CHEB : BG_CHAIN_POWER, s));
     BG_TRY(bg_regroup_f32(b.dYs, b.dX, N, K1, 2, dl, 1, s));
     BG_TRY(mm(2 * N, H2, K1 * dl, b.dX, K1 * dl, Wl, H2, 0, b.dG2, nullptr, nullptr, s));                   // d G2 = dX Wl
-    BG_TRY(bg_gather_arg_f32(b.dG2, H2, b.arg_b, b.dgp_b, H2, B, H2, s));
-    BG_TRY(bg_gather_arg_f32(b.dG2 + N * H2, H2, b.arg_s, b.dgp_s, H2, S, H2, s));
+    BG_TRY(bg_gather_arg_pair_f32(b.dG2, H2, b.arg_b, b.dgp_b, B, b.dG2 + N * H2, H2, b.arg_s, b.dgp_s, S, H2, H2, s));
     // ---- both decoders' backward, one launch each (bg_decoder_bwd_f32: every gradient is rank one).  Penalty share:
     // every row of d D / d pooled is the same w2 W1, so its gradient is the column sum c of the rows gathered above
     // (g W1 = w2 (x) c, g W2 = W1 c).  D(real), D(fake): building decoder, back through the story level, story decoder.
@@ -1068,8 +1068,8 @@ extern "C" int bg_gloss_head_forward_f32(const bgCriticHead* hp, const float* la
     }
     BG_TRY(bg_segmax_f32(b.v, H2, h.st_rowptr, h.st_col, nullptr, 0, 0, nullptr, nullptr, b.Xs, H2, b.as, S, H2, s));
     BG_TRY(bg_segmax_f32(b.Xs, H2, h.sg_rowptr, h.sg_col, nullptr, 0, 0, nullptr, nullptr, b.Xb, H2, b.ab, B, H2, s));
-    BG_TRY(bg_decoder_fwd_f32(S, H2, Hd, b.Xs, H2, h.s_w1, H2, h.s_b1, h.s_w2, h.s_b2, b.vals, b.gp_s, s));
-    BG_TRY(bg_decoder_fwd_f32(B, H2, Hd, b.Xb, H2, h.b_w1, H2, h.b_b1, h.b_w2, h.b_b2, b.valb, b.gp_b, s));
+    BG_TRY(bg_decoder_fwd_pair_f32(H2, Hd, S, b.Xs, H2, h.s_w1, H2, h.s_b1, h.s_w2, h.s_b2, b.vals, b.gp_s,
+                                   B, b.Xb, H2, h.b_w1, H2, h.b_b1, h.b_w2, h.b_b2, b.valb, b.gp_b, s));
     BG_TRY(bg_critic_loss_f32(b.valb, h.wb, B, b.vals, h.ws, S, nullptr, 0, 0, 0, 0.f, b.part, loss, s));
     return BG_OK;
 }

@@ -519,6 +519,42 @@ __global__ __launch_bounds__(256) void k_scatter_arg_dense4(const float* __restr
     bg_st4(out + (int64_t)r * ldo + h, v);
 }
 
+// two such scatters over the same rows in one launch (blockIdx.y picks the operands): the critic's forward sends the
+// building decoder's row and the story decoder's row to their arg-max voxels side by side
+struct ScatterPair { const float* g[2]; int64_t ldg[2]; const int32_t* arg[2]; const int32_t* seg_of[2]; float* out[2]; };
+__global__ __launch_bounds__(256) void k_scatter_arg_dense4_pair(ScatterPair p, int64_t ldo, uint32_t n4, uint32_t H4) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n4) return;
+    const int y = blockIdx.y;
+    const uint32_t r = t / H4, h = 4u * (t - r * H4);
+    const int32_t s = p.seg_of[y][r];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s >= 0) {
+        const int4 ar = *reinterpret_cast<const int4*>(p.arg[y] + (int64_t)s * (4 * H4) + h);
+        const float4 gv = bg_ld4(p.g[y] + (int64_t)s * p.ldg[y] + h);
+        v.x = ar.x == (int32_t)r ? gv.x : 0.f; v.y = ar.y == (int32_t)r ? gv.y : 0.f;
+        v.z = ar.z == (int32_t)r ? gv.z : 0.f; v.w = ar.w == (int32_t)r ? gv.w : 0.f;
+    }
+    bg_st4(p.out[y] + (int64_t)r * ldo + h, v);
+}
+
+// two gathers in one launch: threads [0, n0 H) serve the first, the rest the second
+__global__ void k_gather_arg_pair(const float* __restrict__ x0, int64_t ldx0, const int32_t* __restrict__ arg0,
+                                  float* __restrict__ out0, int64_t n0, const float* __restrict__ x1, int64_t ldx1,
+                                  const int32_t* __restrict__ arg1, float* __restrict__ out1, int64_t n1, int64_t ldo, int H) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (n0 + n1) * H) return;
+    const bool second = t >= n0 * H;
+    if (second) t -= n0 * H;
+    const float* x = second ? x1 : x0;
+    const int64_t ldx = second ? ldx1 : ldx0;
+    const int32_t* arg = second ? arg1 : arg0;
+    float* out = second ? out1 : out0;
+    int64_t s = t / H; int h = (int)(t % H);
+    int32_t a = arg[t];
+    out[s * ldo + h] = a >= 0 ? x[(int64_t)a * ldx + h] : 0.f;
+}
+
 // the batches of one row by one thread, and their sum (in batch order: (v_0 + v_1) + ..) written beside them
 __global__ __launch_bounds__(256) void k_scatter_arg_dense4_sum(const float* __restrict__ g, int64_t ldg,
                                                                 const int32_t* __restrict__ arg, const int32_t* __restrict__ seg_of,
@@ -1297,6 +1333,45 @@ int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, const in
     }
     if (n_seg == 0) return BG_OK;
     k_scatter_arg<<<bg_grid_for(n_seg * H, 256, 0x7fffffff), 256, 0, s>>>(g, ldg, arg, out, ldo, n_seg, (int)H);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+// Two gathers of the same width in one launch (the critic's backward reads the penalty's gradient at the arg-max voxels
+// of the buildings and of the stories): out_i[s, h] = x_i[arg_i[s, h], h], 0 where arg_i is -1
+int bg_gather_arg_pair_f32(const float* x0, int64_t ldx0, const int32_t* arg0, float* out0, int64_t n_seg0,
+                           const float* x1, int64_t ldx1, const int32_t* arg1, float* out1, int64_t n_seg1,
+                           int64_t ldo, int64_t H, bgStream stream) {
+    if (n_seg0 < 0 || n_seg1 < 0 || H < 0) return BG_ERR_ARG;
+    if (n_seg0 + n_seg1 == 0 || H == 0) return BG_OK;
+    if ((n_seg0 > 0 && (!x0 || !arg0 || !out0)) || (n_seg1 > 0 && (!x1 || !arg1 || !out1)) || ldo < H) return BG_ERR_ARG;
+    k_gather_arg_pair<<<bg_grid_for((n_seg0 + n_seg1) * H, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
+        x0, ldx0, arg0, out0, n_seg0, x1, ldx1, arg1, out1, n_seg1, ldo, (int)H);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+// Two scatters over the same rows in one launch, each with its own segments: out_i[r, h] = g_i[seg_of_i[r], h] where
+// arg_i[seg_of_i[r], h] == r, else 0 (bg_scatter_arg_f32's one-launch form twice; the shapes it does not take -- no
+// segment ids, H % 4 != 0, unaligned rows -- go through two calls of that function)
+int bg_scatter_arg_pair_f32(const float* g0, int64_t ldg0, const int32_t* arg0, const int32_t* seg_of0, float* out0, int64_t n_seg0,
+                            const float* g1, int64_t ldg1, const int32_t* arg1, const int32_t* seg_of1, float* out1, int64_t n_seg1,
+                            int64_t ldo, int64_t n_rows, int64_t H, bgStream stream) {
+    if (n_seg0 < 0 || n_seg1 < 0 || H < 0 || n_rows < 0) return BG_ERR_ARG;
+    if (n_rows == 0 || H == 0) return BG_OK;
+    if (!out0 || !out1 || ldo < H) return BG_ERR_ARG;
+    const bool vec = n_seg0 > 0 && n_seg1 > 0 && g0 && g1 && arg0 && arg1 && seg_of0 && seg_of1 && H % 4 == 0 &&
+                     ldg0 % 4 == 0 && ldg1 % 4 == 0 && ldo % 4 == 0 && bg_aligned16(g0) && bg_aligned16(g1) &&
+                     bg_aligned16(arg0) && bg_aligned16(arg1) && bg_aligned16(out0) && bg_aligned16(out1) &&
+                     n_rows * (H / 4) < 0x7fffffff;
+    if (!vec) {
+        int rc = bg_scatter_arg_f32(g0, ldg0, arg0, seg_of0, out0, ldo, n_seg0, n_rows, H, stream);
+        if (rc != BG_OK) return rc;
+        return bg_scatter_arg_f32(g1, ldg1, arg1, seg_of1, out1, ldo, n_seg1, n_rows, H, stream);
+    }
+    const uint32_t n4 = (uint32_t)(n_rows * (H / 4));
+    ScatterPair p{{g0, g1}, {ldg0, ldg1}, {arg0, arg1}, {seg_of0, seg_of1}, {out0, out1}};
+    k_scatter_arg_dense4_pair<<<dim3((n4 + 255u) / 256u, 2), 256, 0, (hipStream_t)stream>>>(p, ldo, n4, (uint32_t)(H / 4));
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -298,6 +298,23 @@ int bg_scatter_arg_batch_f32(const float* g, int64_t ldg, int64_t g_step, const 
                              const int32_t* seg_of, float* out, int64_t ldo, int64_t out_step, int64_t n_seg,
                              int64_t n_rows, int64_t H, int64_t n_batch, float* sum_out, int64_t ld_sum, bgStream stream);
 
+/* Two bg_gather_arg_f32 of the same width H and output pitch ldo in ONE launch (results bit for bit those of the two
+ * calls): out_i[s, h] = arg_i[s, h] >= 0 ? x_i[arg_i[s, h], h] : 0 for s < n_seg_i.
+ * replaces: the two scatter_max backward reads of the penalty's double backward (Model/losses.py:83-88 through
+ * global_max_pool by building and by story, Model/models.py:262-263).                                            */
+int bg_gather_arg_pair_f32(const float* x0, int64_t ldx0, const int32_t* arg0, float* out0, int64_t n_seg0,
+                           const float* x1, int64_t ldx1, const int32_t* arg1, float* out1, int64_t n_seg1,
+                           int64_t ldo, int64_t H, bgStream stream);
+
+/* Two bg_scatter_arg_f32 of the row-lookup form over the same n_rows rows, each with its own segments (seg_of_i, arg_i,
+ * g_i, n_seg_i), in ONE launch; same results bit for bit.  Shapes the one-launch form does not take (a NULL seg_of,
+ * H % 4 != 0, rows not 16-byte aligned) are served by two calls of bg_scatter_arg_f32.
+ * replaces: the scatter_max backward of both global_max_pool levels at the penalty's sample point
+ * (Model/losses.py:83-84: d D(sample) / d voxel features, closed form).                                          */
+int bg_scatter_arg_pair_f32(const float* g0, int64_t ldg0, const int32_t* arg0, const int32_t* seg_of0, float* out0, int64_t n_seg0,
+                            const float* g1, int64_t ldg1, const int32_t* arg1, const int32_t* seg_of1, float* out1, int64_t n_seg1,
+                            int64_t ldo, int64_t n_rows, int64_t H, bgStream stream);
+
 /* out[k] = dot(a[r_k,:], b[c_k,:]) for every CSR slot k (r_k = the row owning slot k),
  * written to out[eperm ? eperm[k] : k].   The weight-gradient of bg_spmm_f32.                */
 int bg_sddmm_f32(const float* a, int64_t lda, const float* b, int64_t ldb,
@@ -505,6 +522,15 @@ int bg_critic_loss_f32(const float* val_b, const float* wb, int64_t nb, const fl
  * replaces: building_decoder / story_decoder (Model/models.py:251-264): two Linear launches + one product as ONE.  */
 int bg_decoder_fwd_f32(int64_t R, int64_t H2, int64_t Hd, const float* X, int64_t ldx, const float* w1, int64_t ldw1,
                        const float* b1, const float* w2, const float* b2, float* val, float* gp, bgStream stream);
+
+/* Two such decoders of the same widths (H2, Hd), each on its own rows and parameters, in ONE launch: the results of two
+ * bg_decoder_fwd_f32 calls bit for bit (the first decoder's workgroups, then the second's).
+ * replaces: story_decoder and building_decoder of one DiscriminatorVoxel.forward (Model/models.py:262-263), which do
+ * not depend on each other.                                                                                         */
+int bg_decoder_fwd_pair_f32(int64_t H2, int64_t Hd, int64_t R0, const float* X0, int64_t ldx0, const float* w1_0, int64_t ldw1_0,
+                            const float* b1_0, const float* w2_0, const float* b2_0, float* val0, float* gp0,
+                            int64_t R1, const float* X1, int64_t ldx1, const float* w1_1, int64_t ldw1_1,
+                            const float* b1_1, const float* w2_1, const float* b2_1, float* val1, float* gp1, bgStream stream);
 
 /* Its backward, with the gradient-penalty path's share -- every gradient is rank one:
  *   u = dv^T X, sdv = sum dv, c = column sums of dgp [Rp, H2] (Rp may be 0), gp = w2 W1 (from the forward)

@@ -165,6 +165,23 @@ int bg_scatter_arg_f32(const float* g, int64_t ldg, const int32_t* arg, const in
     rec(13, a, sizeof(a) / 8);
     return 0;
 }
+// the pair launchers: a marker (kinds 43 / 44 / 45, one argument) followed by the two single calls they replace, so the
+// extent checks of the tests apply unchanged
+int bg_gather_arg_pair_f32(const float* x0, int64_t ldx0, const int32_t* arg0, float* out0, int64_t n_seg0, const float* x1,
+                           int64_t ldx1, const int32_t* arg1, float* out1, int64_t n_seg1, int64_t ldo, int64_t H, bgStream s) {
+    int64_t a[] = {2};
+    rec(43, a, 1);
+    bg_gather_arg_f32(x0, ldx0, arg0, out0, ldo, n_seg0, H, s);
+    return bg_gather_arg_f32(x1, ldx1, arg1, out1, ldo, n_seg1, H, s);
+}
+int bg_scatter_arg_pair_f32(const float* g0, int64_t ldg0, const int32_t* arg0, const int32_t* seg_of0, float* out0,
+                            int64_t n_seg0, const float* g1, int64_t ldg1, const int32_t* arg1, const int32_t* seg_of1,
+                            float* out1, int64_t n_seg1, int64_t ldo, int64_t n_rows, int64_t H, bgStream s) {
+    int64_t a[] = {2};
+    rec(44, a, 1);
+    bg_scatter_arg_f32(g0, ldg0, arg0, seg_of0, out0, ldo, n_seg0, n_rows, H, s);
+    return bg_scatter_arg_f32(g1, ldg1, arg1, seg_of1, out1, ldo, n_seg1, n_rows, H, s);
+}
 int bg_segmax_batch_f32(const float* x, int64_t ldx, int64_t x_step, const int32_t* rowptr, const int32_t* col, float* out,
                         int64_t ldo, int64_t out_step, int32_t* arg, int64_t arg_step, int64_t n_rows, int64_t H,
                         int64_t n_batch, bgStream) {
@@ -308,6 +325,15 @@ int bg_decoder_fwd_f32(int64_t R, int64_t H2, int64_t Hd, const float* X, int64_
     int64_t a[] = {R, H2, Hd, P(X), ldx, P(w1), ldw1, P(b1), P(w2), P(b2), P(val), P(gp)};
     rec(38, a, sizeof(a) / 8);
     return 0;
+}
+int bg_decoder_fwd_pair_f32(int64_t H2, int64_t Hd, int64_t R0, const float* X0, int64_t ldx0, const float* w1_0, int64_t ldw1_0,
+                            const float* b1_0, const float* w2_0, const float* b2_0, float* val0, float* gp0, int64_t R1,
+                            const float* X1, int64_t ldx1, const float* w1_1, int64_t ldw1_1, const float* b1_1,
+                            const float* w2_1, const float* b2_1, float* val1, float* gp1, bgStream s) {
+    int64_t a[] = {2};
+    rec(45, a, 1);
+    bg_decoder_fwd_f32(R0, H2, Hd, X0, ldx0, w1_0, ldw1_0, b1_0, w2_0, b2_0, val0, gp0, s);
+    return bg_decoder_fwd_f32(R1, H2, Hd, X1, ldx1, w1_1, ldw1_1, b1_1, w2_1, b2_1, val1, gp1, s);
 }
 // one launch of several fills / copies: a marker (kind 27: the job count) followed by each job as the single call it
 // replaces (kind 25 / 20), so the extent checks of the tests apply unchanged

@@ -541,6 +541,8 @@ def _check_critic_calls(calls, R, h):
                 assert R.check(g_w2, Hd * f, tag) == "g_%s_w2" % which and R.check(g_b2, f, tag) == "g_%s_b2" % which
             else:                                         # frozen decoders (generator objective): d X only
                 assert (Rr, Rp) in ((B, 0), (S, 0)) and not (g_b1 or g_w2 or g_b2 or w1 or w2 or b1 or dgp)
+        elif kind in (43, 44, 45):
+            assert a == [2], tag                          # a pair launcher's marker: its two single calls follow
         elif kind == 38:
             Rr, H2, Hd, X, ldx, w1, ldw1, b1, w2, b2, val, gp = a
             assert H2 == h.H2 and Hd == h.Hd and Rr in (B, S, 2 * B, 2 * S)
@@ -560,10 +562,12 @@ def test_critic_head_host_sequence_and_extents(drv, N, S, B, basis):
     assert rc_f == 0 and rc_b == 0
     # 38: a decoder's forward as one launch (it also leaves w2 W1, which the scatters below read)
     # 39: the three label sets pooled by one launch per level (voxel -> story, story -> graph)
-    assert [k for k, _ in fwd] == [10, 1, 28, 1, 39, 39, 38, 38, 12, 13, 13, 1, 10, 14, 15]
+    # 45 / 44 / 43: both decoders, both scatters, both gathers by one launch each (the stub lists the pair's two single
+    # calls behind the marker)
+    assert [k for k, _ in fwd] == [10, 1, 28, 1, 39, 39, 45, 38, 38, 12, 44, 13, 13, 1, 10, 14, 15]
     # 37: a decoder's whole backward (penalty share included) as one launch; 40: real and fake scattered by one launch
     # (the voxel-level scatter also leaves the two sets' sum: no addition launch, kind 18, between the two products)
-    assert [k for k, _ in bwd] == [16, 20, 14, 10, 1, 12, 12, 37, 40, 37, 40, 19, 19]
+    assert [k for k, _ in bwd] == [16, 20, 14, 10, 1, 43, 12, 12, 37, 40, 37, 40, 19, 19]
     sums = [a[13] for k, a in bwd if k == 40]
     assert sums[0] == 0 and R.check(sums[1], N * 256 * 4, "sum of the sets") == "workspace"
     _check_critic_calls(fwd, R, h)
@@ -968,7 +972,7 @@ def test_gloss_head_host_sequence_and_extents(drv, N, S, B):
         return rc, [(drv.stub_call(i)[0], [drv.stub_call(i)[2 + k] for k in range(drv.stub_call(i)[1])])
                     for i in range(drv.stub_count())]
     rc, fwd = calls_of(drv.bg_gloss_head_forward_f32, C.byref(h), label, 6, 6, work, nws, loss, None)
-    assert rc == 0 and [k for k, _ in fwd] == [20, 14, 1, 11, 11, 38, 38, 15]
+    assert rc == 0 and [k for k, _ in fwd] == [20, 14, 1, 11, 11, 45, 38, 38, 15]
     R.r.pop("go")
     rc, bwd = calls_of(drv.bg_gloss_head_backward_f32, C.byref(h), 6, R.new("go", f), work, nws, R.new("g_label", N * 6 * f), None)
     assert rc == 0 and [k for k, _ in bwd] == [16, 37, 13, 37, 13, 1, 14, 20]

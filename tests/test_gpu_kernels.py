@@ -1293,6 +1293,81 @@ def test_fills_and_copies_as_one_launch(cuda):
     assert lib.bg_fill_copy_batch(0, None, None, None, None, None, None, st) == 0
 
 
+@pytest.mark.parametrize("n_rows,S,B,H", [(11520, 88, 8, 256), (301, 7, 2, 64), (40, 40, 1, 8)])
+def test_pair_launchers_equal_their_two_single_calls(cuda, n_rows, S, B, H):
+    """bg_decoder_fwd_pair_f32, bg_scatter_arg_pair_f32, bg_gather_arg_pair_f32 (two independent small launches of the
+    critic's pooled head as one): bit for bit the two single calls, on rows of different counts and with -1 ids."""
+    from building_gan_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(n_rows + H)
+    rnd = lambda *s: (torch.rand(*s, generator=gen) * 2 - 1).to(cuda)
+    nan = lambda *s: torch.full(s, float("nan"), device=cuda)
+    # ---- decoders
+    Hd = H // 2
+    par = [[rnd(Hd, H), rnd(Hd), rnd(Hd), rnd(1)] for _ in range(2)]
+    X = [rnd(2 * S, H), rnd(2 * B, H)]
+    single = []
+    for i in range(2):
+        val, gp = nan(X[i].shape[0]), nan(H)
+        w1, b1, w2, b2 = par[i]
+        assert lib.bg_decoder_fwd_f32(X[i].shape[0], H, Hd, X[i].data_ptr(), H, w1.data_ptr(), H, b1.data_ptr(), w2.data_ptr(),
+                                      b2.data_ptr(), val.data_ptr(), gp.data_ptr(), st) == 0
+        single.append((val, gp))
+    pv = [(nan(X[i].shape[0]), nan(H)) for i in range(2)]
+    args = []
+    for i in range(2):
+        w1, b1, w2, b2 = par[i]
+        args += [X[i].shape[0], X[i].data_ptr(), H, w1.data_ptr(), H, b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                 pv[i][0].data_ptr(), pv[i][1].data_ptr()]
+    assert lib.bg_decoder_fwd_pair_f32(H, Hd, *args, st) == 0
+    for i in range(2):
+        assert torch.equal(pv[i][0], single[i][0]) and torch.equal(pv[i][1], single[i][1])
+    assert lib.bg_decoder_fwd_pair_f32(H, Hd, *([0] + args[1:]), st) == -1            # no rows for the first decoder
+    # ---- scatters: rows -> story (contiguous runs), rows -> building; the arg of a segment is one of its rows or -1
+    seg_s = (torch.arange(n_rows) * S // n_rows).to(torch.int32)
+    seg_b = (torch.arange(n_rows) * B // n_rows).to(torch.int32)
+    seg_s[n_rows // 2] = -1                                               # a row without a segment
+
+    def args_of(seg, n_seg):
+        arg = torch.full((n_seg, H), -1, dtype=torch.int32)
+        for q in range(n_seg):
+            rows = torch.nonzero(seg == q).view(-1)
+            if rows.numel():
+                arg[q] = rows[torch.randint(0, rows.numel(), (H,), generator=gen)].to(torch.int32)
+        arg[0, : H // 4] = -1
+        return arg.to(cuda)
+    arg_s, arg_b = args_of(seg_s, S), args_of(seg_b, B)
+    seg_s, seg_b = seg_s.to(cuda), seg_b.to(cuda)
+    g_s, g_b = rnd(S, H), rnd(1, H)                                       # (the building side: one row for every segment, pitch 0)
+    one = [nan(n_rows, H), nan(n_rows, H)]
+    assert lib.bg_scatter_arg_f32(g_b.data_ptr(), 0, arg_b.data_ptr(), seg_b.data_ptr(), one[0].data_ptr(), H, B, n_rows, H, st) == 0
+    assert lib.bg_scatter_arg_f32(g_s.data_ptr(), H, arg_s.data_ptr(), seg_s.data_ptr(), one[1].data_ptr(), H, S, n_rows, H, st) == 0
+    two = nan(2, n_rows, H)
+    assert lib.bg_scatter_arg_pair_f32(g_b.data_ptr(), 0, arg_b.data_ptr(), seg_b.data_ptr(), two[0].data_ptr(), B,
+                                       g_s.data_ptr(), H, arg_s.data_ptr(), seg_s.data_ptr(), two[1].data_ptr(), S,
+                                       H, n_rows, H, st) == 0
+    assert torch.equal(two[0], one[0]) and torch.equal(two[1], one[1])
+    assert float(two[1][n_rows // 2].abs().max()) == 0.0 and int((two[0] != 0).sum()) > 0
+    # (no segment ids: the two-call path inside the pair launcher)
+    two.fill_(float("nan"))
+    assert lib.bg_scatter_arg_pair_f32(g_b.data_ptr(), 0, arg_b.data_ptr(), None, two[0].data_ptr(), B,
+                                       g_s.data_ptr(), H, arg_s.data_ptr(), None, two[1].data_ptr(), S, H, n_rows, H, st) == 0
+    assert torch.equal(two[0], one[0]) and torch.equal(two[1], one[1])
+    # ---- gathers
+    x0, x1 = rnd(n_rows, H), rnd(n_rows, H + 4)[:, :H]                    # (a pitched source)
+    ref = [nan(B, H), nan(S, H)]
+    assert lib.bg_gather_arg_f32(x0.data_ptr(), H, arg_b.data_ptr(), ref[0].data_ptr(), H, B, H, st) == 0
+    assert lib.bg_gather_arg_f32(x1.data_ptr(), H + 4, arg_s.data_ptr(), ref[1].data_ptr(), H, S, H, st) == 0
+    got = [nan(B, H), nan(S, H)]
+    assert lib.bg_gather_arg_pair_f32(x0.data_ptr(), H, arg_b.data_ptr(), got[0].data_ptr(), B,
+                                      x1.data_ptr(), H + 4, arg_s.data_ptr(), got[1].data_ptr(), S, H, H, st) == 0
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    assert lib.bg_gather_arg_pair_f32(None, H, None, None, 0, x1.data_ptr(), H + 4, arg_s.data_ptr(), got[1].data_ptr(), S, H, H, st) == 0
+    assert lib.bg_gather_arg_pair_f32(None, H, arg_b.data_ptr(), got[0].data_ptr(), B, x1.data_ptr(), H + 4, arg_s.data_ptr(),
+                                      got[1].data_ptr(), S, H, H, st) == -1
+
+
 @pytest.mark.parametrize("R,Rp,H2,Hd,with_add", [(16, 8, 256, 128, False), (176, 88, 256, 128, True), (5, 0, 40, 9, True)])
 def test_decoder_backward_in_one_launch(cuda, R, Rp, H2, Hd, with_add):
     """bg_decoder_fwd_f32 / bg_decoder_bwd_f32 (a two-layer decoder without activation on a batch's pooled rows: the
