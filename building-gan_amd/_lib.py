@@ -49,6 +49,8 @@ SIGNATURES = {
                         _p, _i64, _i64, _i64, _p],
     "bg_spmm_chain_f32": [_p, _i64, _p, _p, _p, _int, _p, _int, _p, _i64, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
                           _i64, _i64, _i32, _p],
+    "bg_spmm_chain_grouped_f32": [_p, _i64, _p, _p, _p, _int, _p, _int, _p, _i64, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64,
+                                  _i64, _i64, _i64, _i32, _i64, _i64, _i64, _i64, _p],
     "bg_segreduce_sum_f32": [_p, _i64, _p, _p, _p, _p, _p, _int, _p, _i32, _i64, _p, _p, _i64, _i64, _i64, _p],
     "bg_segmax_f32": [_p, _i64, _p, _p, _p, _i32, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _p],
     "bg_segmax_static_f32": [_p, _i64, _p, _p, _p, _i32, _i64, _p, _i64, _p, _i64, _i64, _p],

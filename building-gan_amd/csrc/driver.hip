@@ -388,10 +388,10 @@ CriticBuffers carve_critic(Arena& ar, const bgCriticHead& h) {
     b.arg_s = b.as ? b.as + 2 * S * H2 : nullptr; b.arg_sb = b.ab ? b.ab + 2 * B * H2 : nullptr;
     b.arg_b = reinterpret_cast<int32_t*>(ar.take(B * H2));
     b.gp_b = ar.take(H2); b.gp_s = ar.take(H2);
-    b.G2 = b.v[2]; b.X = ar.take(2 * N * K1 * dl); b.Ys = ar.take(N * K1 * 2 * dl); b.acc = ar.take(N * 2 * dl);
+    b.G2 = b.v[2]; b.X = ar.take(2 * N * K1 * dl); b.acc = ar.take(N * 2 * dl);
     b.part = ar.take(128);
     b.dvb = ar.take(2 * B); b.dvs = ar.take(2 * S); b.dacc = ar.take(N * 2 * dl);
-    b.dYs = ar.take(N * K1 * 2 * dl); b.dX = b.Zp[2]; b.dG2 = ar.take(2 * N * H2);
+    b.dX = b.Zp[2]; b.dG2 = ar.take(2 * N * H2);
     b.dgp_b = ar.take(B * H2); b.dgp_s = ar.take(S * H2); b.c_b = ar.take(H2); b.c_s = ar.take(H2);
     b.dhs = ar.take(2 * S * Hd); b.dhb = ar.take(2 * B * Hd); b.dXs = ar.take(2 * S * H2); b.dXb = ar.take(2 * B * H2);
     b.T = ar.take(2 * S * H2);
@@ -488,12 +488,13 @@ extern "C" int bg_critic_head_forward_f32(const bgCriticHead* hp, float coef, fl
                                    b.gp_s, 0, b.arg_s, h.story_of_voxel, b.G2 + N * H2, S, H2, N, H2, s));
     // sum_k (A^T)^k G Wl_k^T: all powers' columns by one product, both outputs side by side through one chain
     BG_TRY(mm(2 * N, K1 * dl, H2, b.G2, H2, Wl, H2, 1, b.X, nullptr, nullptr, s));
-    BG_TRY(bg_regroup_f32(b.X, b.Ys, N, K1, 2, dl, 0, s));
-    const int64_t W2c = 2 * dl, ldy = K1 * W2c;
-    BG_TRY(bg_spmm_chain_f32(b.Ys + h.L * W2c, ldy, h.at_rowptr, h.at_col, nullptr, BG_SCALE_NONE, h.a_count, BG_SCALE_DIV,
-                             h.blk_ptr, h.blk_n, h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg,
-                             b.Ys + (h.L - 1) * W2c, ldy, -W2c, b.acc, W2c, 0, h.L, W2c,
-                             h.basis ? BG_CHAIN_CLENSHAW : BG_CHAIN_POWER, s));
+    // (the chain's 2 dl columns are two groups of dl: the building half and the story half of X's rows, read where the
+    //  product left them -- no regrouping launch in between)
+    const int64_t W2c = 2 * dl, ldx = K1 * dl, half = N * ldx;
+    BG_TRY(bg_spmm_chain_grouped_f32(b.X + h.L * dl, ldx, h.at_rowptr, h.at_col, nullptr, BG_SCALE_NONE, h.a_count, BG_SCALE_DIV,
+                                     h.blk_ptr, h.blk_n, h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg,
+                                     b.X + (h.L - 1) * dl, ldx, -dl, b.acc, W2c, 0, h.L, W2c,
+                                     h.basis ? BG_CHAIN_CLENSHAW : BG_CHAIN_POWER, dl, half, half, 0, s));
     BG_TRY(bg_critic_loss_f32(b.valb, h.wb, 2 * B, b.vals, h.ws, 2 * S, b.acc, dl, 2 * N, dl, coef, b.part, loss, s));
     return BG_OK;
 }
@@ -515,19 +516,24 @@ extern "C" int bg_critic_head_backward_f32(const bgCriticHead* hp, float coef, c
     const float* Wl = h.W + K1 * ds * H2;
     float* gWs = gW;
     float* gWl = gW + K1 * ds * H2;
-    const int64_t W2c = 2 * dl, ldy = K1 * W2c;
+    const int64_t W2c = 2 * dl, ldx = K1 * dl, half = N * ldx;
 
     BG_TRY(bg_critic_loss_bwd_f32(go, h.wb, 2 * B, h.ws, 2 * S, b.acc, dl, 2 * N, dl, coef, b.dvb, b.dvs, b.dacc, s));
     // ---- penalty: transpose of the Horner chain = the powers of A applied to d acc
-    {   // d acc into column group 0 of the chain's matrix (a strided copy, as a kernel)
-        const float* src[4] = {b.dacc, nullptr, nullptr, nullptr};
-        const int64_t lds[4] = {W2c, 0, 0, 0};
-        BG_TRY(bg_pack_columns_f32(src, lds, 1, W2c, W2c, b.dYs, ldy, N, s));
+    // d X [2 N, K1 dl] (building rows, then story rows) is filled in place: block 0 of either half = its dl columns
+    // of d acc (two strided copies, one launch), blocks 1 .. L by the chain, whose 2 dl columns are written as two
+    // groups of dl -- one per half -- instead of a [N, K1, 2 dl] matrix that a regrouping launch would take apart
+    {
+        const int64_t f = (int64_t)sizeof(float);
+        void* const dst[2] = {b.dX, b.dX + half};
+        const void* const src[2] = {b.dacc, b.dacc + dl};
+        const int64_t dp[2] = {f * ldx, f * ldx}, sp[2] = {f * W2c, f * W2c}, wd[2] = {f * dl, f * dl}, rw[2] = {N, N};
+        BG_TRY(bg_fill_copy_batch(2, dst, dp, src, sp, wd, rw, s));
     }
-    BG_TRY(bg_spmm_chain_f32(b.dYs, ldy, h.a_rowptr, h.a_col, h.a_count, BG_SCALE_DIV, nullptr, BG_SCALE_NONE,
-                             h.blk_ptr, h.blk_n, h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg,
-                             nullptr, 0, 0, b.dYs + W2c, ldy, W2c, h.L, W2c, h.basis ? BG_CHAIN_CHEB : BG_CHAIN_POWER, s));
-    BG_TRY(bg_regroup_f32(b.dYs, b.dX, N, K1, 2, dl, 1, s));
+    BG_TRY(bg_spmm_chain_grouped_f32(b.dacc, W2c, h.a_rowptr, h.a_col, h.a_count, BG_SCALE_DIV, nullptr, BG_SCALE_NONE,
+                                     h.blk_ptr, h.blk_n, h.blk_max_rows, h.blk_max_nnz, h.blk_max_deg,
+                                     nullptr, 0, 0, b.dX + dl, ldx, dl, h.L, W2c, h.basis ? BG_CHAIN_CHEB : BG_CHAIN_POWER,
+                                     dl, 0, 0, half, s));
     BG_TRY(mm(2 * N, H2, K1 * dl, b.dX, K1 * dl, Wl, H2, 0, b.dG2, nullptr, nullptr, s));                   // d G2 = dX Wl
     BG_TRY(bg_gather_arg_pair_f32(b.dG2, H2, b.arg_b, b.dgp_b, B, b.dG2 + N * H2, H2, b.arg_s, b.dgp_s, S, H2, H2, s));
     // ---- both decoders' backward, one launch each (bg_decoder_bwd_f32: every gradient is rank one).  Penalty share:

@@ -837,7 +837,21 @@ struct ChainArgs {
     // blockIdx.y >= split_y belong to it (no addend)
     int split_y; const float* x0b; int64_t ldxb; float* outb; int64_t ldob; int64_t out_stepb;
     int basis;
+    // column groups (bg_spmm_chain_grouped_f32): the W columns are groups of grp_w; group g of a matrix with a group
+    // step starts g * step elements behind group 0 -- its own [rows, grp_w ..] matrix -- instead of g * grp_w columns
+    // further right.  0 = that matrix is one plain [rows, W] matrix.
+    int grp_w; int64_t x0_gstep, add_gstep, out_gstep;
 };
+
+// a workgroup's column chunk cc lies in one group: move the bases so that `base + row * ld + cc` lands in it
+__device__ __forceinline__ void chain_group_bases(ChainArgs& a, int cc) {
+    if (!a.grp_w) return;
+    const int g = cc / a.grp_w;
+    const int64_t back = (int64_t)g * a.grp_w;
+    if (a.x0_gstep) a.x0 += g * a.x0_gstep - back;
+    if (a.add && a.add_gstep) a.add += g * a.add_gstep - back;
+    if (a.out_gstep) a.out += g * a.out_gstep - back;
+}
 
 // factor of P y_{k-1} at this step of a three-term chain (the subtraction of y_{k-2} starts at step 2)
 __device__ __forceinline__ float chain_factor(int basis, int step, int n_steps) {
@@ -852,6 +866,7 @@ __global__ __launch_bounds__(1024) void k_spmm_chain(ChainArgs a) {
     const int32_t nr = a.blk_ptr[blockIdx.x + 1] - r0;
     const int cc = 4 * blockIdx.y;
     if (nr <= 0 || nr > a.max_rows) return;                 // uniform per workgroup (host checks the plan)
+    chain_group_bases(a, cc);
     float4* buf0 = chain_smem;
     float4* buf1 = chain_smem + a.max_rows;
     float* s_rs = reinterpret_cast<float*>(chain_smem + 2 * (size_t)a.max_rows);
@@ -1017,6 +1032,8 @@ __global__ __launch_bounds__(1024) void k_spmm_chain_short(ChainArgs a) {
     if (a.x0b && (int)blockIdx.y >= a.split_y) {                // uniform per workgroup: the second matrix
         cc = 4 * ((int)blockIdx.y - a.split_y);
         a.x0 = a.x0b; a.ldx = a.ldxb; a.out = a.outb; a.ldo = a.ldob; a.out_step = a.out_stepb; a.add = nullptr;
+    } else {
+        chain_group_bases(a, cc);                               // (never together with a second matrix)
     }
     const int zero_slot = a.max_rows;                           // both images carry one extra, all-zero row
     float4* buf0 = chain_smem;
@@ -1132,23 +1149,29 @@ int bg_spmm_add_f32(const float* x, int64_t ldx, const int32_t* rowptr, const in
     return spmm_dispatch(a, H, (hipStream_t)stream);
 }
 
-int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const int32_t* col,
-                      const float* row_scale, int row_mode, const float* col_scale, int col_mode,
-                      const int32_t* blk_ptr, int64_t n_blk, int64_t max_rows, int64_t max_nnz, int64_t max_deg,
-                      const float* add, int64_t ld_add, int64_t add_step,
-                      float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, int32_t basis,
-                      bgStream stream) {
-    if (n_blk < 0 || W < 0 || n_steps < 0 || max_rows < 0 || max_nnz < 0 || max_deg < 0) return BG_ERR_ARG;
+int bg_spmm_chain_grouped_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                              const float* row_scale, int row_mode, const float* col_scale, int col_mode,
+                              const int32_t* blk_ptr, int64_t n_blk, int64_t max_rows, int64_t max_nnz, int64_t max_deg,
+                              const float* add, int64_t ld_add, int64_t add_step,
+                              float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, int32_t basis,
+                              int64_t grp_w, int64_t x0_gstep, int64_t add_gstep, int64_t out_gstep, bgStream stream) {
+    if (n_blk < 0 || W < 0 || n_steps < 0 || max_rows < 0 || max_nnz < 0 || max_deg < 0 || grp_w < 0) return BG_ERR_ARG;
     if (basis != BG_CHAIN_POWER && basis != BG_CHAIN_CHEB && basis != BG_CHAIN_CLENSHAW) return BG_ERR_ARG;
     if (n_blk == 0 || W == 0 || n_steps == 0 || max_rows == 0) return BG_OK;
-    if (!x0 || !rowptr || !col || !blk_ptr || !out || ldx < W || ldo < W || (add && ld_add < W)) return BG_ERR_ARG;
+    if (grp_w == 0 && (x0_gstep || add_gstep || out_gstep)) return BG_ERR_ARG;
+    if (grp_w > 0 && (grp_w % 4 != 0 || W % grp_w != 0 || grp_w > (1 << 20))) return BG_ERR_SHAPE;
+    // a matrix with a group step holds grp_w columns per group, a plain one all W
+    const int64_t wx = x0_gstep ? grp_w : W, wa = add_gstep ? grp_w : W, wo = out_gstep ? grp_w : W;
+    if (!x0 || !rowptr || !col || !blk_ptr || !out || ldx < wx || ldo < wo || (add && ld_add < wa)) return BG_ERR_ARG;
     if ((row_mode && !row_scale) || (col_mode && !col_scale)) return BG_ERR_ARG;
     if (W % 4 != 0 || n_blk > 65535 || W / 4 > 65535 || n_steps > (1 << 20)) return BG_ERR_SHAPE;
     if (!bg_aligned16(x0) || !bg_aligned16(out) || ldx % 4 != 0 || ldo % 4 != 0 || out_step % 4 != 0 ||
-        (add && (!bg_aligned16(add) || ld_add % 4 != 0 || add_step % 4 != 0))) return BG_ERR_ALIGN;
+        (add && (!bg_aligned16(add) || ld_add % 4 != 0 || add_step % 4 != 0)) || x0_gstep % 4 != 0 || add_gstep % 4 != 0 ||
+        out_gstep % 4 != 0) return BG_ERR_ALIGN;
     if (max_rows > (1 << 20) || max_nnz > (1 << 26)) return BG_ERR_SHAPE;
     ChainArgs a{x0, ldx, rowptr, col, row_scale, row_mode, col_scale, col_mode, blk_ptr, (int)max_rows, (int)max_nnz,
-                add, ld_add, add_step, out, ldo, out_step, (int)n_steps, 0, nullptr, 0, nullptr, 0, 0, (int)basis};
+                add, ld_add, add_step, out, ldo, out_step, (int)n_steps, 0, nullptr, 0, nullptr, 0, 0, (int)basis,
+                (int)grp_w, x0_gstep, add_gstep, out_gstep};
     hipStream_t s = (hipStream_t)stream;
     if (max_deg <= 8 && max_rows <= (max_deg <= 6 ? 3072 : 2048)) {
         // short rows: indices in registers, 1 to 3 rows per thread (4 rows per thread spills, 3 do with 8 slots)
@@ -1159,6 +1182,17 @@ int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const
     lds = chain_lds_bytes(max_rows, max_nnz, false);
     if (lds <= BG_CHAIN_LDS_LIMIT) return launch_chain<false>(a, n_blk, W, lds, s);
     return BG_ERR_SHAPE;          // a diagonal block does not fit in LDS: run the steps as separate launches
+}
+
+int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                      const float* row_scale, int row_mode, const float* col_scale, int col_mode,
+                      const int32_t* blk_ptr, int64_t n_blk, int64_t max_rows, int64_t max_nnz, int64_t max_deg,
+                      const float* add, int64_t ld_add, int64_t add_step,
+                      float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, int32_t basis,
+                      bgStream stream) {
+    return bg_spmm_chain_grouped_f32(x0, ldx, rowptr, col, row_scale, row_mode, col_scale, col_mode, blk_ptr, n_blk, max_rows,
+                                     max_nnz, max_deg, add, ld_add, add_step, out, ldo, out_step, n_steps, W, basis, 0, 0, 0, 0,
+                                     stream);
 }
 
 int bg_spmm_chain_pair_f32(const float* x0, int64_t ldx, float* out, int64_t ldo, int64_t out_step, int64_t W,

@@ -176,6 +176,22 @@ int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const
                       float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, int32_t basis,
                       bgStream stream);
 
+/* bg_spmm_chain_f32 on matrices kept as column GROUPS: the W columns are W / grp_w groups of grp_w columns
+ * (grp_w % 4 == 0), and for a matrix with a non-zero group step (x0_gstep / add_gstep / out_gstep, in elements) group g
+ * is its own [rows, grp_w] column block starting g * step elements behind group 0 -- the same row pitch, step and
+ * add_step as group 0 -- instead of lying g * grp_w columns further right.  A step of 0 leaves that matrix a plain
+ * [rows, W] one; all steps 0 (grp_w 0) is bg_spmm_chain_f32.  Same kernels, same arithmetic per column: the result
+ * equals regrouping the operands, running the plain chain and regrouping back (bg_regroup_f32), bit for bit.
+ * replaces: the permute / reshape copies either side of the penalty's chains in the critic head (the chain's operand
+ * is a product's [2 N, (L+1) dl] output, rows = building and story halves; Model/losses.py:83-88 through
+ * Model/models.py:150-172 transposed).                                                                           */
+int bg_spmm_chain_grouped_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                              const float* row_scale, int row_mode, const float* col_scale, int col_mode,
+                              const int32_t* blk_ptr, int64_t n_blk, int64_t max_rows, int64_t max_nnz, int64_t max_deg,
+                              const float* add, int64_t ld_add, int64_t add_step,
+                              float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W, int32_t basis,
+                              int64_t grp_w, int64_t x0_gstep, int64_t add_gstep, int64_t out_gstep, bgStream stream);
+
 /* bg_spmm_chain_f32 (no addend) on TWO matrices under the same operator and step count in one launch: the
  * column chunks of both fill the chip side by side (a chain's time does not depend on its width).  Short-row
  * plans only (max_deg <= 8 and max_rows <= 2048, or max_deg <= 6 and max_rows <= 3072), else BG_ERR_SHAPE and the caller launches them one by one.

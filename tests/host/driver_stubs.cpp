@@ -197,6 +197,17 @@ int bg_scatter_arg_batch_f32(const float* g, int64_t ldg, int64_t g_step, const 
     rec(40, a, sizeof(a) / 8);
     return 0;
 }
+int bg_spmm_chain_grouped_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* row_scale,
+                              int row_mode, const float* col_scale, int col_mode, const int32_t* blk_ptr, int64_t n_blk,
+                              int64_t max_rows, int64_t max_nnz, int64_t max_deg, const float* add, int64_t ld_add,
+                              int64_t add_step, float* out, int64_t ldo, int64_t out_step, int64_t n_steps, int64_t W,
+                              int32_t basis, int64_t grp_w, int64_t x0_gstep, int64_t add_gstep, int64_t out_gstep, bgStream) {
+    int64_t a[] = {P(x0), ldx, P(rowptr), P(col), P(row_scale), row_mode, P(col_scale), col_mode, P(blk_ptr), n_blk,
+                   max_rows, max_nnz, max_deg, P(add), ld_add, add_step, P(out), ldo, out_step, n_steps, W, basis,
+                   grp_w, x0_gstep, add_gstep, out_gstep};
+    rec(46, a, sizeof(a) / 8);
+    return 0;
+}
 int bg_spmm_chain_f32(const float* x0, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* row_scale,
                       int row_mode, const float* col_scale, int col_mode, const int32_t* blk_ptr, int64_t n_blk,
                       int64_t max_rows, int64_t max_nnz, int64_t max_deg, const float* add, int64_t ld_add, int64_t add_step,

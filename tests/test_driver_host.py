@@ -543,6 +543,30 @@ def _check_critic_calls(calls, R, h):
                 assert (Rr, Rp) in ((B, 0), (S, 0)) and not (g_b1 or g_w2 or g_b2 or w1 or w2 or b1 or dgp)
         elif kind in (43, 44, 45):
             assert a == [2], tag                          # a pair launcher's marker: its two single calls follow
+        elif kind == 27:
+            assert a == [2], tag                          # bg_fill_copy_batch's marker: its jobs follow as kind 20 / 25
+        elif kind == 46:
+            (x0, ldx, rp, col, rsc, rm, csc, cm, blk, n_blk, mr, mn, md, add, ld_add, add_step, out, ldo, out_step,
+             n_steps, W, basis, gw, xg, ag, og) = a
+            # the penalty's chains on the product's [2 N, K1 dl] matrices: two column groups of dl, one per half of the rows
+            assert basis == ((2 if add else 1) if h.basis else 0) and W == 2 * gw and gw == h.dl and n_steps == h.L, tag
+            R.check(rp, (N + 1) * 4, tag + " rowptr")
+            R.check(blk, (n_blk + 1) * 4, tag + " blk_ptr")
+            assert (rm != 0) != (cm != 0)
+            R.check(rsc if rm else csc, N * f, tag + " scale")
+            for g_ in range(2):
+                wx = gw if xg else W
+                R.check(x0 + g_ * xg * f, ((N - 1) * ldx + wx) * f, tag + " x0 group %d" % g_)
+                for k in range(1, n_steps + 1):
+                    if add:
+                        assert ag, tag
+                        R.check(add + (g_ * ag + (k - 1) * add_step) * f, ((N - 1) * ld_add + gw) * f, tag + " add_%d" % k)
+                    if out_step or k == n_steps:
+                        wo = gw if og else W
+                        R.check(out + (g_ * og + (k - 1) * out_step) * f, ((N - 1) * ldo + wo) * f, tag + " out_%d" % k)
+                if not xg and not og:
+                    break
+            assert (xg != 0) != (og != 0) and xg in (0, N * ldx) and og in (0, N * ldo), tag
         elif kind == 38:
             Rr, H2, Hd, X, ldx, w1, ldw1, b1, w2, b2, val, gp = a
             assert H2 == h.H2 and Hd == h.Hd and Rr in (B, S, 2 * B, 2 * S)
@@ -564,10 +588,12 @@ def test_critic_head_host_sequence_and_extents(drv, N, S, B, basis):
     # 39: the three label sets pooled by one launch per level (voxel -> story, story -> graph)
     # 45 / 44 / 43: both decoders, both scatters, both gathers by one launch each (the stub lists the pair's two single
     # calls behind the marker)
-    assert [k for k, _ in fwd] == [10, 1, 28, 1, 39, 39, 45, 38, 38, 12, 44, 13, 13, 1, 10, 14, 15]
+    # 46: the penalty's chain reading the product's output as two column groups (no regrouping launch, kind 10, before it)
+    assert [k for k, _ in fwd] == [10, 1, 28, 1, 39, 39, 45, 38, 38, 12, 44, 13, 13, 1, 46, 15]
     # 37: a decoder's whole backward (penalty share included) as one launch; 40: real and fake scattered by one launch
     # (the voxel-level scatter also leaves the two sets' sum: no addition launch, kind 18, between the two products)
-    assert [k for k, _ in bwd] == [16, 20, 14, 10, 1, 43, 12, 12, 37, 40, 37, 40, 19, 19]
+    # (27, 20, 20: block 0 of d X's two halves copied from d acc by one launch; 46 writes blocks 1 .. L in place)
+    assert [k for k, _ in bwd] == [16, 27, 20, 20, 46, 1, 43, 12, 12, 37, 40, 37, 40, 19, 19]
     sums = [a[13] for k, a in bwd if k == 40]
     assert sums[0] == 0 and R.check(sums[1], N * 256 * 4, "sum of the sets") == "workspace"
     _check_critic_calls(fwd, R, h)

@@ -854,6 +854,62 @@ def test_operator_chain_pair_equals_two_chains(cuda, preset, ragged, basis):
         assert float(Z1[:, -W1:].abs().max()) > 0 and float(Z2[:, L * W2:(L + 1) * W2].abs().max()) > 0
 
 
+@pytest.mark.parametrize("basis", [0, 1])
+@pytest.mark.parametrize("preset,ragged", [("small", True), ("dataset", False), ("dataset", "jitter")])
+def test_operator_chain_on_column_groups_equals_regrouped_operands(cuda, preset, ragged, basis):
+    """bg_spmm_chain_grouped_f32: a chain whose W = P w columns are P groups living in P separate [N, K w] matrices (the
+    layout a product over P N stacked rows leaves) against bg_regroup_f32 + the plain chain (+ bg_regroup_f32 back): bit
+    for bit, Horner / Clenshaw form reading groups and the powers form writing them, all three kernel variants."""
+    from building_gan_amd import _lib, ops
+    import dataclasses
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g, p = _plan(_batch(preset, 17, ragged), cuda)
+    gen = torch.Generator().manual_seed(31)
+    N, L, P, w = p.Nv, 12, 2, 8
+    K1, W = L + 1, P * w
+    X = (torch.rand(P * N, K1 * w, generator=gen) * 2 - 1).to(cuda)          # what the product leaves: [P][N, K1 w]
+    d0 = (torch.rand(N, W, generator=gen) * 2 - 1).to(cuda)
+
+    def chain(op, blk, x0, ldx, add, ld_add, add_step, out, ldo, out_step, bas, grp):
+        c = op.csr
+        fn = lib.bg_spmm_chain_grouped_f32
+        rc = fn(x0, ldx, c.rowptr.data_ptr(), c.col.data_ptr(), op.row_scale.data_ptr() if op.row_scale is not None else None,
+                op.row_mode, op.col_scale.data_ptr() if op.col_scale is not None else None, op.col_mode, blk.ptr.data_ptr(),
+                blk.n, blk.max_rows, blk.max_nnz, blk.max_deg, add, ld_add, add_step, out, ldo, out_step, L, W, bas, *grp, st)
+        assert rc == 0, rc
+    f = 4
+    half = N * K1 * w
+    for blk in (p.vox_blocks, dataclasses.replace(p.vox_blocks, max_deg=8), dataclasses.replace(p.vox_blocks, max_deg=1 << 20)):
+        if blk.max_deg == 8 and blk.max_rows > 2048:
+            continue                                                    # (8 slots x 3 rows: that plan takes the LDS-index kernel anyway)
+        # ---- Horner / Clenshaw over the transposed operator, operands read in groups
+        Ys = torch.empty(N, K1, P, w, device=cuda)
+        assert lib.bg_regroup_f32(X.data_ptr(), Ys.data_ptr(), N, K1, P, w, 0, st) == 0
+        assert torch.equal(Ys, X.view(P, N, K1, w).permute(1, 2, 0, 3))
+        ref = ops.horner_chain_raw(p.vox_mean.T, Ys.view(N, K1, W), L, W, blk, basis)
+        acc = torch.full((N, W), float("nan"), device=cuda)
+        chain(p.vox_mean.T, blk, X.data_ptr() + f * L * w, K1 * w, X.data_ptr() + f * (L - 1) * w, K1 * w, -w,
+              acc.data_ptr(), W, 0, 2 if basis else 0, (w, half, half, 0))
+        assert torch.equal(acc, ref)
+        # ---- powers, results written in groups (block 0 of the grouped matrix is not the chain's to write)
+        Z = torch.zeros(N, K1 * W, device=cuda)
+        Z[:, :W] = d0
+        ops.power_chain_raw(p.vox_mean, Z, L, W, blk, basis)
+        want = torch.empty(P * N, K1 * w, device=cuda)
+        assert lib.bg_regroup_f32(Z.data_ptr(), want.data_ptr(), N, K1, P, w, 1, st) == 0
+        got = torch.full((P * N, K1 * w), float("nan"), device=cuda)
+        chain(p.vox_mean, blk, d0.data_ptr(), W, None, 0, 0, got.data_ptr() + f * w, K1 * w, w, 1 if basis else 0, (w, 0, 0, half))
+        assert torch.equal(got[:, w:], want[:, w:]) and bool(torch.isnan(got[:, :w]).all())
+    # argument checks: group width must divide W and be a multiple of 4; steps without a width are refused
+    blk = p.vox_blocks
+    c = p.vox_mean.csr
+    bad = lambda *grp: lib.bg_spmm_chain_grouped_f32(
+        d0.data_ptr(), W, c.rowptr.data_ptr(), c.col.data_ptr(), p.vox_mean.row_scale.data_ptr(), p.vox_mean.row_mode, None, 0,
+        blk.ptr.data_ptr(), blk.n, blk.max_rows, blk.max_nnz, blk.max_deg, None, 0, 0, got.data_ptr(), K1 * w, w, L, W, 0, *grp, st)
+    assert bad(6, 0, 0, half) == -2 and bad(12, 0, 0, half) == -2 and bad(0, 0, 0, half) == -1 and bad(w, 0, 0, half + 2) == -3
+
+
 def test_operator_chain_rejects_oversized_blocks(cuda):
     """A diagonal block that cannot live in LDS is refused (BG_ERR_SHAPE); the host then runs the steps one by one."""
     from building_gan_amd import _lib, ops
