@@ -801,9 +801,8 @@ extern "C" int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGener
             float* story = g.story_all + (int64_t)i * S * H;
             BG_TRY(bg_story_bwd_f32(gin, H, g.y[i], H, v, H, p->st_rowptr, p->st_col, p->st_count, 0.01f, gz, H, gterm, H,
                                     story, H, S, H, s));
-            // (the weight gradients of all block calls: one product each after the loop, over the stacked gz / gterm)
-            BG_TRY(bg_spmm_f32(story, H, p->sb_rowptr, p->sb_col, nullptr, nullptr, p->sb_count, BG_SCALE_DIV, nullptr,
-                               BG_SCALE_NONE, g.sb_all + (int64_t)i * S * H, H, S, H, s));
+            // (the weight gradients of all block calls: one product each after the loop, over the stacked gz / gterm;
+            //  the story -> building mean of every call's story term, which only that product reads: one launch there)
             {
                 const float* A[4] = {gz, nullptr, nullptr, nullptr};
                 const int64_t ld[4] = {H, 0, 0, 0}, Ks[4] = {H, 0, 0, 0};
@@ -824,6 +823,8 @@ extern "C" int bg_gstack_backward_f32(const bgGeneratorWeights* w, const bgGener
     }
     // shared weights: the sum over the calls IS the reduction dimension of one product over the stacked rows
     if (have_blk) {
+        BG_TRY(bg_spmm_batch_f32(g.story_all, H, S * H, p->sb_rowptr, p->sb_col, p->sb_count, BG_SCALE_DIV, nullptr,
+                                 BG_SCALE_NONE, g.sb_all, H, S * H, S, H, g.n_blk, s));
         BG_TRY(bg_tile_f32(pdm4, g.pdm4_rep, Nv * 4, g.n_blk, s));
         const float* Bs[4] = {g.vb, g.gm_all, g.pdm4_rep, nullptr};
         const int64_t ldb[4] = {H, H, 4, 0}, Ns[4] = {H, H, 4, 0};

@@ -19,6 +19,8 @@ struct SpmmArgs {
     int nt_store;                     // write the result with non-temporal stores (set by spmm_dispatch for big outputs)
     // optional gathered addend, last in the sum: + gs(grow[i]) applied to gadd[grow[i], :]
     const float* gadd; int64_t ldga; const int32_t* grow; const float* gscale; int gmode;
+    // bg_spmm_batch_f32: blockIdx.y = the batch, which reads x + y * x_step and writes out + y * out_step
+    int64_t x_step, out_step; int n_batch;
 };
 
 __device__ __forceinline__ float apply_scale(float v, float s, int mode) {
@@ -93,6 +95,7 @@ __device__ __forceinline__ void spmm_vec_body(const SpmmArgs& a, int64_t blk) {
 
 template <int LPR, bool GENERAL>
 __global__ __launch_bounds__(256) void k_spmm_vec(SpmmArgs a) {
+    a.x += (int64_t)blockIdx.y * a.x_step; a.out += (int64_t)blockIdx.y * a.out_step;       // (0 outside bg_spmm_batch_f32)
     spmm_vec_body<LPR, GENERAL>(a, xcd_remap(blockIdx.x, gridDim.x));
 }
 
@@ -202,7 +205,7 @@ int launch_spmm_vec(const SpmmArgs& a, hipStream_t s) {
     int lpr = 1;
     while (lpr < a.H4) lpr <<= 1;
     int rpb = 4 * (64 / lpr);
-    int grid = bg_grid_for(a.n_rows, rpb, 0x7fffffff);
+    const dim3 grid((unsigned)bg_grid_for(a.n_rows, rpb, 0x7fffffff), (unsigned)(a.n_batch > 1 ? a.n_batch : 1));
     switch (lpr) {
         case 1: k_spmm_vec<1, GENERAL><<<grid, 256, 0, s>>>(a); break;
         case 2: k_spmm_vec<2, GENERAL><<<grid, 256, 0, s>>>(a); break;
@@ -1131,6 +1134,32 @@ int bg_spmm_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_
     SpmmArgs a{x, ldx, rowptr, col, edge_w, eperm, row_scale, row_mode, col_scale, col_mode, out, ldo, n_rows, 0,
                nullptr, 0, nullptr, 0};
     return spmm_dispatch(a, H, (hipStream_t)stream);
+}
+
+// n_batch matrices under ONE operator in one launch: batch b reads x + b * x_step and writes out + b * out_step
+// (the generator stack's backward applies the story -> building mean to every block call's story term at once).
+// The 16-byte row form only (H % 4 == 0, H <= 256, aligned operands); other shapes run bg_spmm_f32 per batch.
+int bg_spmm_batch_f32(const float* x, int64_t ldx, int64_t x_step, const int32_t* rowptr, const int32_t* col,
+                      const float* row_scale, int row_mode, const float* col_scale, int col_mode,
+                      float* out, int64_t ldo, int64_t out_step, int64_t n_rows, int64_t H, int64_t n_batch, bgStream stream) {
+    if (n_rows < 0 || H < 0 || n_batch < 0 || n_batch > 65535) return BG_ERR_ARG;
+    if (n_rows == 0 || H == 0 || n_batch == 0) return BG_OK;
+    if (!x || !rowptr || !out || ldx < H || ldo < H) return BG_ERR_ARG;
+    if ((row_mode && !row_scale) || (col_mode && !col_scale)) return BG_ERR_ARG;
+    const bool vec = H % 4 == 0 && H <= 256 && ldx % 4 == 0 && ldo % 4 == 0 && x_step % 4 == 0 && out_step % 4 == 0 &&
+                     bg_aligned16(x) && bg_aligned16(out);
+    if (!vec || n_batch == 1) {
+        for (int64_t b = 0; b < n_batch; ++b) {
+            int rc = bg_spmm_f32(x + b * x_step, ldx, rowptr, col, nullptr, nullptr, row_scale, row_mode, col_scale, col_mode,
+                                 out + b * out_step, ldo, n_rows, H, stream);
+            if (rc != BG_OK) return rc;
+        }
+        return BG_OK;
+    }
+    SpmmArgs a{x, ldx, rowptr, col, nullptr, nullptr, row_scale, row_mode, col_scale, col_mode, out, ldo, n_rows, (int)(H / 4),
+               nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, x_step, out_step, (int)n_batch};
+    const bool general = !col || col_mode;
+    return general ? launch_spmm_vec<true>(a, (hipStream_t)stream) : launch_spmm_vec<false>(a, (hipStream_t)stream);
 }
 
 int bg_spmm_add_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,

@@ -212,7 +212,7 @@ class Attention(nn.Module):
             return None, None
         W1, b1, W2, b2 = mods[0].weight, mods[0].bias, mods[1].weight, mods[1].bias
         Wd = ops.MatMul.apply(W2, W1, False, False)                                    # [2, H]
-        bd = torch.addmv(b2, W2, b1)
+        bd = linear(b1.view(1, -1), W2, b2).view(-1)                                   # W2 b1 + b2 (the library's Linear)
         Wcat = torch.cat([self.NN_v.weight, Wd, ops.zeros_view(2, W1.shape[1], device=Wd.device)], dim=0)  # [H + 4, H]
         bcat = torch.cat([self.NN_v.bias, bd, ops.zeros_view(2, device=bd.device)])
         return Wcat, bcat

@@ -137,6 +137,15 @@ int bg_spmm_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_
                 const float* row_scale, int row_mode, const float* col_scale, int col_mode,
                 float* out, int64_t ldo, int64_t n_rows, int64_t H, bgStream stream);
 
+/* bg_spmm_f32 (no edge weights) on n_batch matrices under ONE operator in one launch: batch b reads x + b * x_step
+ * and writes out + b * out_step (steps in elements).  Same kernel and arithmetic as the single call, bit for bit.  The
+ * one-launch form takes H % 4 == 0, H <= 256 and 16-byte aligned operands; other shapes run bg_spmm_f32 per batch.
+ * replaces: the story -> building mean of Model/models.py:166-168 under autograd, which the backward of the generator's
+ * 11 VoxelBlock calls needs once per call for the shared weight's gradient -- here once for all calls.            */
+int bg_spmm_batch_f32(const float* x, int64_t ldx, int64_t x_step, const int32_t* rowptr, const int32_t* col,
+                      const float* row_scale, int row_mode, const float* col_scale, int col_mode,
+                      float* out, int64_t ldo, int64_t out_step, int64_t n_rows, int64_t H, int64_t n_batch, bgStream stream);
+
 /* bg_spmm_f32 (without edge weights) plus up to two addend matrices and one GATHERED addend fused into the
  * store:  out[i,:] = rs(i) * sum_k cs(c_k) x[c_k,:] + add1[i,:] + add2[i,:] + gs(grow[i]) gadd[grow[i],:]
  * (add1 / add2 / gadd may be NULL; gs = the gmode scale by gscale[grow[i]], BG_SCALE_*; the caller keeps

@@ -58,6 +58,17 @@ int bg_spmm_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_
     rec(2, a, sizeof(a) / 8);
     return 0;
 }
+// a marker (kind 47: the batch count) followed by each batch as the single call it replaces
+int bg_spmm_batch_f32(const float* x, int64_t ldx, int64_t x_step, const int32_t* rowptr, const int32_t* col,
+                      const float* row_scale, int row_mode, const float* col_scale, int col_mode, float* out, int64_t ldo,
+                      int64_t out_step, int64_t n_rows, int64_t H, int64_t n_batch, bgStream stream) {
+    int64_t a[] = {n_batch};
+    rec(47, a, 1);
+    for (int64_t b = 0; b < n_batch; ++b)
+        bg_spmm_f32(x + b * x_step, ldx, rowptr, col, nullptr, nullptr, row_scale, row_mode, col_scale, col_mode,
+                    out + b * out_step, ldo, n_rows, H, stream);
+    return 0;
+}
 int bg_spmm_add_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* row_scale,
                     int row_mode, const float* col_scale, int col_mode, const float* add1, int64_t ld1, const float* add2,
                     int64_t ld2, const float* gadd, int64_t ldg, const int32_t* grow, const float* gs, int gmode,

@@ -819,6 +819,8 @@ def _check_generic(calls, R, z):
         elif kind == 34:
             src, dst, n, reps = a
             R.check(src, n * 4, tag + " src"); R.check(dst, n * reps * 4, tag + " dst")
+        elif kind == 47:
+            assert a == [11], tag                                  # bg_spmm_batch_f32's marker: the 11 block calls follow as kind 2
         else:
             raise AssertionError("unexpected launcher %d" % kind)
 
@@ -842,7 +844,7 @@ def test_gstack_host_sequence_and_extents(drv, Np, Nv, S, Ec, one):
     else:
         att_first_np = [22, red, 23, red, 18, 1]
         att = [22, red, 18, 23, red, 18, 1]
-    blk = [21, 2, 1, 1, 3, 3]
+    blk = [21, 1, 1, 3, 3]          # (the story -> building mean of the calls' story terms: one launch after the loop, kind 47)
     seq = [25] + att_last
     n_att_seen = 1
     for i in range(10, -1, -1):                                           # ops in reverse: ..., block i, (attention before it)
@@ -852,7 +854,7 @@ def test_gstack_host_sequence_and_extents(drv, Np, Nv, S, Ec, one):
         if (i - 1) % 2 == 0 and (i - 1) != 0 and i - 1 >= 0:             # an attention call follows block i-1
             seq += att_first_np if n_att_seen == 1 else att
             n_att_seen += 1
-    seq += (att_first_np if n_att_seen == 1 else att) + [34, 19, 19] + [19, 17, 17] + [19, 17, 19, 17, 1]
+    seq += (att_first_np if n_att_seen == 1 else att) + [47] + [2] * 11 + [34, 19, 19] + [19, 17, 17] + [19, 17, 19, 17, 1]
     assert [k for k, _ in bwd] == seq
     # the forward's saved pieces live in the workspace; the last call writes the caller's outputs
     att_calls = [a for k, a in fwd if k == 5]

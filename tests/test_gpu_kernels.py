@@ -1349,6 +1349,32 @@ def test_fills_and_copies_as_one_launch(cuda):
     assert lib.bg_fill_copy_batch(0, None, None, None, None, None, None, st) == 0
 
 
+@pytest.mark.parametrize("H,nb", [(128, 11), (256, 3), (8, 2), (6, 3), (320, 2)])
+def test_one_operator_on_several_matrices_in_one_launch(cuda, H, nb):
+    """bg_spmm_batch_f32 (the story -> building mean of every block call's story term at once) against one bg_spmm_f32 per
+    matrix: identical bits; widths outside the one-launch form (H % 4 != 0, H > 256) take the per-matrix path inside."""
+    from building_gan_amd import _lib, ops
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g, p = _plan(_batch("dataset", 23, "jitter"), cuda)
+    op = p.ops["story_building_mean"]
+    c = op.csr
+    S = c.n_rows
+    gen = torch.Generator().manual_seed(H + nb)
+    x = (torch.rand(nb, S, H, generator=gen) * 2 - 1).to(cuda)
+    ref = torch.stack([ops.spmm_raw(op, x[b]) for b in range(nb)])
+    out = torch.full((nb, S, H), float("nan"), device=cuda)
+    rs = op.row_scale.data_ptr() if op.row_scale is not None else None
+    cs = op.col_scale.data_ptr() if op.col_scale is not None else None
+    assert lib.bg_spmm_batch_f32(x.data_ptr(), H, S * H, c.rowptr.data_ptr(), c.col.data_ptr(), rs, op.row_mode, cs, op.col_mode,
+                                 out.data_ptr(), H, S * H, S, H, nb, st) == 0
+    assert torch.equal(out, ref)
+    assert lib.bg_spmm_batch_f32(x.data_ptr(), H, S * H, c.rowptr.data_ptr(), c.col.data_ptr(), rs, op.row_mode, cs, op.col_mode,
+                                 out.data_ptr(), H, S * H, S, H, 0, st) == 0
+    assert lib.bg_spmm_batch_f32(None, H, S * H, c.rowptr.data_ptr(), c.col.data_ptr(), rs, op.row_mode, cs, op.col_mode,
+                                 out.data_ptr(), H, S * H, S, H, nb, st) == -1
+
+
 @pytest.mark.parametrize("n_rows,S,B,H", [(11520, 88, 8, 256), (301, 7, 2, 64), (40, 40, 1, 8)])
 def test_pair_launchers_equal_their_two_single_calls(cuda, n_rows, S, B, H):
     """bg_decoder_fwd_pair_f32, bg_scatter_arg_pair_f32, bg_gather_arg_pair_f32 (two independent small launches of the
