@@ -836,8 +836,8 @@ struct ChainArgs {
     const float* add; int64_t ld_add; int64_t add_step;
     float* out; int64_t ldo; int64_t out_step;
     int n_steps;
-    // optional second matrix under the same operator and step count (k_spmm_chain_short only): the launch's columns
-    // from split_y on belong to it (no addend)
+    // optional second matrix under the same operator and step count (k_spmm_chain_short only): column chunks
+    // blockIdx.y >= split_y belong to it (no addend)
     int split_y; const float* x0b; int64_t ldxb; float* outb; int64_t ldob; int64_t out_stepb;
     int basis;
     // column groups (bg_spmm_chain_grouped_f32): the W columns are groups of grp_w; group g of a matrix with a group
@@ -964,94 +964,58 @@ int launch_chain(const ChainArgs& a, int64_t n_blk, int64_t W, size_t lds, hipSt
 
 // Step loop of k_spmm_chain_short.  KIND: 1 = rows divided by rs, unit column weights (the mean-aggregation operator);
 // 2 = column weights only (its transpose); 0 = whatever the arguments say.  Same arithmetic in every KIND.
-// CW columns of a row: what a lane of the short-row chain kernel owns (4 = one 16-byte access, or 2)
-template <int CW> struct alignas(4 * CW) CVec { float v[CW]; };
-template <int CW> __device__ __forceinline__ CVec<CW> cv_zero() {
-    CVec<CW> z;
-#pragma unroll
-    for (int k = 0; k < CW; ++k) z.v[k] = 0.f;
-    return z;
-}
-template <int CW> __device__ __forceinline__ CVec<CW> cv_ld(const float* p) { return *reinterpret_cast<const CVec<CW>*>(p); }
-template <int CW> __device__ __forceinline__ void cv_st(float* p, const CVec<CW>& x) { *reinterpret_cast<CVec<CW>*>(p) = x; }
-
-// Step loop of k_spmm_chain_short.  KIND: 1 = rows divided by rs, unit column weights (the mean-aggregation operator);
-// 2 = column weights only (its transpose); 0 = whatever the arguments say.  Same arithmetic per element in every KIND
-// and every column width CW.
-template <int CW, int RPT, int DEG, bool HAS_ADD, int KIND>
-__device__ __forceinline__ void chain_short_steps(const ChainArgs& a, CVec<CW>* buf0, CVec<CW>* buf1,
+template <int RPT, int DEG, bool HAS_ADD, int KIND>
+__device__ __forceinline__ void chain_short_steps(const ChainArgs& a, float4* buf0, float4* buf1,
                                                   const int32_t (&cols)[RPT][DEG], const float (&wts)[RPT][DEG],
                                                   const float (&rs)[RPT], int nr, int32_t r0, int cc, int tid, int nt) {
     const bool use_w = KIND == 2 || (KIND == 0 && a.col_mode);
-    // A step is a few LDS reads and a barrier -- shorter than the round trip of its addend, which the launch before this
-    // one has just written (nothing of it is in L2).  The addends of the next AHEAD steps are kept in flight in a ring of
-    // registers (as many as the register file holds beside the indices); the ring indices are compile-time, so the step
-    // loop runs in groups of AHEAD.
-    constexpr int BUDGET = DEG <= 6 ? (RPT == 3 && CW == 4 ? 12 : 24) : (RPT == 1 ? 16 : 8);
-    constexpr int FIT = BUDGET / (CW * RPT), CAP = RPT == 1 ? 6 : (RPT == 2 ? 3 : 1);      // (a group of steps is unrolled:
-    constexpr int AHEAD = !HAS_ADD ? 1 : (FIT < 1 ? 1 : (FIT > CAP ? CAP : FIT));          //  long groups cost registers too)
-    CVec<CW> ring[AHEAD][RPT];
-    if (HAS_ADD) {
+    float4 ad_next[RPT];
 #pragma unroll
-        for (int d = 0; d < AHEAD; ++d)
-#pragma unroll
-            for (int i = 0; i < RPT; ++i) {
-                ring[d][i] = cv_zero<CW>();
-                const int r = tid + i * nt;
-                if (d < a.n_steps && r < nr) ring[d][i] = cv_ld<CW>(a.add + (int64_t)d * a.add_step + ((int64_t)r0 + r) * a.ld_add + cc);
-            }
+    for (int i = 0; i < RPT; ++i) {
+        ad_next[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int r = tid + i * nt;
+        if (HAS_ADD && r < nr) ad_next[i] = bg_ld4(a.add + ((int64_t)r0 + r) * a.ld_add + cc);
     }
-    for (int base = 0; base < a.n_steps; base += AHEAD) {
+    for (int step = 1; step <= a.n_steps; ++step) {
+        const float4* src = (step & 1) ? buf0 : buf1;
+        float4* dst = (step & 1) ? buf1 : buf0;
+        float* outk = (a.out_step != 0 || step == a.n_steps) ? a.out + (int64_t)(step - 1) * a.out_step : nullptr;
+        const float fac = chain_factor(a.basis, step, a.n_steps);
 #pragma unroll
-        for (int d = 0; d < AHEAD; ++d) {
-            const int step = base + d + 1;
-            if (step > a.n_steps) break;                     // uniform
-            const CVec<CW>* src = (step & 1) ? buf0 : buf1;
-            CVec<CW>* dst = (step & 1) ? buf1 : buf0;
-            float* outk = (a.out_step != 0 || step == a.n_steps) ? a.out + (int64_t)(step - 1) * a.out_step : nullptr;
-            const float fac = chain_factor(a.basis, step, a.n_steps);
+        for (int i = 0; i < RPT; ++i) {
+            const int r = tid + i * nt;
+            if (r < nr) {
+                const int64_t grow = (int64_t)r0 + r;
+                const float4 ad = ad_next[i];
+                if (HAS_ADD && step < a.n_steps)       // the next step's addend travels while this step computes
+                    ad_next[i] = bg_ld4(a.add + (int64_t)step * a.add_step + grow * a.ld_add + cc);
+                float4 v[DEG];
 #pragma unroll
-            for (int i = 0; i < RPT; ++i) {
-                const int r = tid + i * nt;
-                if (r < nr) {
-                    const int64_t grow = (int64_t)r0 + r;
-                    CVec<CW> ad = cv_zero<CW>();
-                    if (HAS_ADD) {
-                        ad = ring[d][i];
-                        if (step - 1 + AHEAD < a.n_steps)    // this slot's next occupant: the addend AHEAD steps on
-                            ring[d][i] = cv_ld<CW>(a.add + (int64_t)(step - 1 + AHEAD) * a.add_step + grow * a.ld_add + cc);
-                    }
-                    CVec<CW> v[DEG];
+                for (int j = 0; j < DEG; ++j) v[j] = src[cols[i][j]];
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (use_w) {
 #pragma unroll
-                    for (int j = 0; j < DEG; ++j) v[j] = src[cols[i][j]];
-                    CVec<CW> acc = cv_zero<CW>();
+                    for (int j = 0; j < DEG; ++j) acc = bg_fma4(wts[i][j], v[j], acc);
+                } else {
 #pragma unroll
-                    for (int j = 0; j < DEG; ++j)
-#pragma unroll
-                        for (int k = 0; k < CW; ++k) acc.v[k] = use_w ? fmaf(wts[i][j], v[j].v[k], acc.v[k]) : acc.v[k] + v[j].v[k];
-#pragma unroll
-                    for (int k = 0; k < CW; ++k) {
-                        if (KIND == 1) acc.v[k] = acc.v[k] / rs[i];
-                        else if (KIND == 0 && a.row_mode) acc.v[k] = apply_scale(acc.v[k], rs[i], a.row_mode);
-                    }
-                    if (a.basis) {
-                        const CVec<CW> p = dst[r];
-#pragma unroll
-                        for (int k = 0; k < CW; ++k) {
-                            acc.v[k] *= fac;
-                            if (step >= 2) acc.v[k] -= p.v[k];
-                        }
-                    }
-                    if (HAS_ADD) {
-#pragma unroll
-                        for (int k = 0; k < CW; ++k) acc.v[k] = acc.v[k] + ad.v[k];
-                    }
-                    dst[r] = acc;
-                    if (outk) cv_st<CW>(outk + grow * a.ldo + cc, acc);
+                    for (int j = 0; j < DEG; ++j) acc = bg_add4(acc, v[j]);
                 }
+                if (KIND == 1) {
+                    acc.x = acc.x / rs[i]; acc.y = acc.y / rs[i]; acc.z = acc.z / rs[i]; acc.w = acc.w / rs[i];
+                } else if (KIND == 0 && a.row_mode) {
+                    acc.x = apply_scale(acc.x, rs[i], a.row_mode); acc.y = apply_scale(acc.y, rs[i], a.row_mode);
+                    acc.z = apply_scale(acc.z, rs[i], a.row_mode); acc.w = apply_scale(acc.w, rs[i], a.row_mode);
+                }
+                if (a.basis) {
+                    acc.x *= fac; acc.y *= fac; acc.z *= fac; acc.w *= fac;
+                    if (step >= 2) { const float4 p = dst[r]; acc.x -= p.x; acc.y -= p.y; acc.z -= p.z; acc.w -= p.w; }
+                }
+                if (HAS_ADD) acc = bg_add4(acc, ad);
+                dst[r] = acc;
+                if (outk) bg_st4(outk + grow * a.ldo + cc, acc);
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
 }
 
@@ -1059,32 +1023,30 @@ __device__ __forceinline__ void chain_short_steps(const ChainArgs& a, CVec<CW>* 
 // neighbours): each thread keeps the local column ids (and column weights) of its RPT rows in registers,
 // rows shorter than DEG are padded with a slot that points at an all-zero LDS row (x + 0 = x exactly),
 // so a step is RPT x DEG independent LDS reads per thread, straight-line code and one barrier; no index
-// tables in LDS.  A workgroup owns one diagonal block and CW columns: a step is bound by the VALU work of the
-// workgroup's 16 waves on ONE CU (~50 instructions per row and column), so a narrow matrix (the penalty's 2 dl = 16
-// columns over 8 graphs: 32 workgroups at CW = 4) is spread over more CUs by giving each workgroup fewer columns.
-template <int CW, int RPT, int DEG>
+// tables in LDS.
+template <int RPT, int DEG>
 __global__ __launch_bounds__(1024) void k_spmm_chain_short(ChainArgs a) {
     extern __shared__ float4 chain_smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int32_t r0 = a.blk_ptr[blockIdx.x];
     const int32_t nr = a.blk_ptr[blockIdx.x + 1] - r0;
-    int cc = CW * blockIdx.y;
+    int cc = 4 * blockIdx.y;
     if (nr <= 0 || nr > a.max_rows || nr > RPT * nt) return;   // uniform per workgroup (host checks the plan)
-    if (a.x0b && cc >= a.split_y) {                             // uniform per workgroup: the second matrix (split_y: columns)
-        cc -= a.split_y;
+    if (a.x0b && (int)blockIdx.y >= a.split_y) {                // uniform per workgroup: the second matrix
+        cc = 4 * ((int)blockIdx.y - a.split_y);
         a.x0 = a.x0b; a.ldx = a.ldxb; a.out = a.outb; a.ldo = a.ldob; a.out_step = a.out_stepb; a.add = nullptr;
     } else {
         chain_group_bases(a, cc);                               // (never together with a second matrix)
     }
     const int zero_slot = a.max_rows;                           // both images carry one extra, all-zero row
-    CVec<CW>* buf0 = reinterpret_cast<CVec<CW>*>(chain_smem);
-    CVec<CW>* buf1 = buf0 + (a.max_rows + 1);
+    float4* buf0 = chain_smem;
+    float4* buf1 = chain_smem + (a.max_rows + 1);
     int32_t cols[RPT][DEG];
     float wts[RPT][DEG];
     float rs[RPT];
     if (tid == 0) {
-        buf0[zero_slot] = cv_zero<CW>();
-        buf1[zero_slot] = cv_zero<CW>();
+        buf0[zero_slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        buf1[zero_slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
@@ -1094,7 +1056,7 @@ __global__ __launch_bounds__(1024) void k_spmm_chain_short(ChainArgs a) {
         for (int j = 0; j < DEG; ++j) { cols[i][j] = zero_slot; wts[i][j] = 0.f; }
         if (r < nr) {
             const int64_t grow = (int64_t)r0 + r;
-            buf0[r] = cv_ld<CW>(a.x0 + grow * a.ldx + cc);
+            buf0[r] = bg_ld4(a.x0 + grow * a.ldx + cc);
             const int32_t kb = a.rowptr[grow];
             const int d = a.rowptr[grow + 1] - kb;              // <= DEG on a checked plan (max_deg)
             if (a.row_mode) rs[i] = a.row_scale[grow];
@@ -1116,20 +1078,20 @@ __global__ __launch_bounds__(1024) void k_spmm_chain_short(ChainArgs a) {
     const bool row_div_only = a.row_mode == BG_SCALE_DIV && !a.col_mode;
     const bool col_only = !a.row_mode && a.col_mode;
     if (a.add) {
-        if (row_div_only) chain_short_steps<CW, RPT, DEG, true, 1>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
-        else if (col_only) chain_short_steps<CW, RPT, DEG, true, 2>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
-        else chain_short_steps<CW, RPT, DEG, true, 0>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
+        if (row_div_only) chain_short_steps<RPT, DEG, true, 1>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
+        else if (col_only) chain_short_steps<RPT, DEG, true, 2>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
+        else chain_short_steps<RPT, DEG, true, 0>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
     } else {
-        if (row_div_only) chain_short_steps<CW, RPT, DEG, false, 1>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
-        else if (col_only) chain_short_steps<CW, RPT, DEG, false, 2>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
-        else chain_short_steps<CW, RPT, DEG, false, 0>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
+        if (row_div_only) chain_short_steps<RPT, DEG, false, 1>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
+        else if (col_only) chain_short_steps<RPT, DEG, false, 2>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
+        else chain_short_steps<RPT, DEG, false, 0>(a, buf0, buf1, cols, wts, rs, nr, r0, cc, tid, nt);
     }
 }
 
-template <int CW, int RPT, int DEG>
+template <int RPT, int DEG>
 int launch_chain_short(const ChainArgs& a, int64_t n_blk, int64_t W, int nt, hipStream_t s) {
-    auto kern = k_spmm_chain_short<CW, RPT, DEG>;
-    const size_t lds = (size_t)(a.max_rows + 1) * 8 * CW;
+    auto kern = k_spmm_chain_short<RPT, DEG>;
+    const size_t lds = (size_t)(a.max_rows + 1) * 32;
     if (lds > 65536) {
         static bool raised[BG_SEG_MAX_DEVICES] = {};
         int dev = 0;
@@ -1141,35 +1103,20 @@ int launch_chain_short(const ChainArgs& a, int64_t n_blk, int64_t W, int nt, hip
             raised[dev] = true;
         }
     }
-    dim3 grid((unsigned)n_blk, (unsigned)(W / CW));
+    dim3 grid((unsigned)n_blk, (unsigned)(W / 4));
     kern<<<grid, nt, lds, s>>>(a);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }
 
-template <int CW, int DEG>
-int dispatch_chain_short_cw(const ChainArgs& a, int64_t n_blk, int64_t W, hipStream_t s) {
-    if (a.max_rows <= 256) return launch_chain_short<CW, 1, DEG>(a, n_blk, W, 256, s);
-    if (a.max_rows <= 512) return launch_chain_short<CW, 1, DEG>(a, n_blk, W, 512, s);
-    if (a.max_rows <= 1024) return launch_chain_short<CW, 1, DEG>(a, n_blk, W, 1024, s);
-    if (a.max_rows <= 2048) return launch_chain_short<CW, 2, DEG>(a, n_blk, W, 1024, s);
-    if constexpr (DEG <= 6) return launch_chain_short<CW, 3, DEG>(a, n_blk, W, 1024, s);   // 8 slots x 3 rows spill
-    return BG_ERR_SHAPE;
-}
-
-// columns per workgroup: 4 (one 16-byte access per lane) when that already gives every CU a workgroup, else 2.
-// Measured on the train step (8 graphs; chains of 56, 16 and 16 columns per critic pass), same box: 4 columns 1.852 ms
-// per step, 2 columns 1.823, 1 column 1.857 (4-byte LDS accesses, four times the index prologues): 1 is not built.
-int chain_cw(int64_t n_blk, int64_t W) {
-    static const int forced = bg_tune_int("BG_CHAIN_CW", 0);
-    if (forced == 2 || forced == 4) return forced;
-    return n_blk * (W / 4) >= 256 ? 4 : 2;
-}
-
 template <int DEG>
 int dispatch_chain_short(const ChainArgs& a, int64_t n_blk, int64_t W, hipStream_t s) {
-    if (chain_cw(n_blk, W) == 4) return dispatch_chain_short_cw<4, DEG>(a, n_blk, W, s);
-    return dispatch_chain_short_cw<2, DEG>(a, n_blk, W, s);
+    if (a.max_rows <= 256) return launch_chain_short<1, DEG>(a, n_blk, W, 256, s);
+    if (a.max_rows <= 512) return launch_chain_short<1, DEG>(a, n_blk, W, 512, s);
+    if (a.max_rows <= 1024) return launch_chain_short<1, DEG>(a, n_blk, W, 1024, s);
+    if (a.max_rows <= 2048) return launch_chain_short<2, DEG>(a, n_blk, W, 1024, s);
+    if constexpr (DEG <= 6) return launch_chain_short<3, DEG>(a, n_blk, W, 1024, s);   // 8 slots x 3 rows spill
+    return BG_ERR_SHAPE;
 }
 
 }  // namespace
@@ -1294,7 +1241,7 @@ int bg_spmm_chain_pair_f32(const float* x0, int64_t ldx, float* out, int64_t ldo
         ldo % 4 != 0 || out_step % 4 != 0 || ldxb % 4 != 0 || ldob % 4 != 0 || out_stepb % 4 != 0) return BG_ERR_ALIGN;
     if (!(max_deg <= 8 && max_rows <= (max_deg <= 6 ? 3072 : 2048))) return BG_ERR_SHAPE;      // short-row plans only: else two bg_spmm_chain_f32 calls
     ChainArgs a{x0, ldx, rowptr, col, row_scale, row_mode, col_scale, col_mode, blk_ptr, (int)max_rows, (int)max_nnz,
-                nullptr, 0, 0, out, ldo, out_step, (int)n_steps, (int)W, x0b, ldxb, outb, ldob, out_stepb, (int)basis};
+                nullptr, 0, 0, out, ldo, out_step, (int)n_steps, (int)(W / 4), x0b, ldxb, outb, ldob, out_stepb, (int)basis};
     hipStream_t s = (hipStream_t)stream;
     return max_deg <= 6 ? dispatch_chain_short<6>(a, n_blk, W + Wb, s) : dispatch_chain_short<8>(a, n_blk, W + Wb, s);
 }
