@@ -932,6 +932,55 @@ __global__ __launch_bounds__(1024) void k_spmm_chain(ChainArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- program ratio (forward only, two launches)
+// program_weight[p] = sum over the cross edges e of program node p of att[e] * (mask[v_e] * area[v_e]): a workgroup per
+// program node, threads stride over its edges, partial sums combined in a fixed tree (lane, wave, workgroup)
+__global__ __launch_bounds__(256) void k_program_weight(const float* __restrict__ att, const float* __restrict__ mask,
+                                                        const float* __restrict__ area, int64_t ld_area,
+                                                        const int32_t* __restrict__ voxel_of_edge,
+                                                        const int32_t* __restrict__ rowptr, const int32_t* __restrict__ edge,
+                                                        float* __restrict__ program_weight) {
+    __shared__ float part[4];
+    const int p = blockIdx.x;
+    float acc = 0.f;
+    for (int32_t k = rowptr[p] + threadIdx.x; k < rowptr[p + 1]; k += 256) {
+        const int32_t e = edge[k];
+        const int32_t v = voxel_of_edge[e];
+        acc += att[e] * (mask[v] * area[(int64_t)v * ld_area]);
+    }
+    acc = bg_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) program_weight[p] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// class slots, graphs, ratio: one workgroup (the slots are 6 per graph).  Sums in CSR slot order, as bg_spmm_f32 forms them.
+__global__ __launch_bounds__(1024) void k_program_ratio_finish(const float* __restrict__ program_weight,
+                                                               const int32_t* __restrict__ slot_rowptr,
+                                                               const int32_t* __restrict__ slot_col, int n_slot,
+                                                               const int32_t* __restrict__ graph_rowptr,
+                                                               const int32_t* __restrict__ graph_col, int B,
+                                                               const int32_t* __restrict__ graph_of_slot,
+                                                               float* __restrict__ ratio, float* __restrict__ far) {
+    extern __shared__ float pr_smem[];                  // class weight [n_slot] | far [B]
+    float* cw = pr_smem;
+    float* fs = pr_smem + n_slot;
+    for (int s = threadIdx.x; s < n_slot; s += blockDim.x) {
+        float acc = 0.f;
+        for (int32_t k = slot_rowptr[s]; k < slot_rowptr[s + 1]; ++k) acc += program_weight[slot_col[k]];
+        cw[s] = acc;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        float acc = 0.f;
+        for (int32_t k = graph_rowptr[b]; k < graph_rowptr[b + 1]; ++k) acc += cw[graph_col[k]];
+        fs[b] = acc;
+        far[b] = acc;
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < n_slot; s += blockDim.x) ratio[s] = cw[s] / (fs[graph_of_slot[s]] + 1e-16f);
+}
+
 constexpr int BG_SEG_MAX_DEVICES = 64;
 constexpr size_t BG_CHAIN_LDS_LIMIT = 160 * 1024;
 
@@ -1160,6 +1209,28 @@ int bg_spmm_batch_f32(const float* x, int64_t ldx, int64_t x_step, const int32_t
                nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, x_step, out_step, (int)n_batch};
     const bool general = !col || col_mode;
     return general ? launch_spmm_vec<true>(a, (hipStream_t)stream) : launch_spmm_vec<false>(a, (hipStream_t)stream);
+}
+
+// get_program_ratio without a gradient (evaluation; the generator step when its ratio losses have zero weight) in two
+// launches instead of nine: see include/bgan.h
+int bg_program_ratio_f32(const float* att, const float* mask, const float* area, int64_t ld_area,
+                         const int32_t* voxel_of_edge, const int32_t* prog_rowptr, const int32_t* prog_edge,
+                         const int32_t* slot_rowptr, const int32_t* slot_col, const int32_t* graph_rowptr,
+                         const int32_t* graph_col, const int32_t* graph_of_slot, float* ratio, float* program_weight,
+                         float* far, int64_t Np, int64_t n_slot, int64_t B, bgStream stream) {
+    if (Np < 0 || n_slot < 0 || B < 0 || ld_area < 1) return BG_ERR_ARG;
+    if (Np == 0 || n_slot == 0 || B == 0) return BG_OK;
+    if (!att || !mask || !area || !voxel_of_edge || !prog_rowptr || !prog_edge || !slot_rowptr || !slot_col || !graph_rowptr ||
+        !graph_col || !graph_of_slot || !ratio || !program_weight || !far) return BG_ERR_ARG;
+    if (Np > 0x7fffffff || n_slot + B > 12000) return BG_ERR_SHAPE;          // class weights and graph sums live in LDS
+    hipStream_t s = (hipStream_t)stream;
+    k_program_weight<<<(unsigned)Np, 256, 0, s>>>(att, mask, area, ld_area, voxel_of_edge, prog_rowptr, prog_edge, program_weight);
+    BG_LAUNCH_CHECK();
+    k_program_ratio_finish<<<1, 1024, (size_t)(n_slot + B) * sizeof(float), s>>>(program_weight, slot_rowptr, slot_col, (int)n_slot,
+                                                                               graph_rowptr, graph_col, (int)B, graph_of_slot,
+                                                                               ratio, far);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
 }
 
 int bg_spmm_add_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,

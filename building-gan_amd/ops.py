@@ -245,6 +245,31 @@ def scatter_arg_batch_raw(g: torch.Tensor, arg: torch.Tensor, n_rows: int, seg_o
     return out
 
 
+def program_ratio_raw(plan, att: torch.Tensor, mask: torch.Tensor, voxel_feature: torch.Tensor, area_col: int):
+    """(class ratio [n_slot, 1], program weight [Np, 1], FAR [B, 1]) of util_graph.get_program_ratio without a gradient:
+    bg_program_ratio_f32, two launches.  None when the entry point does not take the batch (the caller then runs the
+    op-by-op form)."""
+    lib = _lib.load()
+    ev, ep = plan.edge_voxel_gather.csr, plan.edge_program_gather.T.csr
+    sl, sg, gs = plan.slot_sum.csr, plan.slot_graph_sum.csr, plan.slot_graph_gather.csr
+    a2, m2 = _f32c(att).reshape(-1), _f32c(mask).reshape(-1)
+    if (ev.col is None or ep.col is None or sl.col is None or sg.col is None or gs.col is None or not a2.is_contiguous()
+            or not m2.is_contiguous() or a2.numel() != ev.n_rows or m2.numel() != voxel_feature.shape[0]):
+        return None
+    Np, n_slot, B = ep.n_rows, sl.n_rows, sg.n_rows
+    dev = voxel_feature.device
+    ratio = torch.empty(n_slot, 1, dtype=torch.float32, device=dev)
+    pw = torch.empty(Np, 1, dtype=torch.float32, device=dev)
+    far = torch.empty(B, 1, dtype=torch.float32, device=dev)
+    rc = lib.bg_program_ratio_f32(ptr(a2), ptr(m2), voxel_feature.data_ptr() + 4 * area_col, voxel_feature.stride(0), ptr(ev.col),
+                                  ptr(ep.rowptr), ptr(ep.col), ptr(sl.rowptr), ptr(sl.col), ptr(sg.rowptr), ptr(sg.col),
+                                  ptr(gs.col), ptr(ratio), ptr(pw), ptr(far), Np, n_slot, B, stream())
+    if rc == _lib.BG_ERR_SHAPE:
+        return None
+    check(rc, "bg_program_ratio_f32")
+    return ratio, pw, far
+
+
 def gather_arg_raw(x: torch.Tensor, arg: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x2 = _f32c(x)

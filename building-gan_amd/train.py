@@ -488,7 +488,9 @@ class Trainer:
             g_loss = self._g_adversarial(val_b, val_s, Bg, Sg)
         stats = {"g_adv": g_loss.detach()}
         # get_program_ratio runs in every G step although its losses have zero weight by default (losses.py:65)
-        ratio, _, far = self.program_ratio_fn(batch, att["hard"], mask["hard"], 6)
+        # (no gradient is asked of it then: values only, two launches)
+        with torch.set_grad_enabled(self.tr_weight != 0 or self.far_weight != 0):
+            ratio, _, far = self.program_ratio_fn(batch, att["hard"], mask["hard"], 6)
         # smooth_l1_loss means over the 6 B class slots / the B graphs (losses.py:66-67), as local sum / global count
         if self.tr_weight != 0:
             tr = self.tr_weight * F.smooth_l1_loss(ratio.flatten(), batch.program_target_ratio, reduction="sum") / \

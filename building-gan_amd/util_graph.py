@@ -14,6 +14,12 @@ def get_program_ratio(graph, att, mask, area_index_in_voxel_feature):
     (graph, class) slot -> graph.  Returns (normalised class weight [6B,1], program weight
     [Np,1], FAR [B,1])."""
     plan = build_plan(graph)
+    vf = graph.voxel_feature
+    if (vf.is_cuda and not (torch.is_grad_enabled() and (att.requires_grad or mask.requires_grad or vf.requires_grad))
+            and vf.dtype == torch.float32 and vf.stride(1) == 1):
+        got = ops.program_ratio_raw(plan, att, mask, vf, area_index_in_voxel_feature)      # values only: two launches
+        if got is not None:
+            return got
     masked_voxel_weight = mask * graph.voxel_feature[:, area_index_in_voxel_feature].view(-1, 1)
     painted = att * SpMM.apply(masked_voxel_weight, plan.edge_voxel_gather)
     program_weight = SpMM.apply(painted, plan.edge_program_gather.T)

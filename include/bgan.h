@@ -340,6 +340,23 @@ int bg_scatter_arg_pair_f32(const float* g0, int64_t ldg0, const int32_t* arg0, 
                             const float* g1, int64_t ldg1, const int32_t* arg1, const int32_t* seg_of1, float* out1, int64_t n_seg1,
                             int64_t ldo, int64_t n_rows, int64_t H, bgStream stream);
 
+/* get_program_ratio, values only (no gradient), in two launches:
+ *   program_weight[p] = sum over the cross edges e of program node p (prog_rowptr / prog_edge: CSR by program node over
+ *                       edge ids) of att[e] * (mask[v] * area[v * ld_area]), v = voxel_of_edge[e]
+ *   class_weight[s]   = sum of program_weight over the program nodes of (graph, class) slot s (slot_rowptr / slot_col)
+ *   far[b]            = sum of class_weight over the slots of graph b (graph_rowptr / graph_col)
+ *   ratio[s]          = class_weight[s] / (far[graph_of_slot[s]] + 1e-16)
+ * att [Ec], mask [Nv], area = a column of the voxel features (pitch ld_area), ratio [n_slot], program_weight [Np],
+ * far [B].  The per-edge products are those of the op-by-op form; a program node's sum is taken by 256 threads in a
+ * fixed tree (the op-by-op form adds in slot order), so the results agree to rounding, run to run identical.
+ * BG_ERR_SHAPE when n_slot + B > 12000 (the caller then takes the op-by-op form).
+ * replaces: util_graph.py:21-41 where no gradient is asked for (util_eval.py:77,97; Model/losses.py:65 with zero weights). */
+int bg_program_ratio_f32(const float* att, const float* mask, const float* area, int64_t ld_area,
+                         const int32_t* voxel_of_edge, const int32_t* prog_rowptr, const int32_t* prog_edge,
+                         const int32_t* slot_rowptr, const int32_t* slot_col, const int32_t* graph_rowptr,
+                         const int32_t* graph_col, const int32_t* graph_of_slot, float* ratio, float* program_weight,
+                         float* far, int64_t Np, int64_t n_slot, int64_t B, bgStream stream);
+
 /* out[k] = dot(a[r_k,:], b[c_k,:]) for every CSR slot k (r_k = the row owning slot k),
  * written to out[eperm ? eperm[k] : k].   The weight-gradient of bg_spmm_f32.                */
 int bg_sddmm_f32(const float* a, int64_t lda, const float* b, int64_t ldb,

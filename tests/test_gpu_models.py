@@ -163,17 +163,29 @@ def test_generator_backward_through_discriminator(cuda, d_basis):
     _assert_grads_close(Go.named_parameters(), Gh.named_parameters(), 1e-4, "G")
 
 
-def test_program_ratio_parity(cuda):
+@pytest.mark.parametrize("preset,ragged", [("small", True), ("dataset", "jitter")])
+def test_program_ratio_parity(cuda, preset, ragged):
+    """get_program_ratio in both of its forms -- values only (bg_program_ratio_f32, two launches: what evaluation and a
+    generator step with zero ratio weights call) and op by op under autograd -- against the oracle and against each other."""
     from building_gan_amd.util_graph import get_program_ratio as h
     from oracle.pointer import get_program_ratio as o
-    cpu, gpu, sz, *_ = _setup("small", 15, True, cuda)
+    cpu, gpu, sz, *_ = _setup(preset, 15, ragged, cuda)
     torch.manual_seed(15)
     att = torch.rand(sz["Ec"], 1)
     mask = (torch.rand(sz["Nv"], 1) > 0.4).float()
     ro = o(cpu, att, mask, 6)
-    rh = h(gpu, att.to(cuda), mask.to(cuda), 6)
-    for a, b in zip(rh, ro):
+    rh = h(gpu, att.to(cuda), mask.to(cuda), 6)                     # no gradient asked for: the two-launch form
+    att_g = att.to(cuda).requires_grad_()
+    rg = h(gpu, att_g, mask.to(cuda), 6)                            # op by op, differentiable
+    assert rg[0].requires_grad and not rh[0].requires_grad
+    with torch.no_grad():
+        rn = h(gpu, att_g, mask.to(cuda), 6)                        # values only again; the same bits as the first call
+    for a, b, c, d in zip(rh, ro, rg, rn):
+        assert a.shape == b.shape == c.shape
         torch.testing.assert_close(a.cpu(), b, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(c.detach().cpu(), b, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(a, c.detach(), rtol=2e-6, atol=1e-7)          # the forms differ in summation order only
+        assert torch.equal(a, d)
 
 
 def test_trainer_matches_oracle_iterations(cuda):
