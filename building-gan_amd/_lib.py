@@ -45,6 +45,7 @@ SIGNATURES = {
     "bg_plan_counts": [_p, _i64, _p, _p],
     "bg_plan_chunks": [_p, _i64, _i32, _p, _p],
     "bg_spmm_f32": [_p, _i64, _p, _p, _p, _p, _p, _int, _p, _int, _p, _i64, _i64, _i64, _p],
+    "bg_connectivity": [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p],
     "bg_program_ratio_f32": [_p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "bg_spmm_batch_f32": [_p, _i64, _i64, _p, _p, _p, _int, _p, _int, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "bg_spmm_add_f32": [_p, _i64, _p, _p, _p, _int, _p, _int, _p, _i64, _p, _i64, _p, _i64, _p, _p, _int,

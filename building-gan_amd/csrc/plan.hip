@@ -441,6 +441,64 @@ __global__ __launch_bounds__(1024) void k_build_derived(DerivedArgs a) {
                    a.n_slot, a.pp_rowptr, a.pp_col, a.pp_scale, a.nnz_slot);
 }
 
+// ---------------------------------------------------------------- check_connectivity (evaluation)
+// code[src * Np + dst]: bit 0 = a voxel edge with both ends unmasked joins voxels assigned to (src, dst), bit 1 =
+// (src, dst) is an edge of the input program graph.  OR is order-free: the result does not depend on scheduling.
+__global__ void k_conn_mark(const int64_t* __restrict__ ve, int64_t Ev, const float* __restrict__ mask,
+                            const int64_t* __restrict__ prog_of_voxel, int64_t Nv, const int64_t* __restrict__ pe, int64_t Ep,
+                            int64_t Np, int32_t* __restrict__ code) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < Ev) {
+        const int64_t a = ve[t], b = ve[Ev + t];
+        if ((uint64_t)a < (uint64_t)Nv && (uint64_t)b < (uint64_t)Nv && mask[a] + mask[b] == 2.f) {
+            const int64_t pa = prog_of_voxel[a], pb = prog_of_voxel[b];
+            if ((uint64_t)pa < (uint64_t)Np && (uint64_t)pb < (uint64_t)Np) atomicOr(&code[pa * Np + pb], 1);
+        }
+    } else if (t < Ev + Ep) {
+        const int64_t k = t - Ev;
+        const int64_t a = pe[k], b = pe[Ep + k];
+        if ((uint64_t)a < (uint64_t)Np && (uint64_t)b < (uint64_t)Np) atomicOr(&code[a * Np + b], 2);
+    }
+}
+
+// The three edge lists in ascending (src, dst) order -- what torch.unique(dim=1) returns -- by ONE workgroup: thread t
+// owns a contiguous range of the code table, counts its entries per class, three threads scan the counts, every thread
+// writes its entries behind its predecessors'.  class 3 = both (inter), 2 = program graph only (missing), 1 = generated only.
+__global__ __launch_bounds__(1024) void k_conn_lists(const int32_t* __restrict__ code, int64_t n, int64_t Np,
+                                                     int64_t* __restrict__ inter, int64_t cap_i, int64_t* __restrict__ missing,
+                                                     int64_t cap_m, int64_t* __restrict__ gen, int64_t cap_g,
+                                                     int64_t* __restrict__ counts) {
+    __shared__ int32_t cnt[3][1024];
+    __shared__ int32_t total[3];
+    const int t = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024, lo = (int64_t)t * per, hi = lo + per < n ? lo + per : n;
+    int32_t c[3] = {0, 0, 0};
+    for (int64_t k = lo; k < hi; ++k) {
+        const int32_t v = code[k];
+        if (v) ++c[v - 1];
+    }
+    cnt[0][t] = c[0]; cnt[1][t] = c[1]; cnt[2][t] = c[2];
+    __syncthreads();
+    if (t < 3) {                                            // exclusive scan of one class's counts
+        int32_t run = 0;
+        for (int i = 0; i < 1024; ++i) { const int32_t v = cnt[t][i]; cnt[t][i] = run; run += v; }
+        total[t] = run;
+    }
+    __syncthreads();
+    int64_t at[3] = {cnt[0][t], cnt[1][t], cnt[2][t]};
+    int64_t* const dst[3] = {gen, missing, inter};
+    const int64_t cap[3] = {cap_g, cap_m, cap_i};
+    for (int64_t k = lo; k < hi; ++k) {
+        const int32_t v = code[k];
+        if (v) {
+            const int cls = v - 1;
+            const int64_t pos = at[cls]++;
+            if (pos < cap[cls]) { dst[cls][pos] = k / Np; dst[cls][cap[cls] + pos] = k % Np; }
+        }
+    }
+    if (t == 0) { counts[0] = total[2]; counts[1] = total[1]; counts[2] = total[0]; }       // inter, missing, generated
+}
+
 }  // namespace
 
 extern "C" {
@@ -731,6 +789,28 @@ int bg_plan_build(const bgPlanIn* in, int32_t* ai, float* af, bgStream stream) {
                   I(BGP_PCC32), p.target_ratio, (int)Np, (int)Ep, (int)ns, I(BGP_PP_ROWPTR), I(BGP_PP_COL), F(BGP_PP_SCALE),
                   stats + BGS_NNZ_SLOT};
     k_build_derived<<<2, 1024, 0, s>>>(D);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+// check_connectivity (util_eval.py:102-136) as a code table and three sorted edge lists: see include/bgan.h
+int bg_connectivity(const int64_t* voxel_edge, int64_t Ev, const float* mask, const int64_t* prog_of_voxel, int64_t Nv,
+                    const int64_t* program_edge, int64_t Ep, int64_t Np, int32_t* code, int64_t* inter, int64_t cap_inter,
+                    int64_t* missing, int64_t cap_missing, int64_t* gen, int64_t cap_gen, int64_t* counts, bgStream stream) {
+    if (Ev < 0 || Ep < 0 || Nv < 0 || Np <= 0 || cap_inter < 0 || cap_missing < 0 || cap_gen < 0) return BG_ERR_ARG;
+    if (!code || !counts || (Ev > 0 && (!voxel_edge || !mask || !prog_of_voxel)) || (Ep > 0 && !program_edge) ||
+        (cap_inter > 0 && !inter) || (cap_missing > 0 && !missing) || (cap_gen > 0 && !gen)) return BG_ERR_ARG;
+    if (Np > (1 << 13) || Ev + Ep > ((int64_t)1 << 40)) return BG_ERR_SHAPE;            // the table has Np^2 <= 2^26 entries
+    const int64_t n = Np * Np;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = bg_zero_bytes(code, n * (int64_t)sizeof(int32_t), stream);
+    if (rc != BG_OK) return rc;
+    if (Ev + Ep > 0) {
+        k_conn_mark<<<bg_grid_for(Ev + Ep, 256, 0x7fffffff), 256, 0, s>>>(voxel_edge, Ev, mask, prog_of_voxel, Nv, program_edge, Ep,
+                                                                           Np, code);
+        BG_LAUNCH_CHECK();
+    }
+    k_conn_lists<<<1, 1024, 0, s>>>(code, n, Np, inter, cap_inter, missing, cap_missing, gen, cap_gen, counts);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -21,6 +21,10 @@ def check_connectivity(g, max_out_program_index, mask):
     ve = g.voxel_edge
     pe = g.program_edge
     Np = int(g.program_class_feature.shape[0])
+    if ve.is_cuda:
+        got = _check_connectivity_hip(ve, pe, Np, max_out_program_index, mask)
+        if got is not None:
+            return got
     on_edge = mask.reshape(-1)[ve]                       # [2, Ev]
     keep = on_edge.sum(dim=0) == 2                       # both end voxels unmasked (float compare, as the reference)
     masked_edges = ve[:, keep]
@@ -37,6 +41,33 @@ def check_connectivity(g, max_out_program_index, mask):
         return torch.stack((k // Np, k % Np))
 
     return edges(flat & gt), edges(gt & ~flat), edges(flat & ~gt)
+
+
+def _check_connectivity_hip(ve, pe, Np, idx, mask):
+    """bg_connectivity: the code table and the three sorted lists by three launches and ONE read-back (the counts).  None
+    for inputs the entry point does not take (the bitmap form above then runs)."""
+    from . import _lib
+    m = mask.reshape(-1)
+    Ev, Ep, Nv = int(ve.shape[1]), int(pe.shape[1]), int(m.shape[0])
+    if (Ev == 0 or Np <= 0 or Np > 8192 or ve.dtype != torch.int64 or pe.dtype != torch.int64 or idx.dtype != torch.int64
+            or m.dtype != torch.float32 or idx.numel() != Nv or not (ve.is_contiguous() and pe.is_contiguous()
+                                                                  and idx.is_contiguous() and m.is_contiguous())):
+        return None
+    dev = ve.device
+    cap_g = min(Ev, Np * Np)
+    code = torch.empty(Np * Np, dtype=torch.int32, device=dev)
+    inter, missing = torch.empty(2, max(Ep, 1), dtype=torch.int64, device=dev), torch.empty(2, max(Ep, 1), dtype=torch.int64, device=dev)
+    gen = torch.empty(2, max(cap_g, 1), dtype=torch.int64, device=dev)
+    counts = torch.empty(3, dtype=torch.int64, device=dev)
+    _lib.check(_lib.load().bg_connectivity(ve.data_ptr(), Ev, m.data_ptr(), idx.data_ptr(), Nv, pe.data_ptr(), Ep, Np,
+                                           code.data_ptr(), inter.data_ptr(), inter.shape[1], missing.data_ptr(),
+                                           missing.shape[1], gen.data_ptr(), gen.shape[1], counts.data_ptr(), _lib.stream()),
+               "bg_connectivity")
+    ni, nm, ng = (int(x) for x in counts.tolist())          # the one synchronisation
+    if ni + ng == 0:                                          # no voxel edge with both ends unmasked: the reference's else-branch
+        empty = ve[:, :0]
+        return empty, pe, empty
+    return inter[:, :ni], missing[:, :nm], gen[:, :ng]
 
 
 def draw_z(g, noise_dim: int, device, trunc: float = 1.0, generator=None):

@@ -890,6 +890,18 @@ int bg_gloss_head_backward_f32(const bgCriticHead* h, int64_t n_lab, const float
 
 /* ------------------------------------------------------------------ optimiser ----------- */
 
+/* check_connectivity: which program-graph edges a generated design realises.
+ *   code [Np * Np] int32 (workspace, cleared here): bit 0 of code[src * Np + dst] = some voxel edge (a, b) with
+ *   mask[a] + mask[b] == 2 has prog_of_voxel[a] = src, prog_of_voxel[b] = dst; bit 1 = (src, dst) is a program edge.
+ *   inter / missing / gen: int64 [2, cap_*] (row 0 = src, row 1 = dst) -- the pairs with code 3 / 2 / 1 in ascending
+ *   (src, dst) order, i.e. what torch.unique(dim=1) returns; counts [3] int64 = how many of each (entries beyond a
+ *   capacity are counted, not written).  voxel_edge [2, Ev], program_edge [2, Ep], prog_of_voxel [Nv]: int64 as the
+ *   batch holds them.  Three launches, no host synchronisation; Np <= 8192.
+ * replaces: util_eval.py:102-136 (three torch.unique(dim=1) sorts and their set arithmetic).                       */
+int bg_connectivity(const int64_t* voxel_edge, int64_t Ev, const float* mask, const int64_t* prog_of_voxel, int64_t Nv,
+                    const int64_t* program_edge, int64_t Ep, int64_t Np, int32_t* code, int64_t* inter, int64_t cap_inter,
+                    int64_t* missing, int64_t cap_missing, int64_t* gen, int64_t cap_gen, int64_t* counts, bgStream stream);
+
 /* Zero fill and strided device-to-device copy as KERNELS (sizes and pitches in bytes, multiples of 4; 4-byte aligned
  * pointers; `width` bytes of each of `rows` rows).  NO COUNTERPART IN THE REFERENCE: they stand where the composite
  * entry points would otherwise call hipMemsetAsync / hipMemcpy2DAsync, which turn into memset / memcpy graph nodes

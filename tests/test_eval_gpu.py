@@ -7,11 +7,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_check_connectivity_matches_reference_semantics(cuda):
+@pytest.mark.parametrize("preset,ragged", [("small", True), ("dataset", "jitter"), ("tiny", False)])
+def test_check_connectivity_matches_reference_semantics(cuda, preset, ragged):
+    """util_eval.check_connectivity (bg_connectivity: a code table over program-node pairs and three sorted lists, one
+    read-back) against the oracle's torch.unique form: identical edge lists in identical order; the bitmap form in torch
+    that it replaces gives the same; the reference's else-branch when no voxel edge survives the mask."""
+    from building_gan_amd import util_eval
     from building_gan_amd.synthetic import batch_sizes, make_batch
     from building_gan_amd.util_eval import check_connectivity as h
     from oracle.evaluation import check_connectivity as o
-    cpu = make_batch("small", seed=41, ragged=True)
+    cpu = make_batch(preset, seed=41, ragged=ragged)
     sz = batch_sizes(cpu)
     torch.manual_seed(41)
     # a plausible generator output: every voxel points at a program node of its own story
@@ -25,7 +30,15 @@ def test_check_connectivity_matches_reference_semantics(cuda):
     gpu = copy.deepcopy(cpu).to(cuda)
     rh = h(gpu, idx.to(cuda), mask.to(cuda))
     for a, b in zip(rh, ro):
-        assert torch.equal(a.cpu(), b)
+        assert a.dtype == b.dtype and torch.equal(a.cpu(), b)
+    orig = util_eval._check_connectivity_hip
+    try:                                                   # the torch bitmap form (inputs the entry point declines)
+        util_eval._check_connectivity_hip = lambda *a: None
+        rt = h(gpu, idx.to(cuda), mask.to(cuda))
+    finally:
+        util_eval._check_connectivity_hip = orig
+    for a, b in zip(rh, rt):
+        assert torch.equal(a, b)
     # nothing unmasked -> the reference's else branch
     rh = h(gpu, idx.to(cuda), torch.zeros(sz["Nv"], 1, device=cuda))
     assert rh[0].shape[1] == 0 and torch.equal(rh[1].cpu(), cpu.program_edge) and rh[2].shape[1] == 0
