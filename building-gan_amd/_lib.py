@@ -248,6 +248,18 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _get_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
+_PTR_ARRAYS = {}
+
+
+def ptr_array_type(n: int):
+    """``c_void_p * n``, made once per n (a ctypes array type is a class, and a class is a reference cycle of its own:
+    one made per call is garbage that only the cyclic collector frees)."""
+    t = _PTR_ARRAYS.get(n)
+    if t is None:
+        t = _PTR_ARRAYS[n] = C.c_void_p * n
+    return t
+
+
 def stream() -> int:
     """Raw handle of torch's current HIP stream on the current device.  Called once per kernel launch: the
     C-level getters cost ~0.3 us against ~4 us for torch.cuda.current_stream().cuda_stream (a Stream object per

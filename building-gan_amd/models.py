@@ -774,7 +774,7 @@ class Generator(nn.Module):
         att_hard = torch.empty(Ec, 1, dtype=torch.float32, device=dev)
         att_soft = torch.empty(Ec, 1, dtype=torch.float32, device=dev)
         idx = torch.empty(Nv, dtype=torch.int64, device=dev)
-        PA = C.c_void_p * n_calls
+        PA = _lib.ptr_array_type(n_calls)
         cls = ops._f32c(graph.program_class_feature).contiguous()
         rc = lib.bg_generator_forward_f32(C.byref(ws), C.byref(ps), program_in.data_ptr(), v4.data_ptr(), pdm4.data_ptr(),
                                           cls.data_ptr(), PA(*em_ptrs), PA(*ea_ptrs), n_calls, work.data_ptr(), nws,

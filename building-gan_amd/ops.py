@@ -1612,7 +1612,7 @@ class VoxelStackG(torch.autograd.Function):
         keep = [(_f32c(a).contiguous(), _f32c(b.reshape(-1)).contiguous()) for a, b in list(noise)[:n_calls]]
         if len(keep) != n_calls or any(tuple(a.shape) != (Nv, 2) or b.numel() != Ec for a, b in keep):
             raise _lib.BganError("voxel_stack: noise must hold one ([Nv, 2], [Ec]) pair per Attention call")
-        PA = C.c_void_p * n_calls
+        PA = _lib.ptr_array_type(n_calls)
         em, ea = PA(*[a.data_ptr() for a, _ in keep]), PA(*[b.data_ptr() for _, b in keep])
         ws = _lib.GeneratorWeights(H, 0, 0, L, 1, pe.shape[0], None, None, None, None, None, None, ptr(enc_w), ptr(enc_b),
                                    ptr(pe), ptr(Wc), Wc.stride(0), ptr(bc), ptr(Wsb), ptr(Wcat), ptr(bcat), ptr(nnp_w),

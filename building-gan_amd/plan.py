@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import dataclasses
+import weakref
 import os
 from dataclasses import dataclass, field
 from typing import Optional
@@ -67,14 +68,34 @@ class LinOp:
         self.csr = csr
         self.row_scale, self.row_mode = row_scale, row_mode
         self.col_scale, self.col_mode = col_scale, col_mode
-        self.T: Optional["LinOp"] = None
+        self._T: Optional["LinOp"] = None      # the transpose, held by the pair's FIRST operator only
+        self._back = None                      # in the transpose: (weak reference to the first operator, its Csr)
 
     @staticmethod
     def pair(fwd_csr: Csr, rev_csr: Csr, row_scale=None, row_mode=SCALE_NONE):
-        """fwd = diag(rs) P (rows of fwd_csr); its transpose runs over rev_csr with a column scale."""
+        """fwd = diag(rs) P (rows of fwd_csr); its transpose runs over rev_csr with a column scale.
+
+        The two operators do not hold each other: a plan builds ~25 pairs per batch, and pairs in a reference cycle
+        (with their Csr's and ~55 tensor views, i.e. the plan's device memory) were freed by the cyclic collector only
+        -- 150 objects per train step for it to find, and the pauses of its full collections (tools/lab/mode_probe.py:
+        two 50-70 ms stalls per 3,000 steps).  The first operator holds the transpose; the transpose finds the first
+        one through a weak reference and, should that one be gone, makes it again from the Csr it keeps."""
         a = LinOp(fwd_csr, row_scale, row_mode)
         b = LinOp(rev_csr, None, SCALE_NONE, row_scale, row_mode)
-        a.T, b.T = b, a
+        a._T = b
+        b._back = (weakref.ref(a), fwd_csr)
+        return a
+
+    @property
+    def T(self) -> Optional["LinOp"]:
+        if self._T is not None or self._back is None:
+            return self._T
+        ref, fwd_csr = self._back
+        a = ref()
+        if a is None:                          # only the transpose was kept: the same first operator again
+            a = LinOp(fwd_csr, self.col_scale, self.col_mode)
+            a._T = self
+            self._back = (weakref.ref(a), fwd_csr)
         return a
 
 
@@ -199,7 +220,11 @@ def _max_plus_one(t: torch.Tensor) -> int:
 
 ONE_CALL_BUILD = os.environ.get("BG_PLAN_ONE_CALL", "1") != "0"     # bg_plan_build; "0": piece by piece
 _I32 = {n: i for i, n in enumerate(_lib.PLAN_I32)}
+# (ctypes array types made once: `c_int64 * n` in a function body builds a new class per call where n is not cached, and a
+#  class is a reference cycle by itself)
+_I64_I32, _I64x2, _I32x4 = C.c_int64 * len(_lib.PLAN_I32), C.c_int64 * 2, C.c_int32 * 4
 _F32 = {n: i for i, n in enumerate(_lib.PLAN_F32)}
+_I64_F32 = C.c_int64 * len(_lib.PLAN_F32)
 _STAT = {n: i for i, n in enumerate(_lib.PLAN_STATS)}
 _CSR_NAMES = ("program_by_target", "program_by_source", "class_slot", "slot_by_graph", "voxel_by_target", "voxel_by_source",
               "voxel_by_story", "voxel_by_graph", "story_by_graph", "cross_by_voxel", "cross_by_program")
@@ -255,8 +280,8 @@ def _build_plan_one_call(graph, S, defer: bool = False):
     R = (_chunk_rows(Nv, S), _chunk_rows(Nv, B), _chunk_rows(S, B), cp_R)
     pin = _lib.PlanIn(Np, Nv, Ep, Ev, Ec, B, S, n_slot, pe.data_ptr(), pe.data_ptr() + 8 * Ep, ve.data_ptr(),
                       ve.data_ptr() + 8 * Ev, cep.data_ptr(), cev.data_ptr(), vfc.data_ptr(), vbi.data_ptr(), pcc.data_ptr(),
-                      slot_graph.data_ptr(), ratio.data_ptr(), (C.c_int32 * 4)(*R))
-    oi, of, tot = (C.c_int64 * len(_I32))(), (C.c_int64 * len(_F32))(), (C.c_int64 * 2)()
+                      slot_graph.data_ptr(), ratio.data_ptr(), _I32x4(*R))
+    oi, of, tot = _I64_I32(), _I64_F32(), _I64x2()
     rc = lib.bg_plan_layout(C.byref(pin), oi, of, tot)
     if rc == _lib.BG_ERR_SHAPE:
         return None
