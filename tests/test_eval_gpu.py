@@ -39,6 +39,13 @@ def test_check_connectivity_matches_reference_semantics(cuda, preset, ragged):
         util_eval._check_connectivity_hip = orig
     for a, b in zip(rh, rt):
         assert torch.equal(a, b)
+    # every voxel unmasked, and every voxel assigned to ONE program node (a single generated pair, a self-loop)
+    ones = torch.ones(sz["Nv"], 1)
+    for ix in (idx, torch.zeros_like(idx)):
+        ro1 = o(cpu, ix, ones)
+        rh1 = h(gpu, ix.to(cuda), ones.to(cuda))
+        for a, b in zip(rh1, ro1):
+            assert torch.equal(a.cpu(), b)
     # nothing unmasked -> the reference's else branch
     rh = h(gpu, idx.to(cuda), torch.zeros(sz["Nv"], 1, device=cuda))
     assert rh[0].shape[1] == 0 and torch.equal(rh[1].cpu(), cpu.program_edge) and rh[2].shape[1] == 0
