@@ -95,11 +95,20 @@ def evaluate(data_loader, generator, raw_dir: Optional[str], output_dir: Optiona
     device = device_ids[0] if device_ids else next(generator.parameters()).device
     results = []
     total_inter, total_program_edge = 0, 0
+    from .plan import prefetch_plan
+    it = iter(data_loader)
+
+    def fetch(k):
+        b = next(it, None) if k < number_of_batches else None
+        if b is not None:
+            b.to(device)
+        return b
     with torch.no_grad():
-        for i, g in enumerate(data_loader):
-            if i >= number_of_batches:
-                break
-            g.to(device)
+        g, i = fetch(0), 0
+        while g is not None:
+            nxt = fetch(i + 1)
+            if nxt is not None and torch.device(device).type == "cuda":
+                prefetch_plan(nxt)                # the next design's index plan, beside this design's forward (side stream)
             program_z, voxel_z = draw_z(g, generator.noise_dim, device, trunc, generator)
             out, soft_out, mask, att, max_out_program_index = generator(g, program_z, voxel_z)
             inter_edges, missing_edges, gen_edges = check_connectivity(g, max_out_program_index, mask["hard"])
@@ -112,6 +121,7 @@ def evaluate(data_loader, generator, raw_dir: Optional[str], output_dir: Optiona
             if writer is not None:
                 res["written"] = writer(g, class_w, program_w, far, max_out_program_index, out)
             results.append(res)
+            g, i = nxt, i + 1
     acc = total_inter / max(total_program_edge, 1)
     print("acc=", acc)
     return acc, results

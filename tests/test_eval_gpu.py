@@ -60,8 +60,18 @@ def test_evaluate_and_variation_sampling_run(cuda):
     torch.manual_seed(0)
     G = hm.Generator(7, 7, 128, 32, 4, 12, cuda).to(cuda)
     loader = [make_batch("small", seed=s, ragged=True) for s in (1, 2)]
+    torch.manual_seed(5)
     acc, res = evaluate(loader, G, None, None, None, [cuda], number_of_batches=2)
     assert 0.0 <= acc <= 1.0 and len(res) == 2
+    # the second design's plan was prefetched beside the first design's forward (side stream): the same results as
+    # designs evaluated one at a time, each building its own plan
+    torch.manual_seed(5)
+    single = [evaluate([make_batch("small", seed=s, ragged=True)], G, None, None, None, [cuda], number_of_batches=1)[1][0]
+              for s in (1, 2)]
+    for a, b in zip(res, single):
+        for k in ("out", "max_out_program_index", "class_weights", "FAR", "inter_edges", "missing_edges", "gen_edges"):
+            assert torch.equal(a[k], b[k]), k
+    assert len(evaluate(loader, G, None, None, None, [cuda], number_of_batches=1)[1]) == 1
     assert res[0]["out"].shape[1] == 6 and res[0]["FAR"].shape[0] == loader[0].FAR.shape[0]
     data = make_graph(np.random.default_rng(3), 3, 4, 3, [3, 2, 4])
     out, idx, cw, pw, far = generate_multiple_outputs_from_data(data, 25, G, None, None, None, [cuda])
