@@ -121,6 +121,7 @@ SIGNATURES = {
     "bg_regroup_f32": [_p, _p, _i64, _i64, _i64, _i64, _int, _p],
     "bg_add_f32": [_p, _p, _p, _i64, _p],
     "bg_fill_f32": [_p, _i64, _f, _p],
+    "bg_regroup_iota_f32": [_p, _p, _i64, _i64, _i64, _i64, _int, _p, _i64, _i64, _p],
     "bg_iota_mod_i32": [_p, _i64, _i64, _p],
     "bg_critic_head_forward_f32": [_p, _f, _p, _i64, _p, _p],
     "bg_critic_head_backward_f32": [_p, _f, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],

@@ -336,6 +336,22 @@ __global__ void k_regroup(const float4* __restrict__ src, float4* __restrict__ d
     if (to_outer) dst[outer] = src[t]; else dst[t] = src[outer];
 }
 
+// k_regroup and k_iota_mod in one grid (bg_regroup_iota_f32): thread t moves float4 t of the regrouping and, while
+// t < idx_n, writes idx[t] = t mod idx_mod -- two independent writes the critic head needs before the same product
+__global__ void k_regroup_iota(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n, int K, int P, int W4,
+                               int to_outer, int32_t* __restrict__ idx, int64_t idx_n, int32_t idx_mod) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < idx_n) idx[t] = (int32_t)(t % idx_mod);
+    const int64_t total = n * K * P * W4;
+    if (t >= total) return;
+    const int j = (int)(t % W4);
+    const int p = (int)((t / W4) % P);
+    const int k = (int)((t / ((int64_t)W4 * P)) % K);
+    const int64_t v = t / ((int64_t)W4 * P * K);
+    const int64_t outer = (((int64_t)p * n + v) * K + k) * W4 + j;
+    if (to_outer) dst[outer] = src[t]; else dst[t] = src[outer];
+}
+
 // dst[r][i] = src[i] for r < reps (one float4 per thread of dst)
 __global__ void k_tile4(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4, int64_t total4) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -541,6 +557,22 @@ int bg_regroup_f32(const float* src, float* dst, int64_t n, int64_t K, int64_t P
     const int64_t total = n * K * P * (W / 4);
     k_regroup<<<bg_grid_for(total, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
         reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n, (int)K, (int)P, (int)(W / 4), to_outer);
+    BG_LAUNCH_CHECK();
+    return BG_OK;
+}
+
+// bg_regroup_f32 and bg_iota_mod_i32 (idx[t] = t mod idx_mod, t < idx_n) as ONE launch: see include/bgan.h
+int bg_regroup_iota_f32(const float* src, float* dst, int64_t n, int64_t K, int64_t P, int64_t W, int to_outer,
+                        int32_t* idx, int64_t idx_n, int64_t idx_mod, bgStream stream) {
+    if (n < 0 || K <= 0 || P <= 0 || W <= 0 || idx_n < 0 || idx_mod <= 0 || idx_mod >= ((int64_t)1 << 31)) return BG_ERR_ARG;
+    if (n == 0 && idx_n == 0) return BG_OK;
+    if ((n > 0 && (!src || !dst)) || (idx_n > 0 && !idx)) return BG_ERR_ARG;
+    if (W % 4 != 0 || K > (1 << 20) || P > (1 << 20)) return BG_ERR_SHAPE;
+    if (n > 0 && (!bg_aligned16(src) || !bg_aligned16(dst))) return BG_ERR_ALIGN;
+    const int64_t total = n * K * P * (W / 4);
+    k_regroup_iota<<<bg_grid_for(total > idx_n ? total : idx_n, 256, 0x7fffffff), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n, (int)K, (int)P, (int)(W / 4), to_outer, idx, idx_n,
+        (int32_t)idx_mod);
     BG_LAUNCH_CHECK();
     return BG_OK;
 }

@@ -462,11 +462,11 @@ extern "C" int bg_critic_head_forward_f32(const bgCriticHead* hp, float coef, fl
     const float* Wl = h.W + K1 * ds * H2;
 
     // label powers [N, K1, 3, dl] -> one contiguous [N, K1 dl] matrix per label set
-    BG_TRY(bg_regroup_f32(h.Zk, b.Zp[0], N, K1, 3, dl, 1, s));
+    // (and, by the same launch, the row of the label-free part that row r of the 3 N stacked rows adds: r mod N)
+    BG_TRY(bg_regroup_iota_f32(h.Zk, b.Zp[0], N, K1, 3, dl, 1, b.idx3, 3 * N, N, s));
     // label-free part once, then one thin product per label set on top of it (models.py collapsed_multi)
     BG_TRY(mm(N, H2, K1 * ds, h.Zs, K1 * ds, Ws, H2, 0, b.Sb, nullptr, nullptr, s));
     {   // all three sets in one product over 3 N rows; row r adds S[r mod N]
-        BG_TRY(bg_iota_mod_i32(b.idx3, 3 * N, N, s));
         const float* A[4] = {b.Zp[0], nullptr, nullptr, nullptr};
         const int64_t ld[4] = {K1 * dl, 0, 0, 0}, Ks[4] = {K1 * dl, 0, 0, 0};
         BG_TRY(bg_gemm_f32(0, 0, 3 * N, H2, 1, A, ld, Ks, Wl, H2, b.v[0], H2, nullptr, nullptr, BG_ACT_NONE, 0.f, nullptr, 0,

@@ -825,6 +825,13 @@ int bg_fill_f32(float* p, int64_t n, float value, bgStream stream);
  * same [mod, N] addend (bg_gemm_f32's pre_add_rows).  No reference counterpart (see bg_regroup_f32).            */
 int bg_iota_mod_i32(int32_t* out, int64_t n, int64_t mod, bgStream stream);
 
+/* bg_regroup_f32 (same arguments) and bg_iota_mod_i32 (idx[t] = t mod idx_mod for t < idx_n) in ONE launch: two independent
+ * writes that the critic head needs before its row-stacked product (the label powers per label set; the row of the
+ * label-free part that row r of the 3 N stacked rows adds).  Same values as the two calls.
+ * replaces: as bg_regroup_f32 and bg_iota_mod_i32.                                                               */
+int bg_regroup_iota_f32(const float* src, float* dst, int64_t n, int64_t K, int64_t P, int64_t W, int to_outer,
+                        int32_t* idx, int64_t idx_n, int64_t idx_mod, bgStream stream);
+
 /* out = a + b over n floats (n % 4 == 0, 16-byte aligned): the one elementwise sum the critic's backward needs
  * (the gradients of D(real) and D(fake) with respect to the shared label-free part).
  * replaces: autograd's gradient accumulation for a tensor used twice.                                      */

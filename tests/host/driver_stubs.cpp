@@ -307,6 +307,14 @@ int bg_iota_mod_i32(int32_t* out, int64_t n, int64_t mod, bgStream) {
     rec(28, a, sizeof(a) / 8);
     return 0;
 }
+// a marker (kind 48) followed by the two single calls it replaces
+int bg_regroup_iota_f32(const float* src, float* dst, int64_t n, int64_t K, int64_t P, int64_t W, int to_outer, int32_t* idx,
+                        int64_t idx_n, int64_t idx_mod, bgStream s) {
+    int64_t a[] = {2};
+    rec(48, a, 1);
+    bg_regroup_f32(src, dst, n, K, P, W, to_outer, s);
+    return bg_iota_mod_i32(idx, idx_n, idx_mod, s);
+}
 int bg_tile_f32(const float* src, float* dst, int64_t n, int64_t reps, bgStream) {
     int64_t a[] = {P(src), P(dst), n, reps};
     rec(34, a, sizeof(a) / 8);

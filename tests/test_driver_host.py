@@ -541,7 +541,7 @@ def _check_critic_calls(calls, R, h):
                 assert R.check(g_w2, Hd * f, tag) == "g_%s_w2" % which and R.check(g_b2, f, tag) == "g_%s_b2" % which
             else:                                         # frozen decoders (generator objective): d X only
                 assert (Rr, Rp) in ((B, 0), (S, 0)) and not (g_b1 or g_w2 or g_b2 or w1 or w2 or b1 or dgp)
-        elif kind in (43, 44, 45):
+        elif kind in (43, 44, 45, 48):
             assert a == [2], tag                          # a pair launcher's marker: its two single calls follow
         elif kind == 27:
             assert a == [2], tag                          # bg_fill_copy_batch's marker: its jobs follow as kind 20 / 25
@@ -589,7 +589,8 @@ def test_critic_head_host_sequence_and_extents(drv, N, S, B, basis):
     # 45 / 44 / 43: both decoders, both scatters, both gathers by one launch each (the stub lists the pair's two single
     # calls behind the marker)
     # 46: the penalty's chain reading the product's output as two column groups (no regrouping launch, kind 10, before it)
-    assert [k for k, _ in fwd] == [10, 1, 28, 1, 39, 39, 45, 38, 38, 12, 44, 13, 13, 1, 46, 15]
+    # 48: the regrouping of the label powers and the stacked rows' index by one launch (marker, then the two single calls)
+    assert [k for k, _ in fwd] == [48, 10, 28, 1, 1, 39, 39, 45, 38, 38, 12, 44, 13, 13, 1, 46, 15]
     # 37: a decoder's whole backward (penalty share included) as one launch; 40: real and fake scattered by one launch
     # (the voxel-level scatter also leaves the two sets' sum: no addition launch, kind 18, between the two products)
     # (27, 20, 20: block 0 of d X's two halves copied from d acc by one launch; 46 writes blocks 1 .. L in place)

@@ -1375,6 +1375,30 @@ def test_one_operator_on_several_matrices_in_one_launch(cuda, H, nb):
                                  out.data_ptr(), H, S * H, S, H, nb, st) == -1
 
 
+@pytest.mark.parametrize("n,K,P,W,idx_n,mod", [(11520, 13, 3, 8, 34560, 11520), (5, 2, 3, 4, 1000, 7), (0, 1, 1, 4, 9, 4)])
+def test_regroup_and_row_index_in_one_launch(cuda, n, K, P, W, idx_n, mod):
+    """bg_regroup_iota_f32 against bg_regroup_f32 + bg_iota_mod_i32 (more index entries than regrouped chunks, and the
+    other way round; no rows at all)."""
+    from building_gan_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(n + K)
+    src = torch.rand(max(n, 1) * K * P * W, generator=gen).to(cuda)
+    for to_outer in (1, 0):
+        want = torch.full_like(src, float("nan"))
+        widx = torch.full((idx_n,), -1, dtype=torch.int32, device=cuda)
+        if n:
+            assert lib.bg_regroup_f32(src.data_ptr(), want.data_ptr(), n, K, P, W, to_outer, st) == 0
+        assert lib.bg_iota_mod_i32(widx.data_ptr(), idx_n, mod, st) == 0
+        got = torch.full_like(src, float("nan"))
+        gidx = torch.full((idx_n,), -1, dtype=torch.int32, device=cuda)
+        assert lib.bg_regroup_iota_f32(src.data_ptr(), got.data_ptr(), n, K, P, W, to_outer, gidx.data_ptr(), idx_n, mod, st) == 0
+        assert torch.equal(gidx, widx) and torch.equal(gidx.cpu().long(), torch.arange(idx_n) % mod)
+        if n:
+            assert torch.equal(got, want)
+    assert lib.bg_regroup_iota_f32(src.data_ptr(), got.data_ptr(), max(n, 1), K, P, W, 1, None, 5, mod, st) == -1
+
+
 @pytest.mark.parametrize("n_rows,S,B,H", [(11520, 88, 8, 256), (301, 7, 2, 64), (40, 40, 1, 8)])
 def test_pair_launchers_equal_their_two_single_calls(cuda, n_rows, S, B, H):
     """bg_decoder_fwd_pair_f32, bg_scatter_arg_pair_f32, bg_gather_arg_pair_f32 (two independent small launches of the
