@@ -42,27 +42,45 @@ __global__ void k_hist(const int64_t* __restrict__ key, int64_t E, int64_t N,
 }
 
 // In-place inclusive scan of a[0..n) by ONE workgroup of 1024 threads (copy != NULL: a second copy of the result).
+// Tiles of 4,096 consecutive elements, four per thread: neighbouring lanes read neighbouring words (the first form gave
+// every thread ONE contiguous range of n / 1024 elements -- 4 KB apart between lanes at n = 10^6: 3.0 ms per scan of a
+// 1,048,576-voxel batch's row counts).  Integer sums: the result does not depend on the order of the additions.
 __device__ __forceinline__ void d_scan_inplace(int32_t* __restrict__ a, int64_t n, int32_t* __restrict__ copy) {
-    __shared__ int32_t part[1024];
-    const int t = threadIdx.x;
-    const int64_t per = (n + 1023) / 1024;
-    const int64_t b = (int64_t)t * per;
-    const int64_t e = (b + per < n) ? b + per : n;
-    int32_t s = 0;
-    for (int64_t i = b; i < e; ++i) s += a[i];
-    part[t] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int32_t v = (t >= off) ? part[t - off] : 0;
+    __shared__ int32_t wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int32_t carry = 0;
+    for (int64_t base = 0; base < n; base += 4096) {               // uniform trip count
+        const int64_t i0 = base + 4 * t;
+        int32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = i0 + k < n ? a[i0 + k] : 0;
+        v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+        int32_t x = v[3];                                          // inclusive scan of the threads' sums over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
         __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    int32_t run = part[t] - s;
-    for (int64_t i = b; i < e; ++i) {
-        run += a[i];
-        a[i] = run;
-        if (copy) copy[i] = run;
+        int32_t before = 0, tile = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int32_t sw = wsum[w];
+            if (w < wave) before += sw;
+            tile += sw;
+        }
+        const int32_t excl = carry + before + (x - v[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < n) {
+                const int32_t r = excl + v[k];
+                a[i0 + k] = r;
+                if (copy) copy[i0 + k] = r;
+            }
+        }
+        carry += tile;
+        __syncthreads();                                           // wsum is written again by the next tile
     }
 }
 

@@ -85,10 +85,18 @@ class VolumeDesignGraph:
         instead of behind everything queued on the current stream, so the next batch's plan runs beside the iteration
         in flight rather than after it.  Code that rewrites a batch's tensors with device ops afterwards must drop the
         attribute (or move the batch again)."""
+        moved = False
         for k in self.keys:
             v = getattr(self, k)
             if torch.is_tensor(v):
-                setattr(self, k, v.to(device, non_blocking=non_blocking))
+                w = v.to(device, non_blocking=non_blocking)
+                if w is not v:
+                    moved = True
+                    setattr(self, k, w)
+        if not moved:
+            # every tensor is where it was asked to be (util_eval's ``batch.to(device)`` on a resident batch): the same
+            # tensors, so the index plan built from them -- and a plan in flight -- stay valid
+            return self
         self.__dict__.pop("_bg_plan", None)  # device-side plans do not survive a move
         self.__dict__.pop("_bg_plan_pending", None)
         self.__dict__.pop("_bg_h2d_event", None)

@@ -154,8 +154,13 @@ def test_prefetched_plan_equals_direct_build_and_orders_the_consumer(cuda):
     _same(a, b, "plan", set())
     # moving the batch drops a pending plan like a finished one
     P.prefetch_plan(_drop(g))
+    g.to(cuda)                                                     # already there: nothing moves, the pending plan stays
+    assert "_bg_plan_pending" in g.__dict__
+    g.to("cpu")
     g.to(cuda)
     assert "_bg_plan_pending" not in g.__dict__ and "_bg_plan" not in g.__dict__
+    kept = P.build_plan(g)
+    assert g.to(cuda) is g and g.__dict__.get("_bg_plan") is kept  # a resident batch keeps its finished plan as well
     # no story count on the batch: the synchronous form, built on the CURRENT stream (it starts with a read-back, so
     # nothing would overlap, and its tensors must belong to the stream whose kernels read them)
     g.__dict__.pop("num_stories", None)
