@@ -352,8 +352,12 @@ __global__ void k_plan_misc(MiscJobs J) {
             }
             int32_t* stats = static_cast<int32_t*>(j.out);
             if ((threadIdx.x & 63) == 0) {
-                if (j.p0 >= 0 && d_min != 0x7fffffff) atomicMin(&stats[j.p0], d_min);
-                if (j.p1 >= 0) atomicMax(&stats[j.p1], d_max);
+                // (a minimum only falls and a maximum only rises, so a wave whose value cannot improve on the one it
+                //  reads -- possibly stale, hence a weaker bound -- has nothing to contribute: at 10^6 rows nearly every
+                //  wave, and 16 k atomics on one word are serialised)
+                const volatile int32_t* seen = stats;
+                if (j.p0 >= 0 && d_min != 0x7fffffff && d_min < seen[j.p0]) atomicMin(&stats[j.p0], d_min);
+                if (j.p1 >= 0 && d_max > seen[j.p1]) atomicMax(&stats[j.p1], d_max);
             }
         } break;
         case MJ_MAXI32: {
